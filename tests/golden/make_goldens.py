@@ -1,0 +1,246 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running THE REFERENCE ITSELF in the build
+container.  Run from the repo root:  python tests/golden/make_goldens.py
+
+The reference (/root/reference) is Python-2 / torch-0.3 source.  This script
+makes a throw-away transliteration under /tmp (never in the repo, never
+shipped), imports it, feeds it the seeded inputs of tests/inputs.py and the
+deterministic weights of oracle.model.deterministic_fill_, and stores inputs'
+seeds + the reference's outputs.  Steps:
+  1. copy the checkout to /tmp/ref3, drop stale *.pyc
+  2. lib2to3 fixers print/import/dict/xrange
+  3. restore py2 integer division where it matters (out_num/2, height / 4, res/10)
+  4. numpy-2 strictness: squeeze 1-element scale/rot arrays handed to GetTransform
+Only data (arrays) is written to the repo.
+"""
+import os
+import re
+import shutil
+import subprocess
+import sys
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, REPO)
+REF = '/root/reference'
+TMP = '/tmp/ref3_goldens'
+OUT = os.path.join(REPO, 'tests', 'golden')
+
+
+def transliterate():
+    if os.path.isdir(TMP):
+        shutil.rmtree(TMP)
+    shutil.copytree(REF, TMP)
+    for root, _, files in os.walk(TMP):
+        os.chmod(root, 0o755)
+        for f in files:
+            p = os.path.join(root, f)
+            os.chmod(p, 0o644)
+            if f.endswith('.pyc'):
+                os.remove(p)
+    subprocess.run([sys.executable, '-m', 'lib2to3', '-w', '-n', '-f', 'print', '-f', 'import',
+                    '-f', 'dict', '-f', 'xrange', TMP], check=True, capture_output=True)
+
+    def patch(rel, subs):
+        p = os.path.join(TMP, rel)
+        s = open(p).read()
+        for a, b in subs:
+            s, n = re.subn(a, b, s)
+            assert n > 0, (rel, a)
+        open(p, 'w').write(s)
+    patch('models/asn_stacked_hg.py', [(r'out_num/2', 'out_num//2'), (r'height / 4', 'height // 4')])
+    patch('pylib/HumanAcc.py', [(r'normalize = res/10', 'normalize = res//10')])
+    sys.path.insert(0, TMP)
+
+
+def load_ref():
+    transliterate()
+    import scipy.misc  # noqa: F401  (module exists; imresize/imrotate are not used here)
+    from pylib import HumanPts, HumanAug, Evaluation, HumanAcc, Criterion
+    from models import asn_stacked_hg
+    from utils import util
+
+    def squeeze_args(fn):
+        def w(center, scale, rot, res, size):
+            return fn(center, float(np.asarray(scale).reshape(-1)[0]), float(np.asarray(rot).reshape(-1)[0]), res, size)
+        return w
+    HumanAug.GetTransform = squeeze_args(HumanAug.GetTransform)
+    Evaluation.GetTransform = squeeze_args(Evaluation.GetTransform)
+    return dict(HumanPts=HumanPts, HumanAug=HumanAug, Evaluation=Evaluation, HumanAcc=HumanAcc,
+                Criterion=Criterion, M=asn_stacked_hg, util=util)
+
+
+def t(x):
+    return torch.from_numpy(np.ascontiguousarray(x))
+
+
+def gen_pylib(R):
+    from tests import inputs
+    HumanPts, HumanAug, Evaluation, HumanAcc = R['HumanPts'], R['HumanAug'], R['Evaluation'], R['HumanAcc']
+    out = {}
+    # --- heat maps (a7), incl. hand-picked edge cases (Appendix A.1)
+    special = np.array([[2.5, 2.5], [63.9, 63.9], [64.0, 64.0], [64.5, 10.0], [0.0, 0.0], [-1.0, 5.0],
+                        [0.4, 0.4], [3.0, 61.2], [32.0, 32.0], [10.7, 20.2], [1e-3, 30.0], [63.0, 0.5],
+                        [5.0, 64.0], [5.0, 64.01], [33.99, 2.01], [60.5, 60.5]])
+    hm, valid = HumanPts.pts2heatmap(special.copy(), [64, 64], sigma=1)
+    out['hm_special_pts'] = special
+    out['hm_special'] = hm.astype(np.float32)
+    out['hm_special_valid'] = valid
+    pts = inputs.heat_pts(11, 4)
+    hms = np.stack([HumanPts.pts2heatmap(pts[i].copy(), [64, 64], sigma=1)[0] for i in range(4)])
+    out['hm_pts'] = pts
+    out['hm_rand'] = hms[:2].astype(np.float32)          # first two samples stored in full
+    out['hm_rand_digest'] = np.array([[h.sum(), (h * h).sum(), h.max()] for h in hms.reshape(-1, 64, 64)])
+    # --- transforms (a8)
+    c, s, r, gpts, norm = inputs.person_meta(12, 6)
+    out['tf_c'], out['tf_s'], out['tf_r'], out['tf_pts'], out['tf_norm'] = c, s, r, gpts, norm
+    out['tf_T256'] = np.stack([HumanAug.GetTransform(c[i], s[i], r[i], 256, 200) for i in range(6)])
+    out['tf_T64'] = np.stack([HumanAug.GetTransform(c[i], s[i], r[i], 64, 200) for i in range(6)])
+    out['tf_pts64'] = np.stack([HumanAug.TransformPts(gpts[i], c[i], s[i], r[i], 64, 200) for i in range(6)])
+    out['tf_pts64_eval_inv'] = np.stack([
+        Evaluation.TransformPts(out['tf_pts64'][i] + 1, c[i], s[i], r[i], 64, 200, invert=1) for i in range(6)])
+    sh = np.stack([HumanAug.shufflelr(t(gpts[i].copy()), width=1280, dataset='mpii').numpy() for i in range(6)])
+    out['tf_shufflelr'] = sh
+    # --- argmax / PCKh (a11-a15) on heat maps built from the transformed joints
+    n = 6
+    tp = out['tf_pts64'].copy()
+    tp[gpts[..., 0] <= 0] = 0
+    tgt = np.stack([HumanPts.pts2heatmap(tp[i].copy(), [64, 64], sigma=1)[0] for i in range(n)]).astype(np.float32)
+    pred = inputs.noisy_heatmaps(13, tgt, noise=0.2)
+    pred[0, 3] = -1.0          # all-negative map -> zero prediction (Evaluation.py:21-22)
+    # inputs are regenerated from seeds by the tests (tests/inputs.py); only a checksum is stored
+    out['ev_pred_sum'] = np.array([pred.astype(np.float64).sum(), tgt.astype(np.float64).sum()])
+    out['ev_get_preds'] = Evaluation.get_preds(t(pred)).numpy()
+    idx = [0, 1, 2, 3, 4, 5, 10, 11, 14, 15]
+    out['ev_accuracy'] = Evaluation.accuracy(t(pred), t(tgt), idx).numpy()
+    cT, sT, rT = t(c).float(), t(s).float().view(n, 1), t(r).float().view(n, 1)
+    out['ev_final_preds'] = Evaluation.final_preds(t(pred), cT, sT, [64, 64], rT).numpy()
+    out['ev_acc_origin'] = Evaluation.accuracy_origin_res(t(pred), cT, sT, [64, 64], t(gpts).float(),
+                                                           t(norm).float(), rT).numpy()
+    out['ev_per_person'] = Evaluation.per_person_pckh(t(pred), t(tgt), cT, sT, [64, 64], t(gpts).float(),
+                                                      t(norm).float(), rT).numpy()
+    pp = out['ev_get_preds']
+    gp = Evaluation.get_preds(t(tgt)).numpy()
+    out['acc_approx_pckh'] = np.array(HumanAcc.approx_PCKh(t(pp), t(gp), idx, 64), dtype=np.float64)
+    out['flip_maps'] = HumanAug.shuffle_channels_for_horizontal_flipping(HumanAug.flip_channels(t(pred[:1].copy()))).numpy()
+    # --- loss (a6)
+    w = inputs.rng(14).random(pred.shape, dtype=np.float32) + 0.5
+    out['l2_weighted'] = np.array(float(R['Criterion'].weighted_L2(t(pred), t(tgt), t(w))))
+    out['l2_unit'] = np.array(float(R['Criterion'].weighted_L2(t(pred), t(tgt), torch.ones(1))))
+    # --- agent reward shaping (a18)
+    g = inputs.rng(15)
+    logits = g.normal(0, 1.5, (12, 7)).astype(np.float32)
+    p = torch.softmax(t(logits), 1)
+    p[3] = torch.tensor([0.9, 0.02, 0.02, 0.02, 0.02, 0.01, 0.01])      # forces the clamp branch
+    p[4] = torch.tensor([0.0, 0.0, 0.5, 0.5, 0.0, 0.0, 0.0])
+    ind = t(g.integers(0, 7, (12, 1)))
+    ind[3, 0] = 0
+    ind[4, 0] = 0
+    pk_reg = t(g.random(12).astype(np.float32))
+    pk_ag = t(g.random(12).astype(np.float32))
+    pk_ag[5] = pk_reg[5]
+    out['gg_p'] = p.numpy(); out['gg_idx'] = ind.numpy()
+    out['gg_reg'] = pk_reg.numpy(); out['gg_agent'] = pk_ag.numpy()
+    out['gg_out'] = R['util'].gen_groundtruth(p, ind, pk_reg, pk_ag).numpy()
+    np.savez_compressed(os.path.join(OUT, 'pylib.npz'), **out)
+    print('pylib.npz', len(out), 'arrays')
+
+
+def digest(tensors):
+    """per-tensor [sum, l2, first, last] -- compact fingerprint of a list of tensors."""
+    return np.array([[float(x.sum()), float(x.norm()), float(x.flatten()[0]), float(x.flatten()[-1])]
+                     for x in tensors], dtype=np.float64)
+
+
+def gen_nets(R):
+    from tests import inputs
+    from oracle.model import deterministic_fill_
+    from oracle import pylib as opl
+    M = R['M']
+    torch.set_num_threads(8)
+    # --- one residual block, fwd + bwd (a1)
+    blk = M._Residual(32, 32)
+    deterministic_fill_(blk, seed=21)
+    blk.train()
+    x = t(inputs.rng(22).standard_normal((2, 32, 8, 8)).astype(np.float32)).requires_grad_(True)
+    y = blk(x)
+    gy = t(inputs.rng(23).standard_normal((2, 32, 8, 8)).astype(np.float32))
+    y.backward(gy)
+    np.savez_compressed(os.path.join(OUT, 'residual.npz'), y=y.detach().numpy(), dx=x.grad.numpy(),
+                        grads=np.concatenate([p.grad.flatten().numpy() for p in blk.parameters()]),
+                        running=np.concatenate([b.flatten().float().numpy() for b in blk.buffers()]))
+    # --- small 1-stack net: every gradient and the post-RMSprop parameters (a2,a3,a6,a19)
+    for tag, (stacks, chan, seed) in {'hg_s1c8': (1, 8, 31), 'hg_s2c16': (2, 16, 32)}.items():
+        net = M.create_hg(num_stacks=stacks, num_modules=1, num_classes=16, chan=chan)
+        deterministic_fill_(net, seed=seed)
+        net.train()
+        img = t(inputs.images(seed + 100, 2, 128))
+        pts = inputs.heat_pts(seed + 200, 2, res=32)
+        heat = t(inputs.heatmaps_from_pts(pts, res=32))
+        assert np.array_equal(heat.numpy(), np.stack(
+            [R['HumanPts'].pts2heatmap(pts[i].copy(), [32, 32])[0] for i in range(2)]).astype(np.float32))
+        opt = torch.optim.RMSprop(net.parameters(), lr=2.5e-4, alpha=0.99, eps=1e-8, momentum=0, weight_decay=0)
+        out = net(img)
+        loss = 0
+        for o in out:
+            d = (o - heat) ** 2
+            loss = loss + d.sum() / d.numel()
+        opt.zero_grad()
+        loss.backward()
+        grads = [p.grad.clone() for p in net.parameters()]
+        opt.step()
+        acc = R['Evaluation'].accuracy(out[-1].detach(), heat, [0, 1, 2, 3, 4, 5, 10, 11, 14, 15])
+        rec = dict(out=np.stack([o.detach().numpy() for o in out]), loss=np.array(float(loss)),
+                   grad_digest=digest(grads), param_digest=digest([p.detach() for p in net.parameters()]),
+                   buf_digest=digest([b.float() for b in net.buffers()]), acc=acc.numpy(),
+                   nparams=np.array(sum(p.numel() for p in net.parameters())))
+        if tag == 'hg_s1c8':
+            rec['grads'] = np.concatenate([g.flatten().numpy() for g in grads])
+        # eval-mode forward with the updated running stats
+        net.eval()
+        with torch.no_grad():
+            rec['out_eval'] = np.stack([o.numpy() for o in net(img)])
+        np.savez_compressed(os.path.join(OUT, tag + '.npz'), **rec)
+        print(tag, rec['nparams'], 'params, loss', float(loss))
+    # --- agent: half-hourglass logits, KL loss, agent gradients only (a4,a5,a17)
+    net = M.create_hg(num_stacks=2, num_modules=1, num_classes=16, chan=16)
+    asn = M.create_asn(chan_in=16, chan_out=16, scale_num=7, rotation_num=7, is_aug=True)
+    deterministic_fill_(net, seed=41)
+    deterministic_fill_(asn, seed=42)
+    net.eval()
+    asn.train()
+    img = t(inputs.images(141, 2, 256))
+    ls, lr = net(img, asn, is_half_hg=True, is_aug=True)
+    ps, pr = torch.softmax(ls, 1), torch.softmax(lr, 1)
+    g = inputs.rng(43)
+    idx_s, idx_r = t(g.integers(0, 7, (2, 1))), t(g.integers(0, 7, (2, 1)))
+    reg, ag = t(g.random(2).astype(np.float32)), t(g.random(2).astype(np.float32))
+    gs = R['util'].gen_groundtruth(ps, idx_s, reg, ag)
+    gr = R['util'].gen_groundtruth(pr, idx_r, ag, reg)
+    import torch.nn.functional as F
+    loss = F.kl_div(torch.log(ps + 1e-7), gs, reduction='mean') * 7 + \
+        F.kl_div(torch.log(pr + 1e-7), gr, reduction='mean') * 7       # torch-0.3 default = element mean
+    net.zero_grad(); asn.zero_grad()
+    loss.backward()
+    assert all(p.grad is None for p in net.parameters())               # features are detached (:161-162)
+    np.savez_compressed(os.path.join(OUT, 'asn_c16.npz'), logits_s=ls.detach().numpy(), logits_r=lr.detach().numpy(),
+                        idx_s=idx_s.numpy(), idx_r=idx_r.numpy(), reg=reg.numpy(), ag=ag.numpy(),
+                        gs=gs.numpy(), gr=gr.numpy(), loss=np.array(float(loss)),
+                        grad_digest=digest([p.grad for p in asn.parameters()]),
+                        nparams=np.array(sum(p.numel() for p in asn.parameters())))
+    print('asn', float(loss))
+    # full-size parameter counts: 6 570 784 / 2 577 934
+    n_hg = sum(p.numel() for p in M.create_hg(2, 1, 16, 256).parameters())
+    n_asn = sum(p.numel() for p in M.create_asn(256, 256, 7, 7, is_aug=True).parameters())
+    keys = list(M.create_hg(2, 1, 16, 256).state_dict().keys())
+    np.savez_compressed(os.path.join(OUT, 'census.npz'), n_hg=np.array(n_hg), n_asn=np.array(n_asn),
+                        hg_keys=np.array(keys))
+    print('census', n_hg, n_asn, len(keys))
+
+
+if __name__ == '__main__':
+    R = load_ref()
+    gen_pylib(R)
+    gen_nets(R)

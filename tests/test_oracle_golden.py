@@ -1,0 +1,190 @@
+"""Pins the CPU oracle (oracle/) against golden vectors produced by the
+reference itself (tests/golden/make_goldens.py).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import model as om
+from oracle import pylib as opl
+from oracle import step as ostep
+from tests import inputs
+
+G = os.path.join(os.path.dirname(__file__), 'golden')
+
+
+def load(name):
+    return np.load(os.path.join(G, name), allow_pickle=False)
+
+
+def t(x):
+    return torch.from_numpy(np.ascontiguousarray(x))
+
+
+def digest(tensors):
+    return np.array([[float(x.sum()), float(x.norm()), float(x.flatten()[0]), float(x.flatten()[-1])]
+                     for x in tensors], dtype=np.float64)
+
+
+# ------------------------------------------------------------------ pylib
+def test_heatmap_special_and_random():
+    g = load('pylib.npz')
+    hm, valid = opl.pts2heatmap(g['hm_special_pts'].copy(), [64, 64])
+    assert np.array_equal(hm.astype(np.float32), g['hm_special'])
+    assert np.array_equal(valid, g['hm_special_valid'])
+    # Appendix A.1 facts
+    assert hm[0].argmax() == 3 * 64 + 3 and (hm[1] > 0).sum() == 16 and hm[3].sum() == 0
+    pts = inputs.heat_pts(11, 4)
+    assert np.array_equal(pts, g['hm_pts'])
+    hms = np.stack([opl.pts2heatmap(pts[i].copy(), [64, 64])[0] for i in range(4)])
+    assert np.array_equal(hms[:2].astype(np.float32), g['hm_rand'])
+    dg = np.array([[h.sum(), (h * h).sum(), h.max()] for h in hms.reshape(-1, 64, 64)])
+    assert np.allclose(dg, g['hm_rand_digest'], rtol=0, atol=1e-12)
+
+
+def test_transforms():
+    g = load('pylib.npz')
+    c, s, r, pts = g['tf_c'], g['tf_s'], g['tf_r'], g['tf_pts']
+    c2, s2, r2, p2, n2 = inputs.person_meta(12, 6)
+    assert np.array_equal(c, c2) and np.array_equal(pts, p2) and np.array_equal(g['tf_norm'], n2)
+    for i in range(6):
+        assert np.array_equal(opl.get_transform(c[i], s[i], r[i], 256), g['tf_T256'][i])
+        assert np.array_equal(opl.get_transform(c[i], s[i], r[i], 64), g['tf_T64'][i])
+        p64 = opl.transform_pts(pts[i], c[i], s[i], r[i], 64)
+        assert np.array_equal(p64, g['tf_pts64'][i])
+        back = opl.transform_pts_eval(p64 + 1, c[i], s[i], r[i], 64, invert=1)
+        assert np.array_equal(back, g['tf_pts64_eval_inv'][i])
+        assert np.array_equal(opl.shufflelr(pts[i], 1280), g['tf_shufflelr'][i])
+
+
+def _eval_inputs(g):
+    c, s, r, gpts, norm = g['tf_c'], g['tf_s'], g['tf_r'], g['tf_pts'], g['tf_norm']
+    tp = g['tf_pts64'].copy()
+    tp[gpts[..., 0] <= 0] = 0
+    tgt = inputs.heatmaps_from_pts(tp, 64)
+    pred = inputs.noisy_heatmaps(13, tgt, noise=0.2)
+    pred[0, 3] = -1.0
+    assert np.allclose([pred.astype(np.float64).sum(), tgt.astype(np.float64).sum()], g['ev_pred_sum'], atol=1e-6)
+    return c, s, r, gpts, norm, tgt, pred
+
+
+def test_evaluation_and_humanacc():
+    g = load('pylib.npz')
+    c, s, r, gpts, norm, tgt, pred = _eval_inputs(g)
+    n = 6
+    idx = [0, 1, 2, 3, 4, 5, 10, 11, 14, 15]
+    assert np.array_equal(opl.get_preds(t(pred)).numpy(), g['ev_get_preds'])
+    assert np.allclose(opl.accuracy(t(pred), t(tgt), idx).numpy(), g['ev_accuracy'], atol=1e-7)
+    cT, sT, rT = t(c).float(), t(s).float().view(n, 1), t(r).float().view(n, 1)
+    assert np.array_equal(opl.final_preds(t(pred), cT, sT, [64, 64], rT).numpy(), g['ev_final_preds'])
+    a = opl.accuracy_origin_res(t(pred), cT, sT, [64, 64], t(gpts).float(), t(norm).float(), rT)
+    assert np.allclose(a.numpy(), g['ev_acc_origin'], atol=1e-7)
+    pp = opl.per_person_pckh(t(pred), t(tgt), cT, sT, [64, 64], t(gpts).float(), t(norm).float(), rT)
+    assert np.allclose(pp.numpy(), g['ev_per_person'], atol=1e-7)
+    pk = opl.approx_pckh(opl.get_preds(t(pred)), opl.get_preds(t(tgt)), idx, 64)
+    assert abs(pk - float(g['acc_approx_pckh'])) < 1e-7
+    assert np.array_equal(opl.flip_heatmaps(t(pred[:1].copy())).numpy(), g['flip_maps'])
+
+
+def test_losses_and_reward_shaping():
+    g = load('pylib.npz')
+    _, _, _, _, _, tgt, pred = _eval_inputs(g)
+    w = inputs.rng(14).random(pred.shape, dtype=np.float32) + 0.5
+    assert abs(float(opl.weighted_l2(t(pred), t(tgt), t(w))) - float(g['l2_weighted'])) < 1e-7
+    assert abs(float(opl.weighted_l2(t(pred), t(tgt), torch.ones(1))) - float(g['l2_unit'])) < 1e-7
+    assert abs(float(opl.stack_mse([t(pred)], t(tgt))) - float(g['l2_unit'])) < 1e-7
+    out = opl.gen_groundtruth(t(g['gg_p']), t(g['gg_idx']), t(g['gg_reg']), t(g['gg_agent']))
+    assert np.allclose(out.numpy(), g['gg_out'], atol=1e-7)
+
+
+# ------------------------------------------------------------------- nets
+def test_residual_block():
+    g = load('residual.npz')
+    blk = om.Residual(32, 32)
+    om.deterministic_fill_(blk, seed=21)
+    blk.train()
+    x = t(inputs.rng(22).standard_normal((2, 32, 8, 8)).astype(np.float32)).requires_grad_(True)
+    y = blk(x)
+    y.backward(t(inputs.rng(23).standard_normal((2, 32, 8, 8)).astype(np.float32)))
+    assert np.allclose(y.detach().numpy(), g['y'], atol=1e-6)
+    assert np.allclose(x.grad.numpy(), g['dx'], atol=1e-6)
+    assert np.allclose(np.concatenate([p.grad.flatten().numpy() for p in blk.parameters()]), g['grads'], atol=1e-5)
+    assert np.allclose(np.concatenate([b.flatten().float().numpy() for b in blk.buffers()]), g['running'], atol=1e-6)
+
+
+@pytest.mark.parametrize('tag,stacks,chan,seed', [('hg_s1c8', 1, 8, 31), ('hg_s2c16', 2, 16, 32)])
+def test_hourglass_train_step(tag, stacks, chan, seed):
+    g = load(tag + '.npz')
+    torch.set_num_threads(8)
+    net = om.create_hg(stacks, 1, 16, chan)
+    assert sum(p.numel() for p in net.parameters()) == int(g['nparams'])
+    om.deterministic_fill_(net, seed=seed)
+    net.train()
+    img = t(inputs.images(seed + 100, 2, 128))
+    heat = t(inputs.heatmaps_from_pts(inputs.heat_pts(seed + 200, 2, res=32), res=32))
+    opt = ostep.make_optimizer(net)
+    out, loss = ostep.pose_loss_and_grads(net, img, heat)
+    grads = [p.grad.clone() for p in net.parameters()]
+    opt.step()
+    assert np.allclose(np.stack([o.detach().numpy() for o in out]), g['out'], atol=2e-5)
+    assert abs(float(loss) - float(g['loss'])) < 1e-6
+    assert np.allclose(digest(grads), g['grad_digest'], rtol=1e-3, atol=1e-6)
+    if 'grads' in g:
+        assert np.allclose(np.concatenate([x.flatten().numpy() for x in grads]), g['grads'], rtol=1e-3, atol=1e-7)
+    # RMSprop's first step is ~ +-10 lr * sign(g): near-zero gradients (biases in front of a
+    # BN) are rounding noise whose sign is not reproducible, so compare digests loosely ...
+    assert np.allclose(digest([p.detach() for p in net.parameters()])[:, 1], g['param_digest'][:, 1], rtol=2e-2, atol=1e-3)
+    assert np.allclose(digest([b.float() for b in net.buffers()]), g['buf_digest'], rtol=1e-4, atol=1e-5)
+    acc = opl.accuracy(out[-1].detach(), heat, [0, 1, 2, 3, 4, 5, 10, 11, 14, 15])
+    assert np.allclose(acc.numpy(), g['acc'], atol=1e-6)
+    net.eval()
+    with torch.no_grad():
+        oe = np.stack([o.numpy() for o in net(img)])
+    assert np.allclose(oe, g['out_eval'], rtol=1e-3, atol=2e-3)
+
+
+def test_rmsprop_update_matches_torch():
+    p = t(inputs.rng(51).standard_normal(1000).astype(np.float32))
+    gr = t(inputs.rng(52).standard_normal(1000).astype(np.float32))
+    q = torch.nn.Parameter(p.clone())
+    opt = torch.optim.RMSprop([q], lr=2.5e-4, alpha=0.99, eps=1e-8)
+    v = torch.zeros_like(p)
+    for _ in range(3):
+        q.grad = gr.clone()
+        opt.step()
+        ostep.rmsprop_update(p, gr, v, 2.5e-4)
+    assert torch.equal(p, q.detach())
+
+
+def test_agent_half_hourglass():
+    g = load('asn_c16.npz')
+    net = om.create_hg(2, 1, 16, 16)
+    asn = om.create_asn(16, 16, 7, 7, is_aug=True)
+    assert sum(p.numel() for p in asn.parameters()) == int(g['nparams'])
+    om.deterministic_fill_(net, seed=41)
+    om.deterministic_fill_(asn, seed=42)
+    net.eval(); asn.train()
+    img = t(inputs.images(141, 2, 256))
+    ls, lr = ostep.agent_logits(net, asn, img)
+    assert np.allclose(ls.detach().numpy(), g['logits_s'], atol=1e-5)
+    assert np.allclose(lr.detach().numpy(), g['logits_r'], atol=1e-5)
+    ps, pr = torch.softmax(ls, 1), torch.softmax(lr, 1)
+    gs = opl.gen_groundtruth(ps, t(g['idx_s']), t(g['reg']), t(g['ag']))
+    gr = opl.gen_groundtruth(pr, t(g['idx_r']), t(g['ag']), t(g['reg']))
+    assert np.allclose(gs.numpy(), g['gs'], atol=1e-6) and np.allclose(gr.numpy(), g['gr'], atol=1e-6)
+    loss = ostep.agent_kl_loss(ls, lr, gs, gr)
+    assert abs(float(loss) - float(g['loss'])) < 1e-6
+    net.zero_grad(); asn.zero_grad()
+    loss.backward()
+    assert all(p.grad is None for p in net.parameters())
+    assert np.allclose(digest([p.grad for p in asn.parameters()]), g['grad_digest'], rtol=1e-3, atol=1e-7)
+
+
+def test_census_full_size():
+    g = load('census.npz')
+    net = om.create_hg(2, 1, 16, 256)
+    assert sum(p.numel() for p in net.parameters()) == int(g['n_hg']) == 6570784
+    assert list(net.state_dict().keys()) == [str(k) for k in g['hg_keys']]
+    asn = om.create_asn(256, 256, 7, 7, is_aug=True)
+    assert sum(p.numel() for p in asn.parameters()) == int(g['n_asn']) == 2577934
