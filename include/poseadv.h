@@ -1,0 +1,150 @@
+/* poseadv.h -- C ABI of libposeadv_hip.so: the MI355X (gfx950) hot path of the stacked-hourglass
+ * pose trainer with adversarial scale/rotation augmentation.
+ *
+ * Conventions:
+ *   - every function returns 0 on success, otherwise a hipError_t / library error code;
+ *     pa_last_error() gives the message.  No C++ exception crosses the ABI.
+ *   - all pointers are CALLER-OWNED DEVICE pointers unless the name ends in _host; the library
+ *     never allocates persistent device memory: a network runs inside one caller-provided workspace
+ *     whose size comes from pa_net_workspace_bytes().
+ *   - calls are asynchronous on the given hipStream_t (passed as void*); one host thread per net.
+ *   - activations are NHWC bf16 inside the library; the entry points that mirror the reference's
+ *     Python signatures take/return NCHW fp32 exactly like the reference's torch tensors.
+ *
+ * Each entry point cites the reference interface it replaces (paths relative to the reference
+ * checkout zhiqiangdon/pose-adv-aug).
+ */
+#ifndef POSEADV_H
+#define POSEADV_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char* pa_last_error(void);
+int pa_version(void);
+
+/* ---------------------------------------------------------------- pose library (pylib/) ---- */
+
+/* HumanPts.pts2heatmap (pylib/HumanPts.py:36-46) + draw_gaussian (:82-116), batched.
+ * pts: [B][J][2] float64 (x, y) in heat-map pixels; out: [B][J][H][W] fp32. */
+int pa_gaussian_heatmap(const double* pts, float* out, int B, int J, int H, int W, void* stream);
+
+/* Criterion.weighted_L2 (pylib/Criterion.py:12-18); weight may be NULL (== 1), which is the inline
+ * loss term of stack-hg.py:156-159.  *loss (fp32, device) is ACCUMULATED into: zero it first. */
+int pa_weighted_l2(const float* pred, const float* gt, const float* weight, size_t n, float* loss, void* stream);
+
+/* Evaluation.get_preds (pylib/Evaluation.py:6-23): maps [B][J][H][W] fp32 -> preds [B][J][2]
+ * (1-based x, y; zero where the maximum is <= 0).  maxval [B][J] may be NULL. */
+int pa_get_preds(const float* maps, int B, int J, int H, int W, float* preds, float* maxval, void* stream);
+
+/* Evaluation.final_preds (pylib/Evaluation.py:169-193 + transform_preds :195-211 + TransformPts
+ * :240-248): quarter-pixel refinement, +0.5, back-projection to original-image pixels (integer
+ * valued).  center [B][2], scale [B], rot [B] fp32; out [B][J][2] fp32. */
+int pa_final_preds(const float* maps, const float* center, const float* scale, const float* rot,
+                   int B, int J, int H, int W, float* out, float* scratch_preds, void* stream);
+
+/* PCK from point sets: Evaluation.calc_dists/dist_acc/accuracy (pylib/Evaluation.py:25-75; boundary
+ * 1), accuracy_origin_res (:77-97; boundary 0), per_person_pckh (:99-167; `person` output with the
+ * visibility points `vis`), HumanAcc.approx_PCKh (pylib/HumanAcc.py:7-44; boundary 0, norm = res/10
+ * with Python-2 integer division done by the caller).
+ * pred, gt: [B][J][2]; norm: [B]; idxs: int32 [nidx] (device); acc: [nidx+1] or NULL;
+ * person: [B] or NULL; vis: [B][J][2] or NULL; dists: [J][B] (calc_dists' matrix) or NULL. */
+int pa_pck(const float* pred, const float* gt, const float* norm, float boundary, const int32_t* idxs, int nidx,
+           float thr, const float* vis, int B, int J, float* acc, float* person, float* dists, void* stream);
+
+/* HumanAug.GetTransform (pylib/HumanAug.py:10-35) for a batch: params [B][8] fp32 =
+ * {cx, cy, scale, rot_deg, flip, gain_r, gain_g, gain_b}; t_out [B][6] float64 = forward transform
+ * at res_out (first two rows), tinv_in [B][6] = INVERSE transform at res_in (what the warp samples with). */
+int pa_affine_params(const float* params, int B, int res_in, int res_out, double* t_out, double* tinv_in, void* stream);
+
+/* HumanAug.TransformPts (pylib/HumanAug.py:45-54) + shufflelr (:236-257) + the invalid-joint rule of
+ * data/mpii_for_mpii.py:142-146.  pts [B][J][2] fp32 image pixels -> out [B][J][2] float64 heat-map
+ * coords (0 for invalid joints); pts_img (optional) = mirrored/swapped image-space joints. */
+int pa_transform_pts(const float* pts, const float* params, const double* t, int B, int J, float width,
+                     double* out, float* pts_img, void* stream);
+
+/* HumanAug.crop (pylib/HumanAug.py:117-176) + flip / colour gain of data/mpii_for_mpii.py:126-135 as
+ * one inverse-affine bilinear gather.  src: uint8 [B][Hs][Ws][3]; out4: bf16 [B][res][res][4]
+ * (network input layout, 4th channel 0) and/or outf: fp32 [B][3][res][res]; either may be NULL. */
+int pa_affine_warp_bilinear(const uint8_t* src, int Hs, int Ws, const double* tinv, const float* params,
+                            int B, int res, void* out4, float* outf, void* stream);
+
+/* augmentation laws: mode 0 = data/mpii_for_mpii.py:119-135 (regular), 1 = agent bins
+ * (data/joint_train_s_r_agent.py:15-16,33-36,134-139), 2 = agent scale only, 3 = agent rotation only.
+ * meta [B][4] = {objpos_x, objpos_y, scale, frame_width}; params [B][8] as above. */
+int pa_sample_aug(const float* meta, const int32_t* scale_idx, const int32_t* rot_idx, int mode,
+                  uint64_t seed, uint64_t step, int B, float* params, void* stream);
+
+/* softmax + np.random.choice(K, p) of joint-train-pose-s-r-agent.py:252-271.  logits [B][K];
+ * probs [B][K] and idx int32 [B] may be NULL. */
+int pa_sample_categorical(const float* logits, int B, int K, uint64_t seed, uint64_t step, unsigned slot,
+                          float* probs, int32_t* idx, void* stream);
+
+/* torch.optim.RMSprop(alpha, eps, momentum=0) step (stack-hg.py:51-52) on flat fp32 arrays;
+ * gscale multiplies the gradient first (1/world after a sum all-reduce). */
+int pa_rmsprop_step(float* param, const float* grad, float* square_avg, size_t n, float lr, float alpha,
+                    float eps, float gscale, void* stream);
+
+/* ---------------------------------------------------------------- operator level ---------- */
+/* One residual bottleneck block _Residual(C, C) (models/asn_stacked_hg.py:11-49), forward + backward,
+ * NCHW fp32 in/out, parameters in the block's own state_dict order (flat fp32).  Used by the parity
+ * tests; the networks below run the same kernels.  ws: zero-filled workspace of
+ * pa_residual_workspace_bytes(). */
+size_t pa_residual_workspace_bytes(int B, int H, int W, int C);
+int pa_residual_fwd_bwd(const float* x, const float* dy, const float* params, float* y, float* dx, float* grads,
+                        float* buffers, int B, int C, int H, int W, void* ws, void* stream);
+
+/* NCHW fp32 <-> NHWC bf16 */
+int pa_nchw_to_nhwc(const float* src, void* dst_bf16, int B, int C, int H, int W, void* stream);
+int pa_nhwc_to_nchw(const void* src_bf16, float* dst, int B, int C, int H, int W, void* stream);
+
+/* ---------------------------------------------------------------- networks ---------------- */
+typedef struct pa_net pa_net;
+
+/* create_hg(num_stacks, num_modules=1, num_classes=16, chan) (models/asn_stacked_hg.py:344-347) for a
+ * fixed per-GPU batch B and input resolution res (256).  chan must be a multiple of 128. */
+pa_net* pa_hg_create(int num_stacks, int num_classes, int chan, int B, int res);
+/* create_asn(chan, chan, scale_num, rotation_num, is_aug=True) (models/asn_stacked_hg.py:441-444) bound
+ * to the feature shapes of a pose net with neck resolution res/64. */
+pa_net* pa_asn_create(int chan, int scale_num, int rotation_num, int B, int res);
+void pa_net_destroy(pa_net* net);
+
+/* state_dict description (names, shapes, offsets) in the reference's registration order */
+int pa_net_num_tensors(const pa_net* net);
+/* kind: 0 parameter (offset into the flat parameter array), 1 running_mean/var (offset into the flat
+ * buffer array), 2 num_batches_tracked (no storage in the library) */
+int pa_net_tensor_info(const pa_net* net, int i, char* name, int name_cap, int* shape4, int* ndim,
+                       size_t* offset, size_t* numel, int* kind);
+size_t pa_net_param_floats(const pa_net* net);
+size_t pa_net_buffer_floats(const pa_net* net);
+size_t pa_net_workspace_bytes(const pa_net* net);
+
+/* params / grads / buffers: flat fp32 device arrays of pa_net_param_floats / pa_net_buffer_floats;
+ * workspace: pa_net_workspace_bytes bytes, ZERO-FILLED by the caller once. */
+int pa_net_bind(pa_net* net, float* params, float* grads, float* buffers, void* workspace, void* stream);
+/* refresh the bf16 compute copies of the weights (after load_state_dict / an optimizer step) */
+int pa_net_prepare_weights(pa_net* net);
+
+/* _Hourglass_Wrapper.forward (models/asn_stacked_hg.py:282-342) + loss (stack-hg.py:156-159).
+ * img: NCHW fp32 [B][3][res][res], or img4: bf16 NHWC4 from pa_affine_warp_bilinear (one of them).
+ * pts: [B][16][2] float64 heat-map coordinates of the target joints, or NULL (no loss).
+ * train != 0: BatchNorm uses batch statistics and updates the running estimates.
+ * loss_per_stack: device fp32 [num_stacks] or NULL. */
+int pa_hg_forward(pa_net* net, const float* img, const void* img4, const double* pts, int train, float* loss_per_stack);
+/* heat maps of stack i: NHWC fp32 [B][H/4][W/4][16] inside the workspace (valid until the next forward) */
+const float* pa_hg_heatmap_nhwc(const pa_net* net, int stack);
+/* copy stack i's heat maps out as NCHW fp32 [B][16][res/4][res/4] (the reference's output tensors) */
+int pa_hg_heatmap_nchw(pa_net* net, int stack, float* out);
+/* loss.backward() (stack-hg.py:164): fills the flat gradient array bound with pa_net_bind */
+int pa_hg_backward(pa_net* net);
+
+/* Evaluation.accuracy (pylib/Evaluation.py:54-75) of stack i's heat maps against the Gaussian target
+ * of the joints given to the last forward: acc [nidx+1]. */
+int pa_hg_accuracy(pa_net* net, int stack, const int32_t* idxs, int nidx, float* acc, float* scratch);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,116 @@
+"""ctypes binding of libposeadv_hip.so (C ABI: include/poseadv.h).
+
+The HIP library IS the product path: if it is missing or fails to load this module raises --
+there is no CPU fallback anywhere in the package."""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libposeadv_hip.so')
+
+
+class PoseAdvError(RuntimeError):
+    pass
+
+
+def build(verbose=False):
+    """Compile the HIP sources for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    import subprocess
+    r = subprocess.run(['bash', os.path.join(_HERE, 'csrc', 'build.sh')], capture_output=True, text=True)
+    if verbose or r.returncode != 0:
+        print(r.stdout[-4000:])
+        print(r.stderr[-4000:])
+    if r.returncode != 0:
+        raise PoseAdvError('building libposeadv_hip.so failed')
+    return LIB_PATH
+
+
+_lib = None
+
+_vp, _i, _f, _sz, _u64 = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_uint64
+
+_PROTOS = {
+    'pa_last_error': (C.c_char_p, []),
+    'pa_version': (_i, []),
+    'pa_gaussian_heatmap': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    'pa_weighted_l2': (_i, [_vp, _vp, _vp, _sz, _vp, _vp]),
+    'pa_get_preds': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    'pa_final_preds': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    'pa_pck': (_i, [_vp, _vp, _vp, _f, _vp, _i, _f, _vp, _i, _i, _vp, _vp, _vp, _vp]),
+    'pa_affine_params': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
+    'pa_transform_pts': (_i, [_vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp]),
+    'pa_affine_warp_bilinear': (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _vp]),
+    'pa_sample_aug': (_i, [_vp, _vp, _vp, _i, _u64, _u64, _i, _vp, _vp]),
+    'pa_sample_categorical': (_i, [_vp, _i, _i, _u64, _u64, C.c_uint, _vp, _vp, _vp]),
+    'pa_rmsprop_step': (_i, [_vp, _vp, _vp, _sz, _f, _f, _f, _f, _vp]),
+    'pa_residual_workspace_bytes': (_sz, [_i, _i, _i, _i]),
+    'pa_residual_fwd_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    'pa_nchw_to_nhwc': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    'pa_nhwc_to_nchw': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    'pa_hg_create': (_vp, [_i, _i, _i, _i, _i]),
+    'pa_asn_create': (_vp, [_i, _i, _i, _i, _i]),
+    'pa_net_destroy': (None, [_vp]),
+    'pa_net_num_tensors': (_i, [_vp]),
+    'pa_net_tensor_info': (_i, [_vp, _i, C.c_char_p, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_sz), C.POINTER(_sz),
+                                C.POINTER(_i)]),
+    'pa_net_param_floats': (_sz, [_vp]),
+    'pa_net_buffer_floats': (_sz, [_vp]),
+    'pa_net_workspace_bytes': (_sz, [_vp]),
+    'pa_net_bind': (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    'pa_net_prepare_weights': (_i, [_vp]),
+    'pa_hg_forward': (_i, [_vp, _vp, _vp, _vp, _i, _vp]),
+    'pa_hg_heatmap_nhwc': (_vp, [_vp, _i]),
+    'pa_hg_heatmap_nchw': (_i, [_vp, _i, _vp]),
+    'pa_hg_backward': (_i, [_vp]),
+    'pa_hg_accuracy': (_i, [_vp, _i, _vp, _i, _vp, _vp]),
+}
+
+EXPORTS = sorted(_PROTOS)
+
+
+def lib():
+    """The loaded library; raises PoseAdvError (never falls back) when it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.isfile(LIB_PATH):
+            raise PoseAdvError('%s not found: run `python -c "import __graft_entry__ as g; g.build()"` '
+                               '(there is no CPU fallback)' % LIB_PATH)
+        try:
+            l = C.CDLL(LIB_PATH)
+        except OSError as e:
+            raise PoseAdvError('cannot load %s: %s' % (LIB_PATH, e))
+        for name, (res, args) in _PROTOS.items():
+            fn = getattr(l, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(rc, what=''):
+    if rc != 0:
+        msg = lib().pa_last_error()
+        raise PoseAdvError('%s failed (code %d): %s' % (what or 'libposeadv_hip call', rc, msg.decode() if msg else ''))
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL).  Tensors must be contiguous CUDA(HIP) tensors."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise PoseAdvError('expected a GPU tensor: the pose-adv-aug hot path runs only on the HIP device')
+    if not t.is_contiguous():
+        raise PoseAdvError('expected a contiguous tensor')
+    return C.c_void_p(t.data_ptr())
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise PoseAdvError('no HIP device visible: pose_adv_aug_amd has no CPU path')
+    lib()

@@ -1,0 +1,209 @@
+// extern "C" boundary of libposeadv_hip.so (declared in include/poseadv.h).
+#include "../../include/poseadv.h"
+#include "net.h"
+#include <stdio.h>
+#include <string.h>
+#include <new>
+
+static thread_local char g_err[1024] = "";
+void pa_set_error(const char* what, hipError_t e, const char* file, int line) {
+    snprintf(g_err, sizeof g_err, "%s:%d: %s -> %s", file, line, what, hipGetErrorString(e));
+}
+void pa_set_error_msg(const char* msg) { snprintf(g_err, sizeof g_err, "%s", msg); }
+
+struct pa_net { Net n; };
+#define ST(s) reinterpret_cast<hipStream_t>(s)
+#define TRY(x) do { int _r = (x); if (_r) { if (!g_err[0]) pa_set_error("kernel launch", (hipError_t)_r, __FILE__, __LINE__); return _r; } } while (0)
+
+extern "C" {
+
+const char* pa_last_error(void) { return g_err; }
+int pa_version(void) { return 1; }
+
+int pa_gaussian_heatmap(const double* pts, float* out, int B, int J, int H, int W, void* s) {
+    TRY(pa_launch_gaussian_heatmap(pts, out, B, J, H, W, ST(s))); return 0;
+}
+int pa_weighted_l2(const float* pred, const float* gt, const float* weight, size_t n, float* loss, void* s) {
+    TRY(pa_launch_weighted_l2(pred, gt, weight, n, loss, ST(s))); return 0;
+}
+int pa_get_preds(const float* maps, int B, int J, int H, int W, float* preds, float* maxval, void* s) {
+    TRY(pa_launch_argmax(maps, (long)J * H * W, (long)H * W, 1, B, J, H, W, preds, maxval, ST(s))); return 0;
+}
+int pa_final_preds(const float* maps, const float* center, const float* scale, const float* rot, int B, int J, int H, int W,
+                   float* out, float* scratch_preds, void* s) {
+    TRY(pa_launch_argmax(maps, (long)J * H * W, (long)H * W, 1, B, J, H, W, scratch_preds, nullptr, ST(s)));
+    TRY(pa_launch_final_preds(maps, (long)J * H * W, (long)H * W, 1, scratch_preds, center, scale, rot, B, J, H, W, out, ST(s)));
+    return 0;
+}
+int pa_pck(const float* pred, const float* gt, const float* norm, float boundary, const int32_t* idxs, int nidx, float thr,
+           const float* vis, int B, int J, float* acc, float* person, float* dists, void* s) {
+    TRY(pa_launch_pck(pred, gt, norm, boundary, idxs, nidx, thr, vis, B, J, acc, person, dists, ST(s))); return 0;
+}
+int pa_affine_params(const float* params, int B, int res_in, int res_out, double* t_out, double* tinv_in, void* s) {
+    TRY(pa_launch_affine_params(params, B, res_in, res_out, t_out, tinv_in, ST(s))); return 0;
+}
+int pa_transform_pts(const float* pts, const float* params, const double* t, int B, int J, float width, double* out,
+                     float* pts_img, void* s) {
+    TRY(pa_launch_transform_pts(pts, params, t, B, J, width, out, pts_img, ST(s))); return 0;
+}
+int pa_affine_warp_bilinear(const uint8_t* src, int Hs, int Ws, const double* tinv, const float* params, int B, int res,
+                            void* out4, float* outf, void* s) {
+    TRY(pa_launch_warp(src, Hs, Ws, tinv, params, B, res, reinterpret_cast<bf16*>(out4), outf, ST(s))); return 0;
+}
+int pa_sample_aug(const float* meta, const int32_t* scale_idx, const int32_t* rot_idx, int mode, uint64_t seed, uint64_t step,
+                  int B, float* params, void* s) {
+    TRY(pa_launch_sample_aug(meta, scale_idx, rot_idx, mode, seed, step, B, params, ST(s))); return 0;
+}
+int pa_sample_categorical(const float* logits, int B, int K, uint64_t seed, uint64_t step, unsigned slot, float* probs,
+                          int32_t* idx, void* s) {
+    if (K > 64) { pa_set_error_msg("pa_sample_categorical: K <= 64"); return 1; }
+    TRY(pa_launch_sample_categorical(logits, B, K, seed, step, slot, probs, idx, ST(s))); return 0;
+}
+int pa_rmsprop_step(float* p, const float* g, float* v, size_t n, float lr, float alpha, float eps, float gscale, void* s) {
+    TRY(pa_launch_rmsprop(p, g, v, n, lr, alpha, eps, gscale, ST(s))); return 0;
+}
+int pa_nchw_to_nhwc(const float* src, void* dst, int B, int C, int H, int W, void* s) {
+    TRY(pa_launch_nchw_f32_to_nhwc_bf16(src, reinterpret_cast<bf16*>(dst), B, C, H, W, ST(s))); return 0;
+}
+int pa_nhwc_to_nchw(const void* src, float* dst, int B, int C, int H, int W, void* s) {
+    TRY(pa_launch_nhwc_bf16_to_nchw_f32(pa_plain(reinterpret_cast<const bf16*>(src)), dst, B, C, H, W, ST(s))); return 0;
+}
+
+// ---------------------------------------------------------------------------- residual block op
+struct ResidualOp {
+    Net n; Residual r; Act in;
+    size_t build(int B, int H, int W, int C, char* base) {
+        Arena a; a.base = base;
+        for (BNLayer* b : n.bns) { b->stats = a.get<float>(2 * b->C); b->bstats = a.get<float>(2 * b->C); }
+        a.take(0);
+        n.stats_arena = reinterpret_cast<float*>(base); n.stats_arena_floats = a.off / sizeof(float);
+        n.prep_jobs = a.get<PaPrepJob>(n.convs.size());
+        n.red_jobs = a.get<PaWgradReduceJob>(n.convs.size());
+        n.bneval_jobs = a.get<PaBnEvalJob>(n.bns.size());
+        in = n.new_act(a, B, H, W, C, nullptr, true);
+        r.layout(n, a, B, H, W, true);
+        a.take(0);
+        return a.off;
+    }
+};
+
+size_t pa_residual_workspace_bytes(int B, int H, int W, int C) {
+    ResidualOp op; op.n.is_agent = true; op.r.declare(op.n, "", C, C, false);
+    return op.build(B, H, W, C, nullptr);
+}
+
+int pa_residual_fwd_bwd(const float* x, const float* dy, const float* params, float* y, float* dx, float* grads, float* buffers,
+                        int B, int C, int H, int W, void* ws, void* s) {
+    g_err[0] = 0;
+    ResidualOp op; Net& n = op.n;
+    n.is_agent = true; n.B = B; n.st = ST(s);
+    op.r.declare(n, "", C, C, false);
+    op.build(B, H, W, C, reinterpret_cast<char*>(ws));
+    n.params = const_cast<float*>(params); n.grads = grads; n.buffers = buffers;
+    TRY(n.upload_tables());
+    TRY(n.prepare_weights());
+    TRY(n.begin_step());
+    n.train_bn = true;
+    TRY(pa_launch_nchw_f32_to_nhwc_bf16(x, op.in.raw, B, C, H, W, n.st));
+    TRY(op.r.fwd(n, op.in));
+    TRY(pa_launch_nhwc_bf16_to_nchw_f32(n.op(op.r.x3), y, B, C, H, W, n.st));
+    if (dy) {
+        bf16* g = op.r.x1.grad;    // borrow as staging for the incoming gradient (overwritten later by bwd)
+        // x1 is narrower than x3: stage in the input's gradient buffer instead
+        g = op.in.grad;
+        TRY(pa_launch_nchw_f32_to_nhwc_bf16(dy, g, B, C, H, W, n.st));
+        TRY(pa_launch_ep_apply(pa_plain(g), n.final_ep(op.r.x3), op.r.x3.grad, (size_t)B * H * W, C, n.st));
+        TRY(n.finish_grad(op.r.x3));
+        TRY(op.r.bwd(n, op.in, pa_none(), true));
+        TRY(n.reduce_grads());
+        TRY(pa_launch_nhwc_bf16_to_nchw_f32(pa_plain(op.in.grad), dx, B, C, H, W, n.st));
+    }
+    PA_CHECK(hipStreamSynchronize(n.st));
+    return 0;
+}
+
+// ---------------------------------------------------------------------------- networks
+pa_net* pa_hg_create(int num_stacks, int num_classes, int chan, int B, int res) {
+    g_err[0] = 0;
+    if (num_classes != 16 || chan % 128 != 0 || chan > 2048 || res % 64 != 0 || B < 1 || num_stacks < 1) {
+        pa_set_error_msg("pa_hg_create: need num_classes == 16, chan % 128 == 0, res % 64 == 0");
+        return nullptr;
+    }
+    pa_net* p = new (std::nothrow) pa_net;
+    if (!p) return nullptr;
+    Net& n = p->n;
+    n.stacks = num_stacks; n.classes = num_classes; n.chan = chan; n.B = B; n.res = res;
+    n.declare_pose();
+    n.workspace_bytes = n.layout_all(nullptr);
+    return p;
+}
+
+pa_net* pa_asn_create(int chan, int scale_num, int rotation_num, int B, int res) {
+    (void)chan; (void)scale_num; (void)rotation_num; (void)B; (void)res;
+    pa_set_error_msg("pa_asn_create: not built yet");
+    return nullptr;
+}
+
+void pa_net_destroy(pa_net* net) { delete net; }
+
+int pa_net_num_tensors(const pa_net* net) { return (int)net->n.tensors.size(); }
+
+int pa_net_tensor_info(const pa_net* net, int i, char* name, int name_cap, int* shape4, int* ndim, size_t* offset, size_t* numel,
+                       int* kind) {
+    if (i < 0 || i >= (int)net->n.tensors.size()) { pa_set_error_msg("pa_net_tensor_info: index out of range"); return 1; }
+    const TensorInfo& t = net->n.tensors[i];
+    snprintf(name, name_cap, "%s", t.name.c_str());
+    for (int k = 0; k < 4; ++k) shape4[k] = t.shape[k];
+    *ndim = t.ndim; *offset = t.offset; *numel = t.numel; *kind = t.is_buffer;
+    return 0;
+}
+
+size_t pa_net_param_floats(const pa_net* net) { return net->n.n_params; }
+size_t pa_net_buffer_floats(const pa_net* net) { return net->n.n_buffers; }
+size_t pa_net_workspace_bytes(const pa_net* net) { return net->n.workspace_bytes; }
+
+int pa_net_bind(pa_net* net, float* params, float* grads, float* buffers, void* workspace, void* s) {
+    g_err[0] = 0;
+    Net& n = net->n;
+    n.params = params; n.grads = grads; n.buffers = buffers; n.workspace = reinterpret_cast<char*>(workspace); n.st = ST(s);
+    n.layout_all(n.workspace);
+    TRY(n.upload_tables());
+    return n.prepare_weights();
+}
+
+int pa_net_prepare_weights(pa_net* net) { g_err[0] = 0; TRY(net->n.prepare_weights()); return 0; }
+
+int pa_hg_forward(pa_net* net, const float* img, const void* img4, const double* pts, int train, float* loss_per_stack) {
+    g_err[0] = 0;
+    if (!img && !img4) { pa_set_error_msg("pa_hg_forward: need img or img4"); return 1; }
+    TRY(net->n.forward_pose(img, reinterpret_cast<const bf16*>(img4), pts, train != 0, loss_per_stack));
+    return 0;
+}
+
+const float* pa_hg_heatmap_nhwc(const pa_net* net, int stack) { return net->n.heat[stack]; }
+
+int pa_hg_heatmap_nchw(pa_net* net, int stack, float* out) {
+    Net& n = net->n;
+    TRY(pa_launch_nhwc_to_nchw_f32(n.heat[stack], out, n.B, n.res / 4, n.res / 4, 16, n.st));
+    return 0;
+}
+
+int pa_hg_backward(pa_net* net) { g_err[0] = 0; TRY(net->n.backward_pose()); return 0; }
+
+int pa_hg_accuracy(pa_net* net, int stack, const int32_t* idxs, int nidx, float* acc, float* scratch) {
+    g_err[0] = 0;
+    Net& n = net->n;
+    const int H = n.res / 4, J = 16, B = n.B;
+    float* tgt = scratch;                         // [B][16][H][H]
+    float* pp = tgt + (size_t)B * J * H * H;      // [B][16][2]
+    float* gp = pp + (size_t)B * J * 2;
+    float* norm = gp + (size_t)B * J * 2;         // [B]
+    TRY(pa_launch_gaussian_heatmap(n.pts_dev, tgt, B, J, H, H, n.st));
+    TRY(pa_launch_argmax(n.heat[stack], (long)H * H * 16, 1, 16, B, J, H, H, pp, nullptr, n.st));
+    TRY(pa_launch_argmax(tgt, (long)J * H * H, (long)H * H, 1, B, J, H, H, gp, nullptr, n.st));
+    TRY(pa_launch_fill(norm, (float)H / 10.f, B, n.st));
+    TRY(pa_launch_pck(pp, gp, norm, 1.f, idxs, nidx, 0.5f, nullptr, B, J, acc, nullptr, nullptr, n.st));
+    return 0;
+}
+
+}  // extern "C"

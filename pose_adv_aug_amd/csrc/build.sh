@@ -1,0 +1,15 @@
+#!/bin/bash
+# Build libposeadv_hip.so for gfx950 (MI355X) in-tree.  hipcc cross-compiles without a GPU.
+set -e
+cd "$(dirname "$0")"
+mkdir -p ../build
+OBJS=""
+for f in conv_igemm conv_wgrad elementwise pose_ops net api; do
+  if [ ! -f ../build/$f.o ] || [ $f.hip -nt ../build/$f.o ] || [ common.h -nt ../build/$f.o ] || [ kernels.h -nt ../build/$f.o ] || [ net.h -nt ../build/$f.o ] || [ pose_ops.h -nt ../build/$f.o ] || [ ../../include/poseadv.h -nt ../build/$f.o ]; then
+    hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c $f.hip -o ../build/$f.o &
+  fi
+  OBJS="$OBJS ../build/$f.o"
+done
+wait
+hipcc --offload-arch=gfx950 -shared -fPIC $OBJS -o ../libposeadv_hip.so
+echo "built $(cd .. && pwd)/libposeadv_hip.so"

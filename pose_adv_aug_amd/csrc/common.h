@@ -1,0 +1,107 @@
+// Shared device helpers for the gfx950 (MI355X / CDNA4) kernels of the stacked-hourglass
+// training engine.  Activations are NHWC bf16; statistics, accumulators, master weights fp32.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+#define PA_WAVE 64
+
+#define PA_CHECK(expr)                                                                   \
+    do {                                                                                 \
+        hipError_t _e = (expr);                                                          \
+        if (_e != hipSuccess) { pa_set_error(#expr, _e, __FILE__, __LINE__); return (int)_e; } \
+    } while (0)
+
+void pa_set_error(const char* what, hipError_t e, const char* file, int line);
+void pa_set_error_msg(const char* msg);
+
+// How an NHWC operand is turned into a value when it is loaded (per element, per channel c):
+//   PLAIN : v = p[i]
+//   BNRELU: v = max(0, k0[c] * p[i] + k1[c])          (train/eval BatchNorm + ReLU applied on load)
+//   LIN2  : v = k0[c] * p[i] + k1[c] * q[i] + k2[c]    (BatchNorm backward applied on load:
+//                                                       p = masked upstream grad, q = raw conv output)
+enum { PA_LD_NONE = -1, PA_LD_PLAIN = 0, PA_LD_BNRELU = 1, PA_LD_LIN2 = 2 };
+
+struct PaOperand {
+    const bf16* p;
+    const bf16* q;
+    const float* k0;
+    const float* k1;
+    const float* k2;
+    int mode;
+};
+
+// What the epilogue of a conv / elementwise backward kernel does with its value v:
+//   PLAIN: store bf16(v)
+//   STATS: store bf16(v) and accumulate per-channel sum / sum of squares of the stored value
+//          (forward BatchNorm statistics fused into the producer)
+//   BWD  : v is the gradient w.r.t. a = relu(s*x+t); store dz = v*[s*x+t>0] and accumulate
+//          per-channel sum(dz), sum(dz*xhat), xhat=(x-mean)*invstd   (BatchNorm backward
+//          reductions fused into the producer of the gradient)
+enum { PA_OUT_PLAIN = 0, PA_OUT_STATS = 1, PA_OUT_BWD = 2 };
+
+struct PaEpilogue {
+    int mode;
+    float* stats;          // [2][C] accumulators (atomicAdd), zeroed by the caller
+    const bf16* xref;      // BWD: raw conv output of the tensor this gradient belongs to
+    const float* scale;    // BWD: s
+    const float* shift;    // BWD: t
+    const float* mean;     // BWD
+    const float* invstd;   // BWD
+};
+
+__device__ __forceinline__ float bf2f(bf16 v) { return (float)v; }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+template <int MODE>
+__device__ __forceinline__ void pa_load8(const PaOperand& op, size_t idx, int c, float (&v)[8]) {
+    bf16x8 a = *reinterpret_cast<const bf16x8*>(op.p + idx);
+    if (MODE == PA_LD_PLAIN) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (float)a[j];
+    } else if (MODE == PA_LD_BNRELU) {
+        f32x4 s0 = *reinterpret_cast<const f32x4*>(op.k0 + c), s1 = *reinterpret_cast<const f32x4*>(op.k0 + c + 4);
+        f32x4 t0 = *reinterpret_cast<const f32x4*>(op.k1 + c), t1 = *reinterpret_cast<const f32x4*>(op.k1 + c + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            v[j] = fmaxf(fmaf(s0[j], (float)a[j], t0[j]), 0.f);
+            v[j + 4] = fmaxf(fmaf(s1[j], (float)a[j + 4], t1[j]), 0.f);
+        }
+    } else {
+        bf16x8 b = *reinterpret_cast<const bf16x8*>(op.q + idx);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = fmaf(op.k0[c + j], (float)a[j], fmaf(op.k1[c + j], (float)b[j], op.k2[c + j]));
+    }
+}
+
+// runtime-mode 4-wide operand read used by epilogues (8-byte accesses)
+__device__ __forceinline__ void pa_read4(const PaOperand& op, size_t idx, int c, float (&v)[4]) {
+    if (op.mode == PA_LD_NONE) { v[0] = v[1] = v[2] = v[3] = 0.f; return; }
+    bf16x4 a = *reinterpret_cast<const bf16x4*>(op.p + idx);
+    if (op.mode == PA_LD_PLAIN) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = (float)a[j];
+    } else if (op.mode == PA_LD_BNRELU) {
+        f32x4 s = *reinterpret_cast<const f32x4*>(op.k0 + c), t = *reinterpret_cast<const f32x4*>(op.k1 + c);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = fmaxf(fmaf(s[j], (float)a[j], t[j]), 0.f);
+    } else {
+        bf16x4 b = *reinterpret_cast<const bf16x4*>(op.q + idx);
+        f32x4 k0 = *reinterpret_cast<const f32x4*>(op.k0 + c), k1 = *reinterpret_cast<const f32x4*>(op.k1 + c),
+              k2 = *reinterpret_cast<const f32x4*>(op.k2 + c);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = fmaf(k0[j], (float)a[j], fmaf(k1[j], (float)b[j], k2[j]));
+    }
+}

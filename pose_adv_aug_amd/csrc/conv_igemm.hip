@@ -1,0 +1,292 @@
+// Implicit-GEMM convolution (1x1 and 3x3 'same', stride 1) on bf16 MFMA for gfx950.
+//
+//   out[m][n] = epilogue( sum_{tap,c} load(in)[pixel(m)+tap][c] * w[n][tap][c] + bias[n] + add1 + add2 )
+//
+// m = flattened NHWC pixel (B*H*W rows), n = output channel.  The same kernel serves
+//   * forward convs   (reference models/asn_stacked_hg.py:17-24, 241-248): the input's pending
+//     BatchNorm+ReLU is applied while the tile is staged (PA_LD_BNRELU), the residual add and the
+//     per-channel sum / sum^2 needed by the NEXT BatchNorm are done in the epilogue (PA_OUT_STATS);
+//   * data gradients  (dgrad): `in` is the output gradient with the BatchNorm backward applied on
+//     load (PA_LD_LIN2), `w` is the transposed/tap-flipped weight copy, and the epilogue masks by the
+//     ReLU of the tensor the gradient belongs to and accumulates the two BatchNorm-backward
+//     reductions (PA_OUT_BWD).
+//
+// Tiling: BMxBN output tile per 256-thread workgroup (4 waves as 2x2), K step 64.  Both operand
+// tiles are staged global -> registers (transform) -> LDS as [row][64] bf16 with the 16-byte chunk
+// index XOR-swizzled by (row & 7), so the ds_read_b128 fragment reads of
+// v_mfma_f32_16x16x32_bf16 are bank-conflict free.  The weight fragment is the MFMA A operand and
+// the activation fragment the B operand, so each lane ends up with 4 consecutive output channels of
+// one pixel (8-byte bf16x4 stores, per-channel reductions over the 16 pixel lanes by DPP shuffles).
+#include "common.h"
+#include "kernels.h"
+
+// STEM: the A operand is the 4-channel-padded input image and the kernel computes the 7x7 stride-2
+// stem conv (reference models/asn_stacked_hg.py:223) as a K=256 GEMM: k = ky*32 + kx*4 + c, i.e. one
+// 16-byte chunk = 2 horizontally adjacent input pixels; a.H/a.W are the OUTPUT dims.
+template <int BM, int BN, int LDMODE, int TAPS, bool STEM = false>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(PaConvArgs a) {
+    constexpr int AI = BM / 32, BI = BN / 32;      // staged 16-byte chunks per thread (A / B tile)
+    constexpr int MI = BM / 32, NI = BN / 32;      // 16x16 fragments per wave (wave tile BM/2 x BN/2)
+    __shared__ __attribute__((aligned(16))) bf16 lds[(BM + BN) * 64];
+    bf16* As = lds;
+    bf16* Bs = lds + BM * 64;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int M = a.B * a.H * a.W, HW = a.H * a.W;
+    const int K = TAPS * a.Cin;
+    const int nK = K / 64;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int cc = tid & 7, r = tid >> 3;
+
+    int am[AI], ay[AI], ax[AI], ab[AI];
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+        int m = m0 + r + 32 * i;
+        am[i] = m < M ? m : -1;
+        ab[i] = m / HW;
+        int rem = m - ab[i] * HW;
+        ay[i] = rem / a.W;
+        ax[i] = rem - ay[i] * a.W;
+    }
+
+    bf16x8 ra[AI], rq[AI], rb[BI];
+    unsigned okmask = 0;
+    int cur_c = 0;
+
+    auto gload = [&](int kt) {
+        if (STEM) {
+            const int cidx = kt * 8 + cc, ky = cidx >> 2, q = cidx & 3;
+            const int Hin = 2 * a.H, Win = 2 * a.W;
+            okmask = 0;
+#pragma unroll
+            for (int i = 0; i < AI; ++i) {
+                bf16x4 lo = {(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f}, hi = lo;
+                const int yi = 2 * ay[i] + ky - 3, xi = 2 * ax[i] + 2 * q - 3;
+                if (am[i] >= 0 && ky < 7 && (unsigned)yi < (unsigned)Hin) {
+                    const bf16* rowp = a.in.p + ((size_t)ab[i] * Hin + yi) * Win * 4;
+                    if ((unsigned)xi < (unsigned)Win) lo = *reinterpret_cast<const bf16x4*>(rowp + (size_t)xi * 4);
+                    if ((unsigned)(xi + 1) < (unsigned)Win) hi = *reinterpret_cast<const bf16x4*>(rowp + (size_t)(xi + 1) * 4);
+                }
+                ra[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                okmask |= 1u << i;
+            }
+#pragma unroll
+            for (int i = 0; i < BI; ++i)
+                rb[i] = *reinterpret_cast<const bf16x8*>(a.w + (size_t)(n0 + r + 32 * i) * K + kt * 64 + cc * 8);
+            return;
+        }
+        int tap = 0, c0 = kt * 64, dy = 0, dx = 0;
+        if (TAPS == 9) { tap = c0 / a.Cin; c0 -= tap * a.Cin; dy = tap / 3 - 1; dx = tap - (tap / 3) * 3 - 1; }
+        cur_c = c0 + cc * 8;
+        okmask = 0;
+#pragma unroll
+        for (int i = 0; i < AI; ++i) {
+            bool ok = am[i] >= 0;
+            if (TAPS == 9) ok = ok && (unsigned)(ay[i] + dy) < (unsigned)a.H && (unsigned)(ax[i] + dx) < (unsigned)a.W;
+            if (ok) {
+                size_t idx = (size_t)(am[i] + dy * a.W + dx) * a.Cin + cur_c;
+                ra[i] = *reinterpret_cast<const bf16x8*>(a.in.p + idx);
+                if (LDMODE == PA_LD_LIN2) rq[i] = *reinterpret_cast<const bf16x8*>(a.in.q + idx);
+                okmask |= 1u << i;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < BI; ++i)
+            rb[i] = *reinterpret_cast<const bf16x8*>(a.w + (size_t)(n0 + r + 32 * i) * K + kt * 64 + cc * 8);
+    };
+
+    auto lstore = [&]() {
+        float k0[8], k1[8], k2[8];
+        if (LDMODE != PA_LD_PLAIN) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { k0[j] = a.in.k0[cur_c + j]; k1[j] = a.in.k1[cur_c + j]; }
+            if (LDMODE == PA_LD_LIN2) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) k2[j] = a.in.k2[cur_c + j];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < AI; ++i) {
+            int row = r + 32 * i;
+            bf16x8 o;
+            if (okmask & (1u << i)) {
+                if (LDMODE == PA_LD_PLAIN) {
+                    o = ra[i];
+                } else if (LDMODE == PA_LD_BNRELU) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) o[j] = (bf16)fmaxf(fmaf(k0[j], (float)ra[i][j], k1[j]), 0.f);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        o[j] = (bf16)fmaf(k0[j], (float)ra[i][j], fmaf(k1[j], (float)rq[i][j], k2[j]));
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = (bf16)0.f;
+            }
+            *reinterpret_cast<bf16x8*>(As + row * 64 + ((cc ^ (row & 7)) << 3)) = o;
+        }
+#pragma unroll
+        for (int i = 0; i < BI; ++i) {
+            int row = r + 32 * i;
+            *reinterpret_cast<bf16x8*>(Bs + row * 64 + ((cc ^ (row & 7)) << 3)) = rb[i];
+        }
+    };
+
+    f32x4 acc[NI][MI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    gload(0);
+    lstore();
+    __syncthreads();
+
+    const int frow = lane & 15, fchk = lane >> 4;
+    for (int kt = 0; kt < nK; ++kt) {
+        if (kt + 1 < nK) gload(kt + 1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 fa[MI], fw[NI];
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                int row = wm * (BM / 2) + mi * 16 + frow;
+                fa[mi] = *reinterpret_cast<const bf16x8*>(As + row * 64 + (((fchk + 4 * kk) ^ (row & 7)) << 3));
+            }
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                int row = wn * (BN / 2) + ni * 16 + frow;
+                fw[ni] = *reinterpret_cast<const bf16x8*>(Bs + row * 64 + (((fchk + 4 * kk) ^ (row & 7)) << 3));
+            }
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[ni], fa[mi], acc[ni][mi], 0, 0, 0);
+        }
+        __syncthreads();
+        if (kt + 1 < nK) {
+            lstore();
+            __syncthreads();
+        }
+    }
+
+    // ---------------------------------------------------------------- epilogue
+    const int N = a.Cout;
+    float s1[NI][4], s2[NI][4];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { s1[ni][j] = 0.f; s2[ni][j] = 0.f; }
+
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+        const int n = n0 + wn * (BN / 2) + ni * 16 + (lane >> 4) * 4;
+        float bias[4] = {0.f, 0.f, 0.f, 0.f};
+        if (a.bias) {
+            f32x4 b = *reinterpret_cast<const f32x4*>(a.bias + n);
+            bias[0] = b[0]; bias[1] = b[1]; bias[2] = b[2]; bias[3] = b[3];
+        }
+        float es[4], et[4], emu[4], eis[4];
+        if (a.ep.mode == PA_OUT_BWD) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                es[j] = a.ep.scale[n + j]; et[j] = a.ep.shift[n + j];
+                emu[j] = a.ep.mean[n + j]; eis[j] = a.ep.invstd[n + j];
+            }
+        }
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const int m = m0 + wm * (BM / 2) + mi * 16 + (lane & 15);
+            if (m >= M) continue;
+            const size_t idx = (size_t)m * N + n;
+            float v[4], e1[4], e2[4];
+            pa_read4(a.add1, idx, n, e1);
+            pa_read4(a.add2, idx, n, e2);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = acc[ni][mi][j] + bias[j] + e1[j] + e2[j];
+            bf16x4 o;
+            if (a.ep.mode == PA_OUT_BWD) {
+                bf16x4 xr = *reinterpret_cast<const bf16x4*>(a.ep.xref + idx);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float x = (float)xr[j];
+                    float dz = (fmaf(es[j], x, et[j]) > 0.f) ? v[j] : 0.f;
+                    o[j] = (bf16)dz;
+                    float dzr = (float)o[j];
+                    s1[ni][j] += dzr;
+                    s2[ni][j] += dzr * (x - emu[j]) * eis[j];
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    o[j] = (bf16)v[j];
+                    float rv = (float)o[j];
+                    s1[ni][j] += rv;
+                    s2[ni][j] += rv * rv;
+                }
+            }
+            *reinterpret_cast<bf16x4*>(a.out + idx) = o;
+        }
+    }
+    if (a.ep.mode != PA_OUT_PLAIN) {
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float x1 = s1[ni][j], x2 = s2[ni][j];
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) { x1 += __shfl_xor(x1, o, 64); x2 += __shfl_xor(x2, o, 64); }
+                if ((lane & 15) == 0) {
+                    const int n = n0 + wn * (BN / 2) + ni * 16 + (lane >> 4) * 4 + j;
+                    atomicAdd(a.ep.stats + n, x1);
+                    atomicAdd(a.ep.stats + N + n, x2);
+                }
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int TAPS>
+static void launch_ld(const PaConvArgs& a, dim3 grid, hipStream_t st) {
+    switch (a.in.mode) {
+        case PA_LD_PLAIN: hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, PA_LD_PLAIN, TAPS>), grid, dim3(256), 0, st, a); break;
+        case PA_LD_BNRELU: hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, PA_LD_BNRELU, TAPS>), grid, dim3(256), 0, st, a); break;
+        default: hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, PA_LD_LIN2, TAPS>), grid, dim3(256), 0, st, a); break;
+    }
+}
+
+template <int BM, int BN>
+static void launch_taps(const PaConvArgs& a, dim3 grid, hipStream_t st) {
+    if (a.taps == 1) launch_ld<BM, BN, 1>(a, grid, st);
+    else launch_ld<BM, BN, 9>(a, grid, st);
+}
+
+int pa_launch_stem_conv(const PaConvArgs& a, hipStream_t st) {
+    // a.in.p = img4 [B][2H][2W][4]; a.w = [64][256]; a.Cin must be 256 (virtual), a.Cout 64
+    if (a.Cin != 256 || a.Cout != 64 || a.in.mode != PA_LD_PLAIN) { pa_set_error_msg("pa_launch_stem_conv: bad arguments"); return 1; }
+    const int M = a.B * a.H * a.W;
+    if (M >= 128 * 256)
+        hipLaunchKernelGGL((conv_igemm_kernel<128, 64, PA_LD_PLAIN, 1, true>), dim3((M + 127) / 128, 1), dim3(256), 0, st, a);
+    else
+        hipLaunchKernelGGL((conv_igemm_kernel<64, 64, PA_LD_PLAIN, 1, true>), dim3((M + 63) / 64, 1), dim3(256), 0, st, a);
+    return (int)hipGetLastError();
+}
+
+int pa_launch_conv(const PaConvArgs& a, hipStream_t st) {
+    if ((a.taps != 1 && a.taps != 9) || a.Cin % 64 != 0 || a.Cout % 64 != 0) {
+        pa_set_error_msg("pa_launch_conv: channel counts must be multiples of 64 and taps 1 or 9");
+        return 1;
+    }
+    const int M = a.B * a.H * a.W;
+    // small problems get the 64-row tile so that the grid still covers the 256 CUs
+    const bool bigM = M >= 128 * 256;
+    const bool bigN = (a.Cout % 128 == 0);
+    if (bigM && bigN) launch_taps<128, 128>(a, dim3((M + 127) / 128, a.Cout / 128), st);
+    else if (bigM) launch_taps<128, 64>(a, dim3((M + 127) / 128, a.Cout / 64), st);
+    else if (bigN && M >= 64 * 256) launch_taps<64, 128>(a, dim3((M + 63) / 64, a.Cout / 128), st);
+    else launch_taps<64, 64>(a, dim3((M + 63) / 64, a.Cout / 64), st);
+    return (int)hipGetLastError();
+}

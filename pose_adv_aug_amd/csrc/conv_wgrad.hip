@@ -1,0 +1,333 @@
+// Weight gradients of the 1x1 / 3x3 convolutions on bf16 MFMA (gfx950).
+//
+//   dw[n][tap][c] = sum_m dy[m][n] * x[pixel(m)+tap][c]
+//
+// The reduction runs over the pixel index m, which is the SLOW index of both NHWC operands, while
+// v_mfma_f32_16x16x32_bf16 wants 8 consecutive reduction elements per lane.  Each staging thread
+// therefore owns an 8(pixel) x 8(channel) block: it issues 8 coalesced 16-byte loads, applies the
+// operand transform in fp32 (BatchNorm backward on dy: PA_LD_LIN2; BatchNorm+ReLU on x:
+// PA_LD_BNRELU) and packs the block TRANSPOSED, so the LDS tiles are [channel][64 pixels] and the
+// fragment reads are the same swizzled ds_read_b128 pattern as the forward kernel.
+// The pixel range is split over `splits` workgroups per output tile; each writes a deterministic
+// fp32 partial slab that pa_launch_wgrad_reduce sums into the PyTorch-layout gradient.
+#include "common.h"
+#include "kernels.h"
+
+// STEM: x is the 4-channel-padded image and the 'channels' are the 256 (ky*32+kx*4+c) patch
+// elements of the 7x7 stride-2 stem conv (one 16-byte chunk = 2 adjacent input pixels); a.H/a.W
+// are the OUTPUT dims.
+template <int TN, int TK, int PMODE, int QMODE, int TAPS, bool STEM = false>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(PaWgradArgs a) {
+    constexpr int NI = TN / 32, KI = TK / 32;          // fragments per wave (wave tile TN/2 x TK/2)
+    __shared__ __attribute__((aligned(16))) bf16 lds[(TN + TK) * 64];
+    bf16* Pt = lds;                 // [TN][64 pixels]
+    bf16* Qt = lds + TN * 64;       // [TK][64 pixels]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave & 1, wk = wave >> 1;
+    const int M = a.B * a.H * a.W, HW = a.H * a.W;
+    const int Kfull = TAPS * a.Cin;
+    const int ktiles_per_tap = a.Cin / TK;
+    const int split = blockIdx.x;
+    const int tap = blockIdx.y / ktiles_per_tap;
+    const int cbase = (blockIdx.y - tap * ktiles_per_tap) * TK;     // channel offset inside the tap
+    const int nbase = blockIdx.z * TN;
+    const int dy = (TAPS == 9) ? tap / 3 - 1 : 0, dx = (TAPS == 9) ? tap - (tap / 3) * 3 - 1 : 0;
+
+    const int steps_total = (M + 63) / 64;
+    const int steps_per = (steps_total + a.splits - 1) / a.splits;
+    const int step0 = split * steps_per;
+    const int step1 = min(step0 + steps_per, steps_total);
+
+    // staging role of this thread: one 8x8 block of P (dy) or of Q (x)
+    const bool isP = tid < TN, isQ = !isP && tid < TN + TK;
+    const int bid = isP ? tid : tid - TN;
+    const int mg = bid & 7, cg = bid >> 3;
+    const int chan = isP ? nbase + cg * 8 : cbase + cg * 8;
+    float k0[8], k1[8], k2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { k0[j] = 1.f; k1[j] = 0.f; k2[j] = 0.f; }
+    if (isP && PMODE == PA_LD_LIN2) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { k0[j] = a.dy.k0[chan + j]; k1[j] = a.dy.k1[chan + j]; k2[j] = a.dy.k2[chan + j]; }
+    }
+    if (isQ && QMODE == PA_LD_BNRELU) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { k0[j] = a.x.k0[chan + j]; k1[j] = a.x.k1[chan + j]; }
+    }
+
+    bf16x8 rp[8], rq[8];
+    unsigned okmask = 0;
+    float colsum[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) colsum[j] = 0.f;
+    const bool want_db = (a.dbpart != nullptr) && blockIdx.y == 0;
+
+    auto gload = [&](int step) {
+        okmask = 0;
+        const int mfirst = step * 64 + mg * 8;
+        if (isP) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                int m = mfirst + j;
+                if (m < M) {
+                    size_t idx = (size_t)m * a.Cout + chan;
+                    rp[j] = *reinterpret_cast<const bf16x8*>(a.dy.p + idx);
+                    if (PMODE == PA_LD_LIN2) rq[j] = *reinterpret_cast<const bf16x8*>(a.dy.q + idx);
+                    okmask |= 1u << j;
+                }
+            }
+        } else if (isQ && STEM) {
+            const int cidx = chan >> 3, ky = cidx >> 2, q = cidx & 3;
+            const int Hin = 2 * a.H, Win = 2 * a.W;
+            int b = mfirst / HW;
+            int rem = mfirst - b * HW;
+            int y = rem / a.W, x = rem - y * a.W;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                bf16x4 lo = {(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f}, hi = lo;
+                const int yi = 2 * y + ky - 3, xi = 2 * x + 2 * q - 3;
+                if (mfirst + j < M && ky < 7 && (unsigned)yi < (unsigned)Hin) {
+                    const bf16* rowp = a.x.p + ((size_t)b * Hin + yi) * Win * 4;
+                    if ((unsigned)xi < (unsigned)Win) lo = *reinterpret_cast<const bf16x4*>(rowp + (size_t)xi * 4);
+                    if ((unsigned)(xi + 1) < (unsigned)Win) hi = *reinterpret_cast<const bf16x4*>(rowp + (size_t)(xi + 1) * 4);
+                }
+                rp[j] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                okmask |= 1u << j;
+                if (++x == a.W) { x = 0; if (++y == a.H) { y = 0; ++b; } }
+            }
+        } else if (isQ) {
+            int y = 0, x = 0;
+            if (TAPS == 9) { int rem = mfirst % HW; y = rem / a.W; x = rem - y * a.W; }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                int m = mfirst + j;
+                bool ok = m < M;
+                if (TAPS == 9) ok = ok && (unsigned)(y + dy) < (unsigned)a.H && (unsigned)(x + dx) < (unsigned)a.W;
+                if (ok) {
+                    size_t idx = (size_t)(m + dy * a.W + dx) * a.Cin + chan;
+                    rp[j] = *reinterpret_cast<const bf16x8*>(a.x.p + idx);
+                    okmask |= 1u << j;
+                }
+                if (TAPS == 9) { if (++x == a.W) { x = 0; if (++y == a.H) y = 0; } }
+            }
+        }
+    };
+
+    auto lstore = [&]() {
+        if (!(isP || isQ)) return;
+        bf16x8 o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {                  // j = pixel inside the block
+            float v[8];
+            if (okmask & (1u << j)) {
+                if (isP) {
+                    if (PMODE == PA_LD_LIN2) {
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) v[c] = fmaf(k0[c], (float)rp[j][c], fmaf(k1[c], (float)rq[j][c], k2[c]));
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) v[c] = (float)rp[j][c];
+                    }
+                } else {
+                    if (QMODE == PA_LD_BNRELU) {
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) v[c] = fmaxf(fmaf(k0[c], (float)rp[j][c], k1[c]), 0.f);
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) v[c] = (float)rp[j][c];
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) v[c] = 0.f;
+            }
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                o[c][j] = (bf16)v[c];
+                if (want_db && isP) colsum[c] += (float)o[c][j];
+            }
+        }
+        bf16* T = isP ? Pt : Qt;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            int row = cg * 8 + c;
+            *reinterpret_cast<bf16x8*>(T + row * 64 + ((mg ^ (row & 7)) << 3)) = o[c];
+        }
+    };
+
+    f32x4 acc[NI][KI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int ki = 0; ki < KI; ++ki) acc[ni][ki] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int frow = lane & 15, fchk = lane >> 4;
+    if (step0 < step1) {
+        gload(step0);
+        lstore();
+        __syncthreads();
+        for (int step = step0; step < step1; ++step) {
+            if (step + 1 < step1) gload(step + 1);
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                bf16x8 fp[NI], fq[KI];
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                    int row = wn * (TN / 2) + ni * 16 + frow;
+                    fp[ni] = *reinterpret_cast<const bf16x8*>(Pt + row * 64 + (((fchk + 4 * kk) ^ (row & 7)) << 3));
+                }
+#pragma unroll
+                for (int ki = 0; ki < KI; ++ki) {
+                    int row = wk * (TK / 2) + ki * 16 + frow;
+                    fq[ki] = *reinterpret_cast<const bf16x8*>(Qt + row * 64 + (((fchk + 4 * kk) ^ (row & 7)) << 3));
+                }
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                    for (int ki = 0; ki < KI; ++ki)
+                        acc[ni][ki] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fq[ki], fp[ni], acc[ni][ki], 0, 0, 0);
+            }
+            __syncthreads();
+            if (step + 1 < step1) {
+                lstore();
+                __syncthreads();
+            }
+        }
+    }
+
+    // partial slab: part[split][n][tap*Cin + c]; lane holds 4 consecutive c for one n
+    float* slab = a.part + (size_t)split * a.Cout * Kfull;
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+        const int n = nbase + wn * (TN / 2) + ni * 16 + (lane & 15);
+#pragma unroll
+        for (int ki = 0; ki < KI; ++ki) {
+            const int c = cbase + wk * (TK / 2) + ki * 16 + (lane >> 4) * 4;
+            *reinterpret_cast<f32x4*>(slab + (size_t)n * Kfull + tap * a.Cin + c) = acc[ni][ki];
+        }
+    }
+    if (want_db && isP) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            float s = colsum[c];
+            s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+            if (mg == 0) a.dbpart[(size_t)split * a.Cout + chan + c] = s;
+        }
+    }
+}
+
+static int round_up8(int v) { return (v + 7) & ~7; }
+
+static void tile_of(int Cin, int Cout, int& TN, int& TK) {
+    TN = (Cout % 128 == 0) ? 128 : 64;
+    TK = (Cin % 128 == 0) ? 128 : 64;
+}
+
+int pa_wgrad_splits(int M, int Cin, int Cout, int taps) {
+    int TN, TK;
+    tile_of(Cin, Cout, TN, TK);
+    const int tiles = (Cout / TN) * (taps * Cin / TK);
+    const int steps_total = (M + 63) / 64;
+    int s = round_up8((256 + tiles - 1) / tiles);
+    if (s > steps_total) s = steps_total;
+    if (s < 1) s = 1;
+    return s;
+}
+
+template <int TN, int TK, int PMODE, int QMODE>
+static void launch_w_taps(const PaWgradArgs& a, dim3 grid, hipStream_t st) {
+    if (a.taps == 1) hipLaunchKernelGGL((conv_wgrad_kernel<TN, TK, PMODE, QMODE, 1>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((conv_wgrad_kernel<TN, TK, PMODE, QMODE, 9>), grid, dim3(256), 0, st, a);
+}
+
+template <int TN, int TK>
+static void launch_w_modes(const PaWgradArgs& a, dim3 grid, hipStream_t st) {
+    const bool lin2 = a.dy.mode == PA_LD_LIN2, bnrelu = a.x.mode == PA_LD_BNRELU;
+    if (lin2 && bnrelu) launch_w_taps<TN, TK, PA_LD_LIN2, PA_LD_BNRELU>(a, grid, st);
+    else if (lin2) launch_w_taps<TN, TK, PA_LD_LIN2, PA_LD_PLAIN>(a, grid, st);
+    else if (bnrelu) launch_w_taps<TN, TK, PA_LD_PLAIN, PA_LD_BNRELU>(a, grid, st);
+    else launch_w_taps<TN, TK, PA_LD_PLAIN, PA_LD_PLAIN>(a, grid, st);
+}
+
+int pa_launch_stem_wgrad(const PaWgradArgs& a, hipStream_t st) {
+    // a.x.p = img4, a.Cin = 256 (virtual patch length), a.Cout = 64, a.H/a.W output dims
+    if (a.Cin != 256 || a.Cout != 64 || a.taps != 1 || a.x.mode != PA_LD_PLAIN || a.splits < 1) {
+        pa_set_error_msg("pa_launch_stem_wgrad: bad arguments");
+        return 1;
+    }
+    dim3 grid(a.splits, 2, 1);
+    if (a.dy.mode == PA_LD_LIN2)
+        hipLaunchKernelGGL((conv_wgrad_kernel<64, 128, PA_LD_LIN2, PA_LD_PLAIN, 1, true>), grid, dim3(256), 0, st, a);
+    else
+        hipLaunchKernelGGL((conv_wgrad_kernel<64, 128, PA_LD_PLAIN, PA_LD_PLAIN, 1, true>), grid, dim3(256), 0, st, a);
+    return (int)hipGetLastError();
+}
+
+int pa_launch_wgrad(const PaWgradArgs& a, hipStream_t st) {
+    if ((a.taps != 1 && a.taps != 9) || a.Cin % 64 != 0 || a.Cout % 64 != 0 || a.splits < 1) {
+        pa_set_error_msg("pa_launch_wgrad: channel counts must be multiples of 64, taps 1 or 9, splits >= 1");
+        return 1;
+    }
+    int TN, TK;
+    tile_of(a.Cin, a.Cout, TN, TK);
+    dim3 grid(a.splits, a.taps * a.Cin / TK, a.Cout / TN);
+    if (TN == 128 && TK == 128) launch_w_modes<128, 128>(a, grid, st);
+    else if (TN == 128) launch_w_modes<128, 64>(a, grid, st);
+    else if (TK == 128) launch_w_modes<64, 128>(a, grid, st);
+    else launch_w_modes<64, 64>(a, grid, st);
+    return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// sum the split slabs and scatter into PyTorch layout  dst[n][c][tap]   (one job per conv layer)
+__global__ void wgrad_reduce_kernel(const PaWgradReduceJob* jobs) {
+    const PaWgradReduceJob j = jobs[blockIdx.y];
+    const int K = j.taps * j.Cin;
+    const int total = j.real_cout * j.real_cin * j.taps;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total + j.real_cout; e += gridDim.x * blockDim.x) {
+        if (e < total) {
+            // e enumerates the SOURCE order (n, tap, c) so that reads are coalesced
+            const int n = e / (j.taps * j.real_cin);
+            const int r = e - n * j.taps * j.real_cin;
+            const int tap = r / j.real_cin, c = r - tap * j.real_cin;
+            const float* src = j.part + (size_t)n * K + tap * j.Cin + c;
+            float s = 0.f;
+            for (int sp = 0; sp < j.splits; ++sp) s += src[(size_t)sp * j.Cout * K];
+            j.dst[((size_t)n * j.real_cin + c) * j.taps + tap] = s;
+        } else if (j.dbdst) {
+            const int n = e - total;
+            float s = 0.f;
+            if (j.dbpart)
+                for (int sp = 0; sp < j.splits; ++sp) s += j.dbpart[(size_t)sp * j.Cout + n];
+            j.dbdst[n] = s;
+        }
+    }
+}
+
+int pa_launch_wgrad_reduce(const PaWgradReduceJob* jobs_dev, int njobs, int max_elems, hipStream_t st) {
+    if (njobs <= 0) return 0;
+    int bx = (max_elems + 255) / 256;
+    if (bx > 64) bx = 64;
+    if (bx < 1) bx = 1;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(bx, njobs), dim3(256), 0, st, jobs_dev);
+    return (int)hipGetLastError();
+}
+
+__global__ void stem_wgrad_reduce_kernel(const float* part, int splits, float* dst) {
+    const int total = 64 * 3 * 49;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        int n = e / 147, r = e - n * 147;
+        int c = r / 49, t = r - c * 49;
+        int ky = t / 7, kx = t - ky * 7;
+        const float* src = part + (size_t)n * 256 + ky * 32 + kx * 4 + c;
+        float s = 0.f;
+        for (int sp = 0; sp < splits; ++sp) s += src[(size_t)sp * 64 * 256];
+        dst[e] = s;
+    }
+}
+
+int pa_launch_stem_wgrad_reduce(const float* part, int splits, float* dst, hipStream_t st) {
+    hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3(37), dim3(256), 0, st, part, splits, dst);
+    return (int)hipGetLastError();
+}

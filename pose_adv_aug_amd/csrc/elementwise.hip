@@ -1,0 +1,518 @@
+// Streaming (HBM-bound) kernels around the convolutions: BatchNorm bookkeeping, 2x2 max pool,
+// nearest-upsample + add, their backward passes with the ReLU mask / BatchNorm-backward reductions
+// fused in, RMSprop, weight re-packing and layout conversion.  NHWC bf16, 16-byte accesses
+// (8 channels per thread), per-channel reductions staged through LDS atomics, one global atomic per
+// channel per workgroup.
+#include "common.h"
+#include "kernels.h"
+
+// ------------------------------------------------------------------------------------------------
+// BatchNorm bookkeeping (reference semantics: torch.nn.BatchNorm2d, eps 1e-5, momentum 0.1,
+// biased variance for normalisation, unbiased for the running estimate).
+__global__ void bn_finalize_kernel(const float* stats, const float* gamma, const float* beta, float* rmean, float* rvar,
+                                   float* scale, float* shift, float* mean, float* invstd, int C, float count,
+                                   float momentum, float eps, int update_running) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float mu = stats[c] / count;
+    float var = fmaxf(stats[C + c] / count - mu * mu, 0.f);
+    float is = rsqrtf(var + eps);
+    float s = gamma[c] * is;
+    scale[c] = s;
+    shift[c] = beta[c] - mu * s;
+    mean[c] = mu;
+    invstd[c] = is;
+    if (update_running) {
+        float unb = count > 1.f ? var * count / (count - 1.f) : var;
+        rmean[c] = (1.f - momentum) * rmean[c] + momentum * mu;
+        rvar[c] = (1.f - momentum) * rvar[c] + momentum * unb;
+    }
+}
+
+int pa_launch_bn_finalize(const float* stats, const float* gamma, const float* beta, float* rmean, float* rvar,
+                          float* scale, float* shift, float* mean, float* invstd, int C, float count,
+                          float momentum, float eps, int update_running, hipStream_t st) {
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, st, stats, gamma, beta, rmean, rvar, scale,
+                       shift, mean, invstd, C, count, momentum, eps, update_running);
+    return (int)hipGetLastError();
+}
+
+__global__ void bn_eval_kernel(const PaBnEvalJob* jobs, float eps) {
+    const PaBnEvalJob j = jobs[blockIdx.x];
+    for (int c = threadIdx.x; c < j.C; c += blockDim.x) {
+        float s = j.gamma[c] * rsqrtf(j.rvar[c] + eps);
+        j.scale[c] = s;
+        j.shift[c] = j.beta[c] - j.rmean[c] * s;
+    }
+}
+
+int pa_launch_bn_eval(const PaBnEvalJob* jobs_dev, int njobs, float eps, hipStream_t st) {
+    if (njobs <= 0) return 0;
+    hipLaunchKernelGGL(bn_eval_kernel, dim3(njobs), dim3(256), 0, st, jobs_dev, eps);
+    return (int)hipGetLastError();
+}
+
+// dx = s*(dz - S1/M - xhat*S2/M) = kA*dz + kB*x + kC    (per channel)
+__global__ void bn_bwd_finalize_kernel(const float* bstats, const float* scale, const float* mean, const float* invstd,
+                                       float* kA, float* kB, float* kC, float* dgamma, float* dbeta, int C, float count) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float S1 = bstats[c], S2 = bstats[C + c];
+    float s = scale[c], is = invstd[c], mu = mean[c];
+    kA[c] = s;
+    float b = -s * is * S2 / count;
+    kB[c] = b;
+    kC[c] = -s * S1 / count - b * mu;
+    if (dgamma) dgamma[c] = S2;
+    if (dbeta) dbeta[c] = S1;
+}
+
+int pa_launch_bn_bwd_finalize(const float* bstats, const float* scale, const float* mean, const float* invstd,
+                              float* kA, float* kB, float* kC, float* dgamma, float* dbeta, int C, float count,
+                              hipStream_t st) {
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, st, bstats, scale, mean, invstd, kA, kB,
+                       kC, dgamma, dbeta, C, count);
+    return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void load8_rt(const PaOperand& op, size_t idx, int c, float (&v)[8]) {
+    if (op.mode == PA_LD_PLAIN) pa_load8<PA_LD_PLAIN>(op, idx, c, v);
+    else if (op.mode == PA_LD_BNRELU) pa_load8<PA_LD_BNRELU>(op, idx, c, v);
+    else if (op.mode == PA_LD_LIN2) pa_load8<PA_LD_LIN2>(op, idx, c, v);
+    else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = 0.f;
+    }
+}
+
+// apply an epilogue to 8 channel values at element offset idx (channel c..c+7); s1/s2 accumulate the
+// per-channel reductions of the STATS / BWD modes
+__device__ __forceinline__ bf16x8 epilogue8(const PaEpilogue& ep, size_t idx, int c, const float (&v)[8],
+                                            float (&s1)[8], float (&s2)[8]) {
+    bf16x8 o;
+    if (ep.mode == PA_OUT_BWD) {
+        bf16x8 xr = *reinterpret_cast<const bf16x8*>(ep.xref + idx);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float x = (float)xr[j];
+            float dz = (fmaf(ep.scale[c + j], x, ep.shift[c + j]) > 0.f) ? v[j] : 0.f;
+            o[j] = (bf16)dz;
+            float dzr = (float)o[j];
+            s1[j] += dzr;
+            s2[j] += dzr * (x - ep.mean[c + j]) * ep.invstd[c + j];
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            o[j] = (bf16)v[j];
+            float r = (float)o[j];
+            s1[j] += r;
+            s2[j] += r * r;
+        }
+    }
+    return o;
+}
+
+// block-level flush of per-thread channel partials: LDS float atomics, then one global atomic per channel
+__device__ __forceinline__ void flush_stats(float* red /* [2*C] LDS, zeroed */, float* gstats, int C, int c,
+                                            const float (&s1)[8], const float (&s2)[8], bool active) {
+    if (active) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { atomicAdd(red + c + j, s1[j]); atomicAdd(red + C + c + j, s2[j]); }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) atomicAdd(gstats + i, red[i]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// 2x2/2 max pool (reference models/asn_stacked_hg.py:69,227), input transform applied on load
+__global__ void maxpool_fwd_kernel(PaOperand in, bf16* out, int B, int H, int W, int C) {
+    const int Ho = H / 2, Wo = W / 2, CG = C / 8;
+    const size_t total = (size_t)B * Ho * Wo * CG;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+        int cg = (int)(t % CG);
+        size_t p = t / CG;
+        int xo = (int)(p % Wo);
+        size_t q = p / Wo;
+        int yo = (int)(q % Ho), b = (int)(q / Ho);
+        int c = cg * 8;
+        float m[8];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            size_t idx = (((size_t)b * H + 2 * yo + (k >> 1)) * W + 2 * xo + (k & 1)) * C + c;
+            float v[8];
+            load8_rt(in, idx, c, v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) m[j] = (k == 0) ? v[j] : fmaxf(m[j], v[j]);
+        }
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (bf16)m[j];
+        *reinterpret_cast<bf16x8*>(out + p * C + c) = o;
+    }
+}
+
+int pa_launch_maxpool_fwd(const PaOperand& in, bf16* out, int B, int H, int W, int C, hipStream_t st) {
+    size_t total = (size_t)B * (H / 2) * (W / 2) * (C / 8);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(blocks), dim3(256), 0, st, in, out, B, H, W, C);
+    return (int)hipGetLastError();
+}
+
+// gradient of the max pool: routed to the first maximum in scan order (torch semantics), plus an
+// optional addend (other consumers' gradient), then the epilogue of the tensor being differentiated
+__global__ void maxpool_bwd_kernel(const bf16* dout, PaOperand in, PaOperand add, PaEpilogue ep, bf16* din,
+                                   int B, int H, int W, int C) {
+    extern __shared__ float red[];
+    const int Ho = H / 2, Wo = W / 2, CG = C / 8;
+    if (ep.mode != PA_OUT_PLAIN) {
+        for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) red[i] = 0.f;
+        __syncthreads();
+    }
+    const size_t total = (size_t)B * Ho * Wo * CG;
+    // blockDim (256) is a multiple of CG (<= 32), so a thread keeps its channel group across the loop
+    float s1[8], s2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+    const int cg = threadIdx.x % CG, c = cg * 8;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+        size_t p = t / CG;
+        int xo = (int)(p % Wo);
+        size_t q = p / Wo;
+        int yo = (int)(q % Ho), b = (int)(q / Ho);
+        bf16x8 g = *reinterpret_cast<const bf16x8*>(dout + p * C + c);
+        float v[4][8];
+        size_t idx[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            idx[k] = (((size_t)b * H + 2 * yo + (k >> 1)) * W + 2 * xo + (k & 1)) * C + c;
+            load8_rt(in, idx[k], c, v[k]);
+        }
+        int arg[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            int a = 0; float m = v[0][j];
+#pragma unroll
+            for (int k = 1; k < 4; ++k) if (v[k][j] > m) { m = v[k][j]; a = k; }
+            arg[j] = a;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float e[8], r[8];
+            load8_rt(add, idx[k], c, e);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) r[j] = (arg[j] == k ? (float)g[j] : 0.f) + e[j];
+            *reinterpret_cast<bf16x8*>(din + idx[k]) = epilogue8(ep, idx[k], c, r, s1, s2);
+        }
+    }
+    if (ep.mode != PA_OUT_PLAIN) flush_stats(red, ep.stats, C, c, s1, s2, true);
+}
+
+int pa_launch_maxpool_bwd(const bf16* dout, const PaOperand& in, const PaOperand& add, const PaEpilogue& ep, bf16* din,
+                          int B, int H, int W, int C, hipStream_t st) {
+    size_t total = (size_t)B * (H / 2) * (W / 2) * (C / 8);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(blocks), dim3(256), 2 * C * sizeof(float), st, dout, in, add, ep, din, B, H, W, C);
+    return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// out = nearest_upsample_x2(low) + skip   (reference models/asn_stacked_hg.py:193-203)
+__global__ void upadd_fwd_kernel(PaOperand low, PaOperand skip, bf16* out, int B, int H, int W, int C) {
+    const int CG = C / 8, Hl = H / 2, Wl = W / 2;
+    const size_t total = (size_t)B * H * W * CG;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+        int cg = (int)(t % CG);
+        size_t p = t / CG;
+        int x = (int)(p % W);
+        size_t q = p / W;
+        int y = (int)(q % H), b = (int)(q / H);
+        int c = cg * 8;
+        float a[8], s[8];
+        load8_rt(low, (((size_t)b * Hl + (y >> 1)) * Wl + (x >> 1)) * C + c, c, a);
+        load8_rt(skip, p * C + c, c, s);
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (bf16)(a[j] + s[j]);
+        *reinterpret_cast<bf16x8*>(out + p * C + c) = o;
+    }
+}
+
+int pa_launch_upadd_fwd(const PaOperand& low, const PaOperand& skip, bf16* out, int B, int H, int W, int C, hipStream_t st) {
+    size_t total = (size_t)B * H * W * (C / 8);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(upadd_fwd_kernel, dim3(blocks), dim3(256), 0, st, low, skip, out, B, H, W, C);
+    return (int)hipGetLastError();
+}
+
+// backward: dskip = epilogue_skip(dout), dlow = epilogue_low(sum of the 2x2 dout block)
+__global__ void upadd_bwd_kernel(const bf16* dout, PaEpilogue epl, bf16* dlow, PaEpilogue eps, bf16* dskip,
+                                 int B, int H, int W, int C) {
+    extern __shared__ float red[];     // [2*C] low | [2*C] skip
+    const int CG = C / 8, Hl = H / 2, Wl = W / 2;
+    for (int i = threadIdx.x; i < 4 * C; i += blockDim.x) red[i] = 0.f;
+    __syncthreads();
+    float l1[8], l2[8], k1[8], k2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { l1[j] = l2[j] = k1[j] = k2[j] = 0.f; }
+    const int cg = threadIdx.x % CG, c = cg * 8;
+    const size_t total = (size_t)B * Hl * Wl * CG;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+        size_t p = t / CG;
+        int xl = (int)(p % Wl);
+        size_t q = p / Wl;
+        int yl = (int)(q % Hl), b = (int)(q / Hl);
+        float sum[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sum[j] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            size_t idx = (((size_t)b * H + 2 * yl + (k >> 1)) * W + 2 * xl + (k & 1)) * C + c;
+            bf16x8 g = *reinterpret_cast<const bf16x8*>(dout + idx);
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { v[j] = (float)g[j]; sum[j] += v[j]; }
+            *reinterpret_cast<bf16x8*>(dskip + idx) = epilogue8(eps, idx, c, v, k1, k2);
+        }
+        size_t li = p * C + c;
+        *reinterpret_cast<bf16x8*>(dlow + li) = epilogue8(epl, li, c, sum, l1, l2);
+    }
+    if (epl.mode != PA_OUT_PLAIN) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { atomicAdd(red + c + j, l1[j]); atomicAdd(red + C + c + j, l2[j]); }
+    }
+    if (eps.mode != PA_OUT_PLAIN) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { atomicAdd(red + 2 * C + c + j, k1[j]); atomicAdd(red + 3 * C + c + j, k2[j]); }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) {
+        if (epl.mode != PA_OUT_PLAIN) atomicAdd(epl.stats + i, red[i]);
+        if (eps.mode != PA_OUT_PLAIN) atomicAdd(eps.stats + i, red[2 * C + i]);
+    }
+}
+
+int pa_launch_upadd_bwd(const bf16* dout, const PaEpilogue& ep_low, bf16* dlow, const PaEpilogue& ep_skip, bf16* dskip,
+                        int B, int H, int W, int C, hipStream_t st) {
+    size_t total = (size_t)B * (H / 2) * (W / 2) * (C / 8);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(upadd_bwd_kernel, dim3(blocks), dim3(256), 4 * C * sizeof(float), st, dout, ep_low, dlow, ep_skip, dskip,
+                       B, H, W, C);
+    return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// RMSprop exactly as torch.optim.RMSprop(alpha, eps, momentum=0, weight_decay=0, centered=False)
+// (reference stack-hg.py:51-52): v = alpha v + (1-alpha) g^2 ; p -= lr g / (sqrt(v) + eps).
+// gscale multiplies the gradient first (1/world_size after a sum all-reduce).
+__global__ void rmsprop_kernel(float* p, const float* g, float* v, size_t n, float lr, float alpha, float eps, float gscale) {
+    size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const size_t stride = (size_t)gridDim.x * blockDim.x * 4;
+    for (; i + 3 < n; i += stride) {
+        f32x4 gg = *reinterpret_cast<const f32x4*>(g + i), vv = *reinterpret_cast<f32x4*>(v + i), pp = *reinterpret_cast<f32x4*>(p + i);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float gr = gg[j] * gscale;
+            vv[j] = alpha * vv[j] + (1.f - alpha) * gr * gr;
+            pp[j] = pp[j] - lr * (gr / (sqrtf(vv[j]) + eps));
+        }
+        *reinterpret_cast<f32x4*>(v + i) = vv;
+        *reinterpret_cast<f32x4*>(p + i) = pp;
+    }
+    for (; i < n && i + 3 >= n; ++i) {          // tail (at most 3 elements, one thread)
+        float gr = g[i] * gscale;
+        v[i] = alpha * v[i] + (1.f - alpha) * gr * gr;
+        p[i] = p[i] - lr * (gr / (sqrtf(v[i]) + eps));
+    }
+}
+
+int pa_launch_rmsprop(float* p, const float* g, float* v, size_t n, float lr, float alpha, float eps, float gscale, hipStream_t st) {
+    if (n == 0) return 0;
+    int blocks = (int)((n / 4 + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(rmsprop_kernel, dim3(blocks), dim3(256), 0, st, p, g, v, n, lr, alpha, eps, gscale);
+    return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// fp32 master weights (PyTorch layout [Cout][Cin][taps]) -> bf16 compute copies
+//   wf[n][tap][c]            forward / wgrad layout, zero padded to pad_cout x pad_cin
+//   wb[c][taps-1-tap][n]     dgrad layout (transposed, taps flipped)
+// taps == 49 marks the 7x7 stem: wf[n][ky*32 + kx*4 + c] (K padded to 256), no wb.
+__global__ void weight_prep_kernel(const PaPrepJob* jobs) {
+    const PaPrepJob j = jobs[blockIdx.y];
+    if (j.taps == 49) {
+        const int total = j.pad_cout * 256;
+        for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+            int n = e >> 8, k = e & 255;
+            int ky = k >> 5, kx = (k & 31) >> 2, c = k & 3;
+            float v = 0.f;
+            if (n < j.Cout && ky < 7 && kx < 7 && c < j.Cin) v = j.w[((size_t)(n * j.Cin + c) * 7 + ky) * 7 + kx];
+            j.wf[e] = (bf16)v;
+        }
+        return;
+    }
+    const int per = j.pad_cout * j.pad_cin * j.taps;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < 2 * per; e += gridDim.x * blockDim.x) {
+        if (e < per) {
+            int n = e / (j.taps * j.pad_cin);
+            int r = e - n * j.taps * j.pad_cin;
+            int tap = r / j.pad_cin, c = r - tap * j.pad_cin;
+            float v = (n < j.Cout && c < j.Cin) ? j.w[((size_t)n * j.Cin + c) * j.taps + tap] : 0.f;
+            j.wf[e] = (bf16)v;
+        } else if (j.wb) {
+            int f = e - per;
+            int c = f / (j.taps * j.pad_cout);
+            int r = f - c * j.taps * j.pad_cout;
+            int tapb = r / j.pad_cout, n = r - tapb * j.pad_cout;
+            int tap = j.taps - 1 - tapb;
+            float v = (n < j.Cout && c < j.Cin) ? j.w[((size_t)n * j.Cin + c) * j.taps + tap] : 0.f;
+            j.wb[f] = (bf16)v;
+        }
+    }
+}
+
+int pa_launch_weight_prep(const PaPrepJob* jobs_dev, int njobs, int max_elems, hipStream_t st) {
+    if (njobs <= 0) return 0;
+    int bx = (2 * max_elems + 255) / 256;
+    if (bx > 64) bx = 64;
+    if (bx < 1) bx = 1;
+    hipLaunchKernelGGL(weight_prep_kernel, dim3(bx, njobs), dim3(256), 0, st, jobs_dev);
+    return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// layout conversion
+__global__ void nchw_to_nhwc4_kernel(const float* src, bf16* dst, int B, int H, int W) {
+    const size_t total = (size_t)B * H * W;
+    for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (size_t)gridDim.x * blockDim.x) {
+        size_t hw = (size_t)H * W;
+        size_t b = p / hw, r = p - b * hw;
+        bf16x4 o;
+        o[0] = (bf16)src[(b * 3 + 0) * hw + r];
+        o[1] = (bf16)src[(b * 3 + 1) * hw + r];
+        o[2] = (bf16)src[(b * 3 + 2) * hw + r];
+        o[3] = (bf16)0.f;
+        *reinterpret_cast<bf16x4*>(dst + p * 4) = o;
+    }
+}
+
+int pa_launch_nchw_to_nhwc4(const float* src, bf16* dst, int B, int H, int W, hipStream_t st) {
+    size_t total = (size_t)B * H * W;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(nchw_to_nhwc4_kernel, dim3(blocks), dim3(256), 0, st, src, dst, B, H, W);
+    return (int)hipGetLastError();
+}
+
+__global__ void nhwc_to_nchw_f32_kernel(const float* src, float* dst, int B, int H, int W, int C) {
+    const size_t total = (size_t)B * C * H * W;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        size_t hw = (size_t)H * W;
+        size_t b = e / (C * hw), r = e - b * C * hw;
+        size_t c = r / hw, p = r - c * hw;
+        dst[e] = src[(b * hw + p) * C + c];
+    }
+}
+
+int pa_launch_nhwc_to_nchw_f32(const float* src, float* dst, int B, int H, int W, int C, hipStream_t st) {
+    size_t total = (size_t)B * H * W * C;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(nhwc_to_nchw_f32_kernel, dim3(blocks), dim3(256), 0, st, src, dst, B, H, W, C);
+    return (int)hipGetLastError();
+}
+
+__global__ void nchw_f32_to_nhwc_bf16_kernel(const float* src, bf16* dst, int B, int C, int H, int W) {
+    const size_t total = (size_t)B * C * H * W;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        size_t hw = (size_t)H * W;
+        size_t c = e % C, p = e / C;           // destination order
+        size_t b = p / hw, r = p - b * hw;
+        dst[e] = (bf16)src[(b * C + c) * hw + r];
+    }
+}
+
+int pa_launch_nchw_f32_to_nhwc_bf16(const float* src, bf16* dst, int B, int C, int H, int W, hipStream_t st) {
+    size_t total = (size_t)B * H * W * C;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(nchw_f32_to_nhwc_bf16_kernel, dim3(blocks), dim3(256), 0, st, src, dst, B, C, H, W);
+    return (int)hipGetLastError();
+}
+
+__global__ void nhwc_bf16_to_nchw_f32_kernel(PaOperand src, float* dst, int B, int C, int H, int W) {
+    const size_t total = (size_t)B * C * H * W;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        size_t hw = (size_t)H * W;
+        size_t c = e % C, p = e / C;           // source order
+        size_t b = p / hw, r = p - b * hw;
+        float v = (float)src.p[e];
+        if (src.mode == PA_LD_BNRELU) v = fmaxf(fmaf(src.k0[c], v, src.k1[c]), 0.f);
+        else if (src.mode == PA_LD_LIN2) v = fmaf(src.k0[c], v, fmaf(src.k1[c], (float)src.q[e], src.k2[c]));
+        dst[(b * C + c) * hw + r] = v;
+    }
+}
+
+int pa_launch_nhwc_bf16_to_nchw_f32(const PaOperand& src, float* dst, int B, int C, int H, int W, hipStream_t st) {
+    size_t total = (size_t)B * H * W * C;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(nhwc_bf16_to_nchw_f32_kernel, dim3(blocks), dim3(256), 0, st, src, dst, B, C, H, W);
+    return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// apply an epilogue to a gradient tensor (e.g. mask + BatchNorm-backward reductions of a gradient
+// that arrives from outside the conv kernels)
+__global__ void ep_apply_kernel(PaOperand g, PaEpilogue ep, bf16* out, size_t M, int C) {
+    extern __shared__ float red[];
+    const int CG = C / 8;
+    if (ep.mode != PA_OUT_PLAIN) {
+        for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) red[i] = 0.f;
+        __syncthreads();
+    }
+    float s1[8], s2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+    const int c = (threadIdx.x % CG) * 8;
+    const size_t total = M * CG;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+        const size_t idx = (t / CG) * C + c;
+        float v[8];
+        load8_rt(g, idx, c, v);
+        *reinterpret_cast<bf16x8*>(out + idx) = epilogue8(ep, idx, c, v, s1, s2);
+    }
+    if (ep.mode != PA_OUT_PLAIN) flush_stats(red, ep.stats, C, c, s1, s2, true);
+}
+
+int pa_launch_ep_apply(const PaOperand& g, const PaEpilogue& ep, bf16* out, size_t M, int C, hipStream_t st) {
+    size_t total = M * (C / 8);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(ep_apply_kernel, dim3(blocks), dim3(256), 2 * C * sizeof(float), st, g, ep, out, M, C);
+    return (int)hipGetLastError();
+}
+
+__global__ void fill_kernel(float* p, float v, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}
+
+int pa_launch_fill(float* p, float v, size_t n, hipStream_t st) {
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(fill_kernel, dim3(blocks), dim3(256), 0, st, p, v, n);
+    return (int)hipGetLastError();
+}

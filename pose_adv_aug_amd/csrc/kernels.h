@@ -1,0 +1,80 @@
+// Host-side launch interface of the HIP kernels (internal; the public C ABI is include/poseadv.h).
+#pragma once
+#include "common.h"
+
+struct PaConvArgs {
+    PaOperand in;        // [B][H][W][Cin] NHWC bf16
+    const bf16* w;       // [Cout][taps*Cin] bf16 (tap-major, channel-minor)
+    const float* bias;   // [Cout] or nullptr
+    PaOperand add1;      // optional epilogue addends over [M][Cout]
+    PaOperand add2;
+    PaEpilogue ep;
+    bf16* out;           // [M][Cout]
+    int B, H, W, Cin, Cout, taps;
+};
+int pa_launch_conv(const PaConvArgs& a, hipStream_t st);
+
+// Weight gradient: dw[n][tap][c] = sum_m dy(m)[n] * x(pixel(m)+tap)[c], split over m into `splits`
+// deterministic partial slabs part[split][Cout][taps*Cin] (fp32); optional bias-gradient partials
+// dbpart[split][Cout] (column sums of dy).
+struct PaWgradArgs {
+    PaOperand dy;        // [M][Cout]  (PLAIN or LIN2)
+    PaOperand x;         // [B][H][W][Cin] (PLAIN or BNRELU)
+    float* part;
+    float* dbpart;       // or nullptr
+    int B, H, W, Cin, Cout, taps, splits;
+};
+int pa_launch_wgrad(const PaWgradArgs& a, hipStream_t st);
+int pa_wgrad_splits(int M, int Cin, int Cout, int taps);
+
+// reduce partial slabs into the fp32 gradient in PyTorch layout  dst[n][c][tap]  (real_cin/real_cout
+// select the un-padded sub-block for the 16-channel head layers)
+struct PaWgradReduceJob {
+    const float* part; float* dst; const float* dbpart; float* dbdst;
+    int Cout, Cin, taps, splits, real_cout, real_cin;
+};
+int pa_launch_wgrad_reduce(const PaWgradReduceJob* jobs_dev, int njobs, int max_elems, hipStream_t st);
+
+// ---- BatchNorm bookkeeping
+// forward: stats[2][C] (sum, sumsq over `count` values) -> scale/shift/mean/invstd, running stats update
+int pa_launch_bn_finalize(const float* stats, const float* gamma, const float* beta, float* rmean, float* rvar,
+                          float* scale, float* shift, float* mean, float* invstd, int C, float count,
+                          float momentum, float eps, int update_running, hipStream_t st);
+// eval: scale/shift from running stats, for `n` BatchNorms described by a device table
+struct PaBnEvalJob { const float* gamma; const float* beta; const float* rmean; const float* rvar; float* scale; float* shift; int C; };
+int pa_launch_bn_eval(const PaBnEvalJob* jobs_dev, int njobs, float eps, hipStream_t st);
+// backward: bstats[2][C] (sum dz, sum dz*xhat) -> LIN2 coefficients (A,B,C), dgamma, dbeta
+int pa_launch_bn_bwd_finalize(const float* bstats, const float* scale, const float* mean, const float* invstd,
+                              float* kA, float* kB, float* kC, float* dgamma, float* dbeta, int C, float count,
+                              hipStream_t st);
+
+// ---- pooling / upsampling (NHWC bf16)
+int pa_launch_maxpool_fwd(const PaOperand& in, bf16* out, int B, int H, int W, int C, hipStream_t st);
+// grad of 2x2 max pool routed to the arg-max (first max in scan order), + optional addend, then epilogue
+int pa_launch_maxpool_bwd(const bf16* dout, const PaOperand& in, const PaOperand& add, const PaEpilogue& ep, bf16* din,
+                          int B, int H, int W, int C, hipStream_t st);
+// out = nearest_up2(low) + skip        (low: [B][H/2][W/2][C], skip/out: [B][H][W][C])
+int pa_launch_upadd_fwd(const PaOperand& low, const PaOperand& skip, bf16* out, int B, int H, int W, int C, hipStream_t st);
+int pa_launch_upadd_bwd(const bf16* dout, const PaEpilogue& ep_low, bf16* dlow, const PaEpilogue& ep_skip, bf16* dskip,
+                        int B, int H, int W, int C, hipStream_t st);
+
+// ---- stem 7x7 stride-2 conv as a K=256 GEMM over the 4-channel-padded NHWC bf16 image
+// (in.p / x.p = img4 [B][2H][2W][4], Cin = 256 virtual patch length, Cout = 64, H/W = OUTPUT dims)
+int pa_launch_stem_conv(const PaConvArgs& a, hipStream_t st);
+int pa_launch_stem_wgrad(const PaWgradArgs& a, hipStream_t st);
+// reduce the stem's partial slabs [splits][64][256] into PyTorch layout dst[64][3][7][7]
+int pa_launch_stem_wgrad_reduce(const float* part, int splits, float* dst, hipStream_t st);
+
+// ---- optimizer / weight preparation
+int pa_launch_rmsprop(float* p, const float* g, float* v, size_t n, float lr, float alpha, float eps, float gscale, hipStream_t st);
+struct PaPrepJob { const float* w; bf16* wf; bf16* wb; int Cout, Cin, taps, pad_cout, pad_cin; };
+int pa_launch_weight_prep(const PaPrepJob* jobs_dev, int njobs, int max_elems, hipStream_t st);
+
+// ---- layout helpers
+int pa_launch_nchw_to_nhwc4(const float* src, bf16* dst, int B, int H, int W, hipStream_t st);
+int pa_launch_nhwc_to_nchw_f32(const float* src, float* dst, int B, int H, int W, int C, hipStream_t st);
+int pa_launch_nchw_f32_to_nhwc_bf16(const float* src, bf16* dst, int B, int C, int H, int W, hipStream_t st);
+int pa_launch_nhwc_bf16_to_nchw_f32(const PaOperand& src, float* dst, int B, int C, int H, int W, hipStream_t st);
+
+int pa_launch_ep_apply(const PaOperand& g, const PaEpilogue& ep, bf16* out, size_t M, int C, hipStream_t st);
+int pa_launch_fill(float* p, float v, size_t n, hipStream_t st);

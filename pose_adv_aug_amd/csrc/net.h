@@ -1,0 +1,161 @@
+// Stacked-hourglass pose network + ASN scale/rotation agent as an explicit launch plan over the
+// HIP kernels (no autograd, no graph compiler): forward saves exactly what the hand-written backward
+// needs.  Mirrors the reference module tree (models/asn_stacked_hg.py) name-for-name so that
+// checkpoints interchange.  Internal header; the public C ABI is include/poseadv.h.
+#pragma once
+#include <string>
+#include <vector>
+#include "common.h"
+#include "kernels.h"
+#include "pose_ops.h"
+
+struct Arena {
+    char* base = nullptr;
+    size_t off = 0;
+    void* take(size_t bytes) {
+        off = (off + 255) & ~(size_t)255;
+        void* p = base ? base + off : nullptr;
+        off += bytes;
+        return p;
+    }
+    template <typename T> T* get(size_t n) { return reinterpret_cast<T*>(take(n * sizeof(T))); }
+};
+
+struct TensorInfo {          // one state_dict entry
+    std::string name;
+    int shape[4];
+    int ndim;
+    size_t offset;           // element offset into the flat parameter (or buffer) array
+    size_t numel;
+    int is_buffer;           // 0 parameter, 1 running_mean/var buffer, 2 num_batches_tracked (host-side int64)
+};
+
+struct BNLayer {
+    int C = 0;
+    size_t p_gamma = 0, p_beta = 0, b_rmean = 0, b_rvar = 0;
+    float *stats = nullptr, *bstats = nullptr;                 // [2C] each, zeroed at the start of a step
+    float *scale = nullptr, *shift = nullptr, *mean = nullptr, *invstd = nullptr;
+    float *kA = nullptr, *kB = nullptr, *kC = nullptr;
+};
+
+struct ConvLayer {
+    int Cin = 0, Cout = 0, k = 1;          // real dims
+    int pcin = 0, pcout = 0;               // padded (multiple of 64) dims used by the kernels
+    size_t p_w = 0, p_b = 0;
+    bf16 *wf = nullptr, *wb = nullptr;
+    float *part = nullptr, *dbpart = nullptr;
+    int splits = 0;
+    bool has_bn_after = true;
+    int taps() const { return k * k; }
+};
+
+struct Act {                 // NHWC bf16 activation; `bn` != null means BatchNorm+ReLU is still pending
+    bf16* raw = nullptr;
+    bf16* grad = nullptr;    // masked gradient dz when bn != null, plain gradient otherwise
+    BNLayer* bn = nullptr;
+    int B = 0, H = 0, W = 0, C = 0;
+    size_t numel() const { return (size_t)B * H * W * C; }
+    int M() const { return B * H * W; }
+};
+
+struct Net;
+
+struct Residual {
+    ConvLayer c1, c2, c3, ad;
+    BNLayer b1, b2, b3;
+    bool has_adapter = false;
+    int cin = 0, cout = 0;
+    Act x1, x2, x3;          // raw conv outputs (x3 includes the shortcut)
+    bf16* adout = nullptr;   // adapter(x)
+    bf16* adgrad = nullptr;  // scratch for the adapter's data gradient
+    void declare(Net& n, const std::string& prefix, int cin, int cout, bool adapter);
+    void layout(Net& n, Arena& a, int B, int H, int W, bool need_grad);
+    int fwd(Net& n, const Act& in);
+    int bwd(Net& n, const Act& in, const PaOperand& extra, bool in_needs_grad);
+};
+
+struct Hourglass {
+    Residual down[4], up[4], skip[4], neck;
+    Act pooled[4], merged[4];     // pool outputs p_k (k=1..4), upsample-add outputs o_k
+    bf16* poolgrad[4] = {nullptr, nullptr, nullptr, nullptr};   // gradient of the pool routed back to its input
+    void declare(Net& n, const std::string& prefix, int chan);
+    void layout(Net& n, Arena& a, int B, int H, int W, bool need_grad);
+    int encode(Net& n, const Act& in);
+    int decode(Net& n);
+    int bwd(Net& n, const Act& in, const PaOperand& extra0);
+    const Act& out() const { return merged[0]; }
+};
+
+struct Net {
+    // configuration
+    int stacks = 2, chan = 256, classes = 16, B = 0, res = 256;
+    bool is_agent = false;
+    // tables
+    std::vector<TensorInfo> tensors;           // state_dict order
+    size_t n_params = 0, n_buffers = 0;
+    std::vector<ConvLayer*> convs;
+    std::vector<BNLayer*> bns;
+    // bound memory
+    float *params = nullptr, *grads = nullptr, *buffers = nullptr;
+    char* workspace = nullptr;
+    size_t workspace_bytes = 0;
+    float *stats_arena = nullptr;
+    size_t stats_arena_floats = 0;
+    float* loss_dev = nullptr;                 // [stacks] per-stack loss, part of the stats arena
+    // device job tables
+    PaPrepJob* prep_jobs = nullptr; int n_prep = 0, prep_max = 0;
+    PaWgradReduceJob* red_jobs = nullptr; int n_red = 0, red_max = 0;
+    PaBnEvalJob* bneval_jobs = nullptr; int n_bneval = 0;
+    // run state
+    hipStream_t st = nullptr;
+    bool train_bn = true;
+    float momentum = 0.1f, eps = 1e-5f;
+
+    // ---- pose net modules
+    ConvLayer stem_conv; BNLayer stem_bn;
+    Residual res1, res2, res3;
+    std::vector<Hourglass> hg;
+    std::vector<Residual> post;
+    std::vector<ConvLayer> lin; std::vector<BNLayer> lin_bn;
+    std::vector<ConvLayer> outc, forth, inc;
+    bf16* img4 = nullptr;
+    Act a0, pool0;
+    bf16* pool0grad_unused = nullptr;
+    std::vector<Act> lin_out, xin;                 // xin[i] = input of stack i
+    std::vector<float*> heat; std::vector<bf16*> heat64, dheat64, dheat_in, forth_tmp, lgrad_tmp;
+    double* pts_dev = nullptr;                     // [B][16][2] heat-map coords (caller provided per step)
+
+    // ---- declaration helpers
+    size_t add_param(const std::string& name, std::initializer_list<int> shape);
+    size_t add_buffer(const std::string& name, int C);
+    void declare_conv(ConvLayer& c, const std::string& name, int cin, int cout, int k, bool bn_after);
+    void declare_bn(BNLayer& b, const std::string& name, int C);
+    void layout_conv(ConvLayer& c, Arena& a, int M);
+    void layout_bn(BNLayer& b, Arena& a);
+    Act new_act(Arena& a, int B, int H, int W, int C, BNLayer* bn, bool need_grad);
+
+    void declare_pose();
+    size_t layout_all(char* base);
+    int upload_tables();
+
+    // ---- runtime helpers
+    PaOperand op(const Act& a) const;               // value of an activation (BNRELU pending or PLAIN)
+    PaOperand gradop(const Act& a) const;           // gradient w.r.t. the raw tensor (LIN2 or PLAIN)
+    PaEpilogue final_ep(const Act& a) const;        // epilogue that finishes a gradient for `a`
+    int finish_grad(const Act& a);                  // BatchNorm backward finalize (if pending BN)
+    int conv_fwd(ConvLayer& c, const PaOperand& in, int B, int H, int W, const PaOperand& add1, const PaOperand& add2,
+                 bf16* out, BNLayer* bn_after);
+    int conv_dgrad(ConvLayer& c, const PaOperand& dy, int B, int H, int W, const PaOperand& add1, const PaOperand& add2,
+                   const PaEpilogue& ep, bf16* out);
+    int conv_wgrad(ConvLayer& c, const PaOperand& dy, const PaOperand& x, int B, int H, int W);
+
+    int prepare_weights();
+    int begin_step();
+    const bf16* cur_image = nullptr;
+    int forward_pose(const float* img_nchw, const bf16* img4_in, const double* pts, bool train, float* loss_out_dev);
+    int backward_pose();
+    int reduce_grads();
+};
+
+PaOperand pa_plain(const bf16* p);
+PaOperand pa_none();

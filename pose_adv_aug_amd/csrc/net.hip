@@ -1,0 +1,468 @@
+// Launch plan of the stacked-hourglass pose network (reference models/asn_stacked_hg.py:11-347):
+// declaration of the parameter table in the reference's state_dict order, workspace layout, forward,
+// hand-written backward and gradient reduction.  See net.h.
+#include "net.h"
+#include <stdio.h>
+#include <string.h>
+
+#define TRY(x) do { int _r = (x); if (_r) return _r; } while (0)
+
+PaOperand pa_plain(const bf16* p) { PaOperand o; o.p = p; o.q = nullptr; o.k0 = o.k1 = o.k2 = nullptr; o.mode = PA_LD_PLAIN; return o; }
+PaOperand pa_none() { PaOperand o; o.p = o.q = nullptr; o.k0 = o.k1 = o.k2 = nullptr; o.mode = PA_LD_NONE; return o; }
+static PaEpilogue ep_plain() { PaEpilogue e; memset(&e, 0, sizeof e); e.mode = PA_OUT_PLAIN; return e; }
+static int round64(int v) { return (v + 63) / 64 * 64; }
+
+// ------------------------------------------------------------------------------------------------
+// declaration
+size_t Net::add_param(const std::string& name, std::initializer_list<int> shape) {
+    TensorInfo t; t.name = name; t.ndim = (int)shape.size(); t.is_buffer = 0;
+    size_t n = 1; int i = 0;
+    for (int s : shape) { t.shape[i++] = s; n *= (size_t)s; }
+    for (; i < 4; ++i) t.shape[i] = 1;
+    n_params = (n_params + 3) & ~(size_t)3;           // 16-byte aligned tensors (float4 bias loads)
+    t.offset = n_params; t.numel = n;
+    n_params += n;
+    tensors.push_back(t);
+    return t.offset;
+}
+
+size_t Net::add_buffer(const std::string& name, int C) {
+    TensorInfo t; t.name = name; t.ndim = 1; t.shape[0] = C; t.shape[1] = t.shape[2] = t.shape[3] = 1; t.is_buffer = 1;
+    t.offset = n_buffers; t.numel = (size_t)C;
+    n_buffers += (size_t)C;
+    tensors.push_back(t);
+    return t.offset;
+}
+
+void Net::declare_conv(ConvLayer& c, const std::string& name, int cin, int cout, int k, bool bn_after) {
+    c.Cin = cin; c.Cout = cout; c.k = k; c.has_bn_after = bn_after;
+    c.pcin = (k == 7) ? 256 : round64(cin);
+    c.pcout = round64(cout);
+    c.p_w = add_param(name + ".weight", {cout, cin, k, k});
+    c.p_b = add_param(name + ".bias", {cout});
+    convs.push_back(&c);
+}
+
+void Net::declare_bn(BNLayer& b, const std::string& name, int C) {
+    b.C = C;
+    b.p_gamma = add_param(name + ".weight", {C});
+    b.p_beta = add_param(name + ".bias", {C});
+    b.b_rmean = add_buffer(name + ".running_mean", C);
+    b.b_rvar = add_buffer(name + ".running_var", C);
+    TensorInfo t; t.name = name + ".num_batches_tracked"; t.ndim = 0; t.shape[0] = t.shape[1] = t.shape[2] = t.shape[3] = 1;
+    t.is_buffer = 2; t.offset = 0; t.numel = 1;
+    tensors.push_back(t);
+    bns.push_back(&b);
+}
+
+void Residual::declare(Net& n, const std::string& p, int cin_, int cout_, bool adapter) {
+    cin = cin_; cout = cout_; has_adapter = adapter;
+    const int mid = cout / 2;
+    n.declare_conv(c1, p + "conv1", cin, mid, 1, true);  n.declare_bn(b1, p + "bn1", mid);
+    n.declare_conv(c2, p + "conv2", mid, mid, 3, true);  n.declare_bn(b2, p + "bn2", mid);
+    n.declare_conv(c3, p + "conv3", mid, cout, 1, true); n.declare_bn(b3, p + "bn3", cout);
+    if (adapter) n.declare_conv(ad, p + "adapter", cin, cout, 1, true);     // feeds bn3: bias gradient is zero
+}
+
+void Hourglass::declare(Net& n, const std::string& p, int chan) {
+    // registration order of the reference (:56-68); num_modules == 1 => "<site>.0."
+    const char* dn[4] = {"down1", "down2", "down3", "down4"};
+    const char* un[4] = {"up1", "up2", "up3", "up4"};
+    const char* sn[4] = {"skip1", "skip2", "skip3", "skip4"};
+    for (int k = 0; k < 4; ++k) down[k].declare(n, p + dn[k] + ".0.", chan, chan, false);
+    for (int k = 0; k < 4; ++k) up[k].declare(n, p + un[k] + ".0.", chan, chan, false);
+    for (int k = 0; k < 4; ++k) skip[k].declare(n, p + sn[k] + ".0.", chan, chan, false);
+    neck.declare(n, p + "neck.0.", chan, chan, false);
+}
+
+void Net::declare_pose() {
+    declare_conv(stem_conv, "conv1", 3, 64, 7, true);
+    declare_bn(stem_bn, "bn1", 64);
+    res1.declare(*this, "residual1.", 64, 128, true);
+    res2.declare(*this, "residual2.", 128, 128, false);
+    res3.declare(*this, "residual3.", 128, chan, true);
+    hg.resize(stacks); post.resize(stacks); lin.resize(stacks); lin_bn.resize(stacks); outc.resize(stacks);
+    forth.resize(stacks > 0 ? stacks - 1 : 0); inc.resize(stacks > 0 ? stacks - 1 : 0);
+    char buf[64];
+    for (int i = 0; i < stacks; ++i) { snprintf(buf, sizeof buf, "hg.%d.", i); hg[i].declare(*this, buf, chan); }
+    for (int i = 0; i < stacks; ++i) { snprintf(buf, sizeof buf, "post_res.%d.0.", i); post[i].declare(*this, buf, chan, chan, false); }
+    for (int i = 0; i < stacks; ++i) {
+        snprintf(buf, sizeof buf, "linear.%d.0", i); declare_conv(lin[i], buf, chan, chan, 1, true);
+        snprintf(buf, sizeof buf, "linear.%d.1", i); declare_bn(lin_bn[i], buf, chan);
+    }
+    for (int i = 0; i < stacks; ++i) { snprintf(buf, sizeof buf, "out_conv.%d", i); declare_conv(outc[i], buf, chan, classes, 1, false); }
+    for (int i = 0; i + 1 < stacks; ++i) { snprintf(buf, sizeof buf, "forth_conv.%d", i); declare_conv(forth[i], buf, chan, chan, 1, false); }
+    for (int i = 0; i + 1 < stacks; ++i) { snprintf(buf, sizeof buf, "in_conv.%d", i); declare_conv(inc[i], buf, classes, chan, 1, false); }
+    n_params = (n_params + 3) & ~(size_t)3;
+}
+
+// ------------------------------------------------------------------------------------------------
+// workspace layout
+void Net::layout_conv(ConvLayer& c, Arena& a, int M) {
+    const size_t wn = (size_t)c.pcout * (c.k == 7 ? 1 : c.taps()) * c.pcin;
+    c.wf = a.get<bf16>(wn);
+    c.wb = (c.k == 7) ? nullptr : a.get<bf16>(wn);
+    c.splits = pa_wgrad_splits(M, c.pcin, c.pcout, c.k == 7 ? 1 : c.taps());
+    c.part = a.get<float>((size_t)c.splits * wn);
+    c.dbpart = c.has_bn_after ? nullptr : a.get<float>((size_t)c.splits * c.pcout);
+}
+
+void Net::layout_bn(BNLayer& b, Arena& a) {
+    b.scale = a.get<float>(b.C); b.shift = a.get<float>(b.C); b.mean = a.get<float>(b.C); b.invstd = a.get<float>(b.C);
+    b.kA = a.get<float>(b.C); b.kB = a.get<float>(b.C); b.kC = a.get<float>(b.C);
+}
+
+Act Net::new_act(Arena& a, int B_, int H, int W, int C, BNLayer* bn, bool need_grad) {
+    Act t; t.B = B_; t.H = H; t.W = W; t.C = C; t.bn = bn;
+    t.raw = a.get<bf16>(t.numel());
+    t.grad = need_grad ? a.get<bf16>(t.numel()) : nullptr;
+    return t;
+}
+
+void Residual::layout(Net& n, Arena& a, int B, int H, int W, bool need_grad) {
+    const int M = B * H * W, mid = cout / 2;
+    n.layout_conv(c1, a, M); n.layout_conv(c2, a, M); n.layout_conv(c3, a, M);
+    n.layout_bn(b1, a); n.layout_bn(b2, a); n.layout_bn(b3, a);
+    x1 = n.new_act(a, B, H, W, mid, &b1, need_grad);
+    x2 = n.new_act(a, B, H, W, mid, &b2, need_grad);
+    x3 = n.new_act(a, B, H, W, cout, &b3, need_grad);
+    if (has_adapter) {
+        n.layout_conv(ad, a, M);
+        adout = a.get<bf16>((size_t)M * cout);
+        adgrad = need_grad ? a.get<bf16>((size_t)M * cin) : nullptr;
+    }
+}
+
+void Hourglass::layout(Net& n, Arena& a, int B, int H, int W, bool need_grad) {
+    const int C = neck.cout;
+    for (int k = 0; k < 4; ++k) {
+        skip[k].layout(n, a, B, H >> k, W >> k, need_grad);
+        pooled[k] = n.new_act(a, B, H >> (k + 1), W >> (k + 1), C, nullptr, need_grad);
+        down[k].layout(n, a, B, H >> (k + 1), W >> (k + 1), need_grad);
+        poolgrad[k] = need_grad ? a.get<bf16>((size_t)B * (H >> k) * (W >> k) * C) : nullptr;
+    }
+    neck.layout(n, a, B, H >> 4, W >> 4, need_grad);
+    for (int k = 3; k >= 0; --k) {
+        up[k].layout(n, a, B, H >> (k + 1), W >> (k + 1), need_grad);
+        merged[k] = n.new_act(a, B, H >> k, W >> k, C, nullptr, need_grad);
+    }
+}
+
+size_t Net::layout_all(char* base) {
+    Arena a; a.base = base;
+    // region zeroed at the start of every step: BatchNorm statistic accumulators + per-stack loss
+    size_t zero_begin = a.off;
+    for (BNLayer* b : bns) { b->stats = a.get<float>(2 * b->C); b->bstats = a.get<float>(2 * b->C); }
+    loss_dev = a.get<float>(64);
+    a.take(0);
+    stats_arena = base ? reinterpret_cast<float*>(base + zero_begin) : nullptr;
+    stats_arena_floats = (a.off - zero_begin) / sizeof(float);
+    // job tables
+    prep_jobs = a.get<PaPrepJob>(convs.size());
+    red_jobs = a.get<PaWgradReduceJob>(convs.size());
+    bneval_jobs = a.get<PaBnEvalJob>(bns.size());
+
+    const int H2 = res / 2, H4 = res / 4;
+    img4 = a.get<bf16>((size_t)B * res * res * 4);
+    pts_dev = a.get<double>((size_t)B * classes * 2);
+    layout_conv(stem_conv, a, B * H2 * H2);
+    layout_bn(stem_bn, a);
+    a0 = new_act(a, B, H2, H2, 64, &stem_bn, true);
+    res1.layout(*this, a, B, H2, H2, true);
+    pool0 = new_act(a, B, H4, H4, 128, nullptr, true);
+    res2.layout(*this, a, B, H4, H4, true);
+    res3.layout(*this, a, B, H4, H4, true);
+    lin_out.resize(stacks); xin.resize(stacks); heat.resize(stacks); heat64.resize(stacks); dheat64.resize(stacks);
+    dheat_in.resize(stacks); forth_tmp.resize(stacks); lgrad_tmp.resize(stacks);
+    const int M = B * H4 * H4;
+    for (int i = 0; i < stacks; ++i) {
+        hg[i].layout(*this, a, B, H4, H4, true);
+        post[i].layout(*this, a, B, H4, H4, true);
+        layout_conv(lin[i], a, M); layout_bn(lin_bn[i], a);
+        lin_out[i] = new_act(a, B, H4, H4, chan, &lin_bn[i], true);
+        layout_conv(outc[i], a, M);
+        heat[i] = a.get<float>((size_t)M * 16);
+        heat64[i] = a.get<bf16>((size_t)M * 64);        // channels 16..63 stay zero (workspace is zero-filled once)
+        dheat64[i] = a.get<bf16>((size_t)M * 64);
+        dheat_in[i] = a.get<bf16>((size_t)M * 64);
+        lgrad_tmp[i] = a.get<bf16>((size_t)M * chan);
+        if (i + 1 < stacks) {
+            layout_conv(forth[i], a, M); layout_conv(inc[i], a, M);
+            forth_tmp[i] = a.get<bf16>((size_t)M * chan);
+        }
+        if (i == 0) xin[0] = res3.x3;
+        if (i + 1 < stacks) xin[i + 1] = new_act(a, B, H4, H4, chan, nullptr, true);
+    }
+    a.take(0);
+    return a.off;
+}
+
+int Net::upload_tables() {
+    std::vector<PaPrepJob> pj; std::vector<PaWgradReduceJob> rj; std::vector<PaBnEvalJob> bj;
+    prep_max = 0; red_max = 0;
+    for (ConvLayer* c : convs) {
+        PaPrepJob p; p.w = params + c->p_w; p.wf = c->wf; p.wb = c->wb; p.Cout = c->Cout; p.Cin = c->Cin;
+        p.taps = c->k == 7 ? 49 : c->taps(); p.pad_cout = c->pcout; p.pad_cin = c->pcin;
+        pj.push_back(p);
+        int pe = c->pcout * (c->k == 7 ? 256 : c->taps() * c->pcin);
+        if (pe > prep_max) prep_max = pe;
+        if (c->k == 7) continue;
+        PaWgradReduceJob r; r.part = c->part; r.dst = grads + c->p_w; r.dbpart = c->dbpart; r.dbdst = grads + c->p_b;
+        r.Cout = c->pcout; r.Cin = c->pcin; r.taps = c->taps(); r.splits = c->splits; r.real_cout = c->Cout; r.real_cin = c->Cin;
+        rj.push_back(r);
+        int re = c->Cout * c->Cin * c->taps() + c->Cout;
+        if (re > red_max) red_max = re;
+    }
+    for (BNLayer* b : bns) {
+        PaBnEvalJob j; j.gamma = params + b->p_gamma; j.beta = params + b->p_beta; j.rmean = buffers + b->b_rmean;
+        j.rvar = buffers + b->b_rvar; j.scale = b->scale; j.shift = b->shift; j.C = b->C;
+        bj.push_back(j);
+    }
+    n_prep = (int)pj.size(); n_red = (int)rj.size(); n_bneval = (int)bj.size();
+    PA_CHECK(hipMemcpyAsync(prep_jobs, pj.data(), pj.size() * sizeof(PaPrepJob), hipMemcpyHostToDevice, st));
+    PA_CHECK(hipMemcpyAsync(red_jobs, rj.data(), rj.size() * sizeof(PaWgradReduceJob), hipMemcpyHostToDevice, st));
+    PA_CHECK(hipMemcpyAsync(bneval_jobs, bj.data(), bj.size() * sizeof(PaBnEvalJob), hipMemcpyHostToDevice, st));
+    PA_CHECK(hipStreamSynchronize(st));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// runtime helpers
+PaOperand Net::op(const Act& a) const {
+    PaOperand o = pa_plain(a.raw);
+    if (a.bn) { o.mode = PA_LD_BNRELU; o.k0 = a.bn->scale; o.k1 = a.bn->shift; }
+    return o;
+}
+
+PaOperand Net::gradop(const Act& a) const {
+    PaOperand o = pa_plain(a.grad);
+    if (a.bn) { o.mode = PA_LD_LIN2; o.q = a.raw; o.k0 = a.bn->kA; o.k1 = a.bn->kB; o.k2 = a.bn->kC; }
+    return o;
+}
+
+PaEpilogue Net::final_ep(const Act& a) const {
+    PaEpilogue e = ep_plain();
+    if (a.bn) {
+        e.mode = PA_OUT_BWD; e.stats = a.bn->bstats; e.xref = a.raw; e.scale = a.bn->scale; e.shift = a.bn->shift;
+        e.mean = a.bn->mean; e.invstd = a.bn->invstd;
+    }
+    return e;
+}
+
+int Net::finish_grad(const Act& a) {
+    if (!a.bn) return 0;
+    BNLayer* b = a.bn;
+    return pa_launch_bn_bwd_finalize(b->bstats, b->scale, b->mean, b->invstd, b->kA, b->kB, b->kC, grads + b->p_gamma,
+                                     grads + b->p_beta, b->C, (float)a.M(), st);
+}
+
+int Net::conv_fwd(ConvLayer& c, const PaOperand& in, int B_, int H, int W, const PaOperand& add1, const PaOperand& add2,
+                  bf16* out, BNLayer* bn_after) {
+    PaConvArgs a; memset(&a, 0, sizeof a);
+    a.in = in; a.w = c.wf; a.bias = params + c.p_b; a.add1 = add1; a.add2 = add2; a.out = out;
+    a.B = B_; a.H = H; a.W = W; a.Cin = c.pcin; a.Cout = c.pcout; a.taps = c.k == 7 ? 1 : c.taps();
+    a.ep = ep_plain();
+    if (bn_after && train_bn) { a.ep.mode = PA_OUT_STATS; a.ep.stats = bn_after->stats; }
+    if (c.k == 7) TRY(pa_launch_stem_conv(a, st));
+    else TRY(pa_launch_conv(a, st));
+    if (bn_after && train_bn)
+        TRY(pa_launch_bn_finalize(bn_after->stats, params + bn_after->p_gamma, params + bn_after->p_beta,
+                                  buffers + bn_after->b_rmean, buffers + bn_after->b_rvar, bn_after->scale, bn_after->shift,
+                                  bn_after->mean, bn_after->invstd, bn_after->C, (float)(B_ * H * W), momentum, eps, 1, st));
+    return 0;
+}
+
+int Net::conv_dgrad(ConvLayer& c, const PaOperand& dy, int B_, int H, int W, const PaOperand& add1, const PaOperand& add2,
+                    const PaEpilogue& ep, bf16* out) {
+    PaConvArgs a; memset(&a, 0, sizeof a);
+    a.in = dy; a.w = c.wb; a.bias = nullptr; a.add1 = add1; a.add2 = add2; a.out = out; a.ep = ep;
+    a.B = B_; a.H = H; a.W = W; a.Cin = c.pcout; a.Cout = c.pcin; a.taps = c.taps();
+    return pa_launch_conv(a, st);
+}
+
+int Net::conv_wgrad(ConvLayer& c, const PaOperand& dy, const PaOperand& x, int B_, int H, int W) {
+    PaWgradArgs a; memset(&a, 0, sizeof a);
+    a.dy = dy; a.x = x; a.part = c.part; a.dbpart = c.dbpart;
+    a.B = B_; a.H = H; a.W = W; a.Cin = c.pcin; a.Cout = c.pcout; a.taps = c.k == 7 ? 1 : c.taps(); a.splits = c.splits;
+    if (c.k == 7) return pa_launch_stem_wgrad(a, st);
+    return pa_launch_wgrad(a, st);
+}
+
+// ------------------------------------------------------------------------------------------------
+// residual block (reference :30-49): x1 = conv1(a), x2 = conv3x3(relu bn1 x1), x3 = conv3(relu bn2 x2) + shortcut
+int Residual::fwd(Net& n, const Act& in) {
+    const int B = in.B, H = in.H, W = in.W;
+    TRY(n.conv_fwd(c1, n.op(in), B, H, W, pa_none(), pa_none(), x1.raw, &b1));
+    TRY(n.conv_fwd(c2, n.op(x1), B, H, W, pa_none(), pa_none(), x2.raw, &b2));
+    if (has_adapter) {
+        TRY(n.conv_fwd(ad, n.op(in), B, H, W, pa_none(), pa_none(), adout, nullptr));
+        TRY(n.conv_fwd(c3, n.op(x2), B, H, W, pa_plain(adout), pa_none(), x3.raw, &b3));
+    } else {
+        TRY(n.conv_fwd(c3, n.op(x2), B, H, W, n.op(in), pa_none(), x3.raw, &b3));
+    }
+    return 0;
+}
+
+// precondition: x3.grad holds the finished masked gradient and finish_grad(x3) has run
+int Residual::bwd(Net& n, const Act& in, const PaOperand& extra, bool in_needs_grad) {
+    const int B = in.B, H = in.H, W = in.W;
+    const PaOperand g3 = n.gradop(x3);
+    TRY(n.conv_wgrad(c3, g3, n.op(x2), B, H, W));
+    TRY(n.conv_dgrad(c3, g3, B, H, W, pa_none(), pa_none(), n.final_ep(x2), x2.grad));
+    TRY(n.finish_grad(x2));
+    const PaOperand g2 = n.gradop(x2);
+    TRY(n.conv_wgrad(c2, g2, n.op(x1), B, H, W));
+    TRY(n.conv_dgrad(c2, g2, B, H, W, pa_none(), pa_none(), n.final_ep(x1), x1.grad));
+    TRY(n.finish_grad(x1));
+    const PaOperand g1 = n.gradop(x1);
+    TRY(n.conv_wgrad(c1, g1, n.op(in), B, H, W));
+    if (has_adapter) TRY(n.conv_wgrad(ad, g3, n.op(in), B, H, W));
+    if (!in_needs_grad) return 0;
+    if (has_adapter) {
+        TRY(n.conv_dgrad(ad, g3, B, H, W, extra, pa_none(), ep_plain(), adgrad));
+        TRY(n.conv_dgrad(c1, g1, B, H, W, pa_plain(adgrad), pa_none(), n.final_ep(in), in.grad));
+    } else {
+        TRY(n.conv_dgrad(c1, g1, B, H, W, g3, extra, n.final_ep(in), in.grad));
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// hourglass (reference :139-157 down path, :192-203 up path)
+int Hourglass::encode(Net& n, const Act& in) {
+    const Act* cur = &in;
+    for (int k = 0; k < 4; ++k) {
+        TRY(skip[k].fwd(n, *cur));
+        TRY(pa_launch_maxpool_fwd(n.op(*cur), pooled[k].raw, cur->B, cur->H, cur->W, cur->C, n.st));
+        TRY(down[k].fwd(n, pooled[k]));
+        cur = &down[k].x3;
+    }
+    return neck.fwd(n, *cur);
+}
+
+int Hourglass::decode(Net& n) {
+    const Act* low = &neck.x3;
+    for (int k = 3; k >= 0; --k) {
+        TRY(up[k].fwd(n, *low));
+        const Act& m = merged[k];
+        TRY(pa_launch_upadd_fwd(n.op(up[k].x3), n.op(skip[k].x3), m.raw, m.B, m.H, m.W, m.C, n.st));
+        low = &merged[k];
+    }
+    return 0;
+}
+
+// precondition: merged[0].grad holds the finished (plain) gradient of the hourglass output.
+// extra0: gradient reaching the hourglass INPUT from consumers outside the hourglass.
+int Hourglass::bwd(Net& n, const Act& in, const PaOperand& extra0) {
+    for (int k = 0; k < 4; ++k) {
+        const Act& m = merged[k];
+        TRY(pa_launch_upadd_bwd(m.grad, n.final_ep(up[k].x3), up[k].x3.grad, n.final_ep(skip[k].x3), skip[k].x3.grad,
+                                m.B, m.H, m.W, m.C, n.st));
+        TRY(n.finish_grad(up[k].x3));
+        TRY(n.finish_grad(skip[k].x3));
+        const Act& upin = (k == 3) ? neck.x3 : merged[k + 1];
+        TRY(up[k].bwd(n, upin, pa_none(), true));
+    }
+    TRY(n.finish_grad(neck.x3));
+    TRY(neck.bwd(n, down[3].x3, pa_none(), true));
+    TRY(n.finish_grad(down[3].x3));
+    for (int k = 3; k >= 0; --k) {
+        TRY(down[k].bwd(n, pooled[k], pa_none(), true));
+        const Act& x = (k == 0) ? in : down[k - 1].x3;
+        TRY(pa_launch_maxpool_bwd(pooled[k].grad, n.op(x), (k == 0) ? extra0 : pa_none(), ep_plain(), poolgrad[k],
+                                  x.B, x.H, x.W, x.C, n.st));
+        TRY(skip[k].bwd(n, x, pa_plain(poolgrad[k]), true));
+        TRY(n.finish_grad(x));
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+int Net::prepare_weights() { return pa_launch_weight_prep(prep_jobs, n_prep, prep_max, st); }
+
+int Net::begin_step() {
+    PA_CHECK(hipMemsetAsync(stats_arena, 0, stats_arena_floats * sizeof(float), st));
+    return 0;
+}
+
+// reference :282-342 (stem :283-289, stacks :292-334) + loss of stack-hg.py:156-159
+int Net::forward_pose(const float* img_nchw, const bf16* img4_in, const double* pts, bool train, float* loss_out_dev) {
+    train_bn = train;
+    TRY(begin_step());
+    if (!train) TRY(pa_launch_bn_eval(bneval_jobs, n_bneval, eps, st));
+    const bf16* image = img4_in ? img4_in : img4;
+    cur_image = image;
+    if (!img4_in) TRY(pa_launch_nchw_to_nhwc4(img_nchw, img4, B, res, res, st));
+    if (pts && pts != pts_dev) PA_CHECK(hipMemcpyAsync(pts_dev, pts, (size_t)B * classes * 2 * sizeof(double), hipMemcpyDeviceToDevice, st));
+    TRY(conv_fwd(stem_conv, pa_plain(image), B, res / 2, res / 2, pa_none(), pa_none(), a0.raw, &stem_bn));
+    TRY(res1.fwd(*this, a0));
+    TRY(pa_launch_maxpool_fwd(op(res1.x3), pool0.raw, B, res / 2, res / 2, 128, st));
+    TRY(res2.fwd(*this, pool0));
+    TRY(res3.fwd(*this, res2.x3));
+    const int Hh = res / 4;
+    for (int i = 0; i < stacks; ++i) {
+        TRY(hg[i].encode(*this, xin[i]));
+        TRY(hg[i].decode(*this));
+        TRY(post[i].fwd(*this, hg[i].out()));
+        TRY(conv_fwd(lin[i], op(post[i].x3), B, Hh, Hh, pa_none(), pa_none(), lin_out[i].raw, &lin_bn[i]));
+        TRY(pa_launch_head_fwd(op(lin_out[i]), outc[i].wf, params + outc[i].p_b, heat[i], heat64[i], pts ? pts_dev : nullptr,
+                               pts ? loss_dev + i : nullptr, B, Hh, Hh, chan, st));
+        if (i + 1 < stacks) {
+            TRY(conv_fwd(forth[i], op(lin_out[i]), B, Hh, Hh, op(xin[i]), pa_none(), forth_tmp[i], nullptr));
+            TRY(conv_fwd(inc[i], pa_plain(heat64[i]), B, Hh, Hh, pa_plain(forth_tmp[i]), pa_none(), xin[i + 1].raw, nullptr));
+        }
+    }
+    if (loss_out_dev) PA_CHECK(hipMemcpyAsync(loss_out_dev, loss_dev, stacks * sizeof(float), hipMemcpyDeviceToDevice, st));
+    return 0;
+}
+
+// hand-written backward of the whole pose net; gradients land in the flat `grads` array
+int Net::backward_pose() {
+    const int Hh = res / 4;
+    const float gscale = 1.f / ((float)B * 16.f * (float)Hh * (float)Hh);
+    for (int i = stacks - 1; i >= 0; --i) {
+        const bool inner = i + 1 < stacks;
+        if (inner) {
+            const PaOperand gx = pa_plain(xin[i + 1].grad);
+            TRY(conv_wgrad(inc[i], gx, pa_plain(heat64[i]), B, Hh, Hh));
+            TRY(conv_dgrad(inc[i], gx, B, Hh, Hh, pa_none(), pa_none(), ep_plain(), dheat_in[i]));
+            TRY(conv_wgrad(forth[i], gx, op(lin_out[i]), B, Hh, Hh));
+        }
+        TRY(pa_launch_heat_grad(heat[i], pts_dev, inner ? dheat_in[i] : nullptr, dheat64[i], gscale, B, Hh, Hh, st));
+        const PaOperand gh = pa_plain(dheat64[i]);
+        TRY(conv_wgrad(outc[i], gh, op(lin_out[i]), B, Hh, Hh));
+        if (inner) {
+            TRY(conv_dgrad(outc[i], gh, B, Hh, Hh, pa_none(), pa_none(), ep_plain(), lgrad_tmp[i]));
+            TRY(conv_dgrad(forth[i], pa_plain(xin[i + 1].grad), B, Hh, Hh, pa_plain(lgrad_tmp[i]), pa_none(),
+                           final_ep(lin_out[i]), lin_out[i].grad));
+        } else {
+            TRY(conv_dgrad(outc[i], gh, B, Hh, Hh, pa_none(), pa_none(), final_ep(lin_out[i]), lin_out[i].grad));
+        }
+        TRY(finish_grad(lin_out[i]));
+        const PaOperand gl = gradop(lin_out[i]);
+        TRY(conv_wgrad(lin[i], gl, op(post[i].x3), B, Hh, Hh));
+        TRY(conv_dgrad(lin[i], gl, B, Hh, Hh, pa_none(), pa_none(), final_ep(post[i].x3), post[i].x3.grad));
+        TRY(finish_grad(post[i].x3));
+        TRY(post[i].bwd(*this, hg[i].out(), pa_none(), true));
+        TRY(hg[i].bwd(*this, xin[i], inner ? pa_plain(xin[i + 1].grad) : pa_none()));
+    }
+    // stem: residual3 <- residual2 <- maxpool <- residual1 <- 7x7 conv
+    TRY(res3.bwd(*this, res2.x3, pa_none(), true));
+    TRY(finish_grad(res2.x3));
+    TRY(res2.bwd(*this, pool0, pa_none(), true));
+    TRY(pa_launch_maxpool_bwd(pool0.grad, op(res1.x3), pa_none(), final_ep(res1.x3), res1.x3.grad, B, res / 2, res / 2, 128, st));
+    TRY(finish_grad(res1.x3));
+    TRY(res1.bwd(*this, a0, pa_none(), true));
+    TRY(finish_grad(a0));
+    TRY(conv_wgrad(stem_conv, gradop(a0), pa_plain(cur_image), B, res / 2, res / 2));
+    return reduce_grads();
+}
+
+int Net::reduce_grads() {
+    TRY(pa_launch_wgrad_reduce(red_jobs, n_red, red_max, st));
+    if (!is_agent) {
+        TRY(pa_launch_stem_wgrad_reduce(stem_conv.part, stem_conv.splits, grads + stem_conv.p_w, st));
+        PA_CHECK(hipMemsetAsync(grads + stem_conv.p_b, 0, 64 * sizeof(float), st));
+    }
+    return 0;
+}

@@ -1,0 +1,277 @@
+"""models/asn_stacked_hg.py of the reference behind the HIP engine.
+
+`create_hg` / `create_asn` keep the reference's signatures (models/asn_stacked_hg.py:344-347, :441-444)
+and return objects with the nn.Module surface the reference's scripts use -- __call__/forward,
+state_dict / load_state_dict (same names, NCHW shapes and order as the reference's modules),
+parameters(), train(), eval(), cuda() -- but the arithmetic runs in libposeadv_hip.so on flat fp32
+parameter / gradient buffers; torch only owns the memory.  There is no autograd graph: use
+`loss_and_backward()` (the fused forward + loss + hand-written backward) instead of loss.backward().
+"""
+import ctypes as C
+import math
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from .._lib import lib, check, ptr, stream, require_gpu, PoseAdvError
+
+
+class _HipModule(object):
+    """Flat-buffer module: parameters / gradients / running statistics live in three flat fp32 GPU
+    tensors laid out by the C library (pa_net_tensor_info), state_dict entries are views into them."""
+
+    def __init__(self):
+        self.training = True
+        self._nets = {}          # batch size -> (handle, workspace tensor)
+        self._table = None
+        self.flat_params = self.flat_grads = self.flat_buffers = None
+        self._nbt = 0            # num_batches_tracked (identical for every BatchNorm of the module)
+        self._weights_dirty = True
+
+    # -- to be provided by subclasses
+    def _create(self, B):
+        raise NotImplementedError
+
+    # -- handle management
+    def _read_table(self, h):
+        L = lib()
+        table = []
+        name = C.create_string_buffer(256)
+        shape = (C.c_int * 4)(); nd = C.c_int(); off = C.c_size_t(); numel = C.c_size_t(); kind = C.c_int()
+        for i in range(L.pa_net_num_tensors(h)):
+            check(L.pa_net_tensor_info(h, i, name, 256, shape, C.byref(nd), C.byref(off), C.byref(numel), C.byref(kind)))
+            table.append((name.value.decode(), tuple(shape[k] for k in range(nd.value)), off.value, numel.value, kind.value))
+        return table
+
+    def _net(self, B):
+        require_gpu()
+        if B not in self._nets:
+            L = lib()
+            h = self._create(B)
+            if not h:
+                raise PoseAdvError('network creation failed: %s' % L.pa_last_error().decode())
+            dev = torch.device('cuda', torch.cuda.current_device())
+            if self._table is None:
+                self._table = self._read_table(h)
+                self.flat_params = torch.zeros(L.pa_net_param_floats(h), dtype=torch.float32, device=dev)
+                self.flat_grads = torch.zeros_like(self.flat_params)
+                self.flat_buffers = torch.zeros(max(1, L.pa_net_buffer_floats(h)), dtype=torch.float32, device=dev)
+                for name, shape, off, numel, kind in self._table:
+                    if kind == 1 and name.endswith('running_var'):
+                        self.flat_buffers[off:off + numel] = 1.0
+                self.reset_parameters()
+            ws = torch.zeros(L.pa_net_workspace_bytes(h), dtype=torch.uint8, device=dev)
+            check(L.pa_net_bind(h, ptr(self.flat_params), ptr(self.flat_grads), ptr(self.flat_buffers), ptr(ws), stream()),
+                  'pa_net_bind')
+            self._nets[B] = (h, ws)
+            self._weights_dirty = False
+        h, _ = self._nets[B]
+        if self._weights_dirty:
+            for hh, _ in self._nets.values():
+                check(lib().pa_net_prepare_weights(hh), 'pa_net_prepare_weights')
+            self._weights_dirty = False
+        return h
+
+    def _ensure_table(self):
+        if self._table is None:
+            self._net(self.default_batch)
+
+    def __del__(self):
+        try:
+            for h, _ in self._nets.values():
+                lib().pa_net_destroy(h)
+        except Exception:
+            pass
+
+    # -- nn.Module surface
+    def weights_changed(self):
+        """Call after writing into parameter views (optimizer step, load_state_dict)."""
+        self._weights_dirty = True
+
+    def named_parameters(self):
+        self._ensure_table()
+        for name, shape, off, numel, kind in self._table:
+            if kind == 0:
+                yield name, self.flat_params[off:off + numel].view(shape)
+
+    def parameters(self):
+        return [p for _, p in self.named_parameters()]
+
+    def named_grads(self):
+        self._ensure_table()
+        for name, shape, off, numel, kind in self._table:
+            if kind == 0:
+                yield name, self.flat_grads[off:off + numel].view(shape)
+
+    def state_dict(self, prefix=''):
+        self._ensure_table()
+        sd = OrderedDict()
+        for name, shape, off, numel, kind in self._table:
+            if kind == 0:
+                sd[prefix + name] = self.flat_params[off:off + numel].view(shape)
+            elif kind == 1:
+                sd[prefix + name] = self.flat_buffers[off:off + numel].view(shape)
+            else:
+                sd[prefix + name] = torch.tensor(self._nbt, dtype=torch.long)
+        return sd
+
+    def load_state_dict(self, state_dict, strict=True):
+        own = self.state_dict()
+        missing = [k for k in own if k not in state_dict and 'module.' + k not in state_dict]
+        unexpected = []
+        for k, v in state_dict.items():
+            kk = k[7:] if k.startswith('module.') else k        # reference checkpoints carry DataParallel's prefix
+            if kk not in own:
+                unexpected.append(k)
+                continue
+            if kk.endswith('num_batches_tracked'):
+                self._nbt = int(v)
+                continue
+            own[kk].copy_(torch.as_tensor(v).to(own[kk].device, torch.float32).view_as(own[kk]))
+        if strict and (missing or unexpected):
+            raise KeyError('load_state_dict: missing %s unexpected %s' % (missing[:5], unexpected[:5]))
+        self.weights_changed()
+        return missing, unexpected
+
+    def train(self, mode=True):
+        self.training = bool(mode)
+        return self
+
+    def eval(self):
+        return self.train(False)
+
+    def cuda(self, *a, **k):
+        require_gpu()
+        return self
+
+    def zero_grad(self):
+        if self.flat_grads is not None:
+            self.flat_grads.zero_()
+
+    def num_params(self):
+        return sum(n for _, _, _, n, k in (self._table or []) if k == 0)
+
+    def reset_parameters(self, seed=None):
+        """The reference's initialisation (models/asn_stacked_hg.py:258-270): conv weight and bias
+        U(+-1/sqrt(k*k*Cin)), BatchNorm gamma U(0,1), beta 0; Linear layers keep torch's default."""
+        g = torch.Generator().manual_seed(int(seed) if seed is not None else torch.initial_seed() % (2 ** 31))
+        bound = None
+        for name, shape, off, numel, kind in self._table:
+            if kind != 0:
+                continue
+            if len(shape) == 4:
+                bound = 1.0 / math.sqrt(shape[1] * shape[2] * shape[3])
+                v = (torch.rand(shape, generator=g) * 2 - 1) * bound
+            elif len(shape) == 2:                               # nn.Linear default: U(+-1/sqrt(fan_in))
+                bound = 1.0 / math.sqrt(shape[1])
+                v = (torch.rand(shape, generator=g) * 2 - 1) * bound
+            elif _is_bn_name(name):
+                v = torch.rand(shape, generator=g) if name.endswith('weight') else torch.zeros(shape)
+            else:                                               # bias of the conv / linear just declared
+                v = (torch.rand(shape, generator=g) * 2 - 1) * bound
+            self.flat_params[off:off + numel] = v.reshape(-1).to(self.flat_params.device)
+        self.weights_changed()
+
+
+def _is_bn_name(name):
+    leaf = name.rsplit('.', 2)
+    mod = leaf[-2] if len(leaf) >= 2 else ''
+    if mod.startswith('bn'):
+        return True
+    return mod == '1' and '.linear.' in '.' + name        # linear.<i>.1 is the BatchNorm of the Sequential
+
+
+class HourglassNet(_HipModule):
+    """_Hourglass_Wrapper of the reference (models/asn_stacked_hg.py:215-342)."""
+
+    def __init__(self, num_modules, num_stacks, chan=256, num_classes=16, res=256, default_batch=24):
+        super().__init__()
+        if num_modules != 1:
+            raise ValueError('the reference scripts always use num_modules=1; that is what the engine builds')
+        self.num_stacks, self.chan, self.num_classes, self.res = num_stacks, chan, num_classes, res
+        self.default_batch = default_batch
+        self._last_B = None
+
+    def _create(self, B):
+        return lib().pa_hg_create(self.num_stacks, self.num_classes, self.chan, B, self.res)
+
+    def forward(self, x=None, asn=None, is_half_hg=False, is_aug=False, is_dropout=False, img4=None, pts=None):
+        """models/asn_stacked_hg.py:282-342.  x: [B][3][res][res] fp32 GPU tensor (or img4: the bf16
+        NHWC4 output of the on-device warp).  Returns the list of per-stack heat maps [B][16][res/4][res/4]
+        (fp32, NCHW) like the reference.  With `asn` and is_half_hg the agent's two logit tensors."""
+        if is_dropout:
+            raise NotImplementedError('the occlusion (dropout) agent is outside the hot path (SURVEY.md 2.1 #3)')
+        if asn is not None:
+            assert is_aug
+            return asn._forward_from_pose(self, x, img4, is_half_hg)
+        B = x.shape[0] if x is not None else img4.shape[0]
+        h = self._net(B)
+        self._last_B = B
+        p = pts.to(torch.float64).contiguous() if pts is not None else None
+        losses = torch.zeros(self.num_stacks, dtype=torch.float32, device=self.flat_params.device) if pts is not None else None
+        check(lib().pa_hg_forward(h, ptr(x.contiguous().float()) if x is not None else None, ptr(img4), ptr(p),
+                                  1 if self.training else 0, ptr(losses)), 'pa_hg_forward')
+        if self.training:
+            self._nbt += 1
+        self._last_losses = losses
+        return self.heatmaps(B)
+
+    __call__ = forward
+
+    def heatmaps(self, B=None):
+        B = B or self._last_B
+        h = self._net(B)
+        outs = []
+        for i in range(self.num_stacks):
+            o = torch.empty((B, 16, self.res // 4, self.res // 4), dtype=torch.float32, device=self.flat_params.device)
+            check(lib().pa_hg_heatmap_nchw(h, i, ptr(o)), 'pa_hg_heatmap_nchw')
+            outs.append(o)
+        return outs
+
+    def loss_and_backward(self, x=None, pts=None, img4=None, want_outputs=False):
+        """One pass of stack-hg.py:153-164 without the optimizer: forward in the current mode, loss
+        sum_stacks mean((out - gaussian(pts))^2) with the target generated on the fly from `pts`
+        ([B][16][2] heat-map coordinates), backward into flat_grads.  Returns (loss 0-d GPU tensor, outputs)."""
+        B = x.shape[0] if x is not None else img4.shape[0]
+        h = self._net(B)
+        self._last_B = B
+        p = pts.to(torch.float64).contiguous()
+        losses = torch.zeros(self.num_stacks, dtype=torch.float32, device=self.flat_params.device)
+        check(lib().pa_hg_forward(h, ptr(x.contiguous().float()) if x is not None else None, ptr(img4), ptr(p),
+                                  1 if self.training else 0, ptr(losses)), 'pa_hg_forward')
+        if self.training:
+            self._nbt += 1
+        check(lib().pa_hg_backward(h), 'pa_hg_backward')
+        return losses.sum(), (self.heatmaps(B) if want_outputs else None)
+
+    def accuracy(self, idxs, stack=-1):
+        """Evaluation.accuracy (pylib/Evaluation.py:54-75) of the last forward's heat maps against the
+        Gaussian target of the joints it was given, entirely on the device."""
+        B = self._last_B
+        h = self._net(B)
+        stack = stack % self.num_stacks
+        Hh = self.res // 4
+        dev = self.flat_params.device
+        scratch = torch.empty(B * 16 * Hh * Hh + 4 * B * 16 + B + 16, dtype=torch.float32, device=dev)
+        ix = torch.as_tensor([int(i) for i in idxs], dtype=torch.int32, device=dev)
+        acc = torch.zeros(len(idxs) + 1, dtype=torch.float32, device=dev)
+        check(lib().pa_hg_accuracy(h, stack, ptr(ix), len(idxs), ptr(acc), ptr(scratch)), 'pa_hg_accuracy')
+        return acc
+
+
+def create_hg(num_stacks, num_modules, num_classes, chan, res=256, default_batch=24):
+    """models/asn_stacked_hg.py:344-347."""
+    return HourglassNet(num_modules=num_modules, num_stacks=num_stacks, chan=chan, num_classes=num_classes,
+                        res=res, default_batch=default_batch)
+
+
+def create_asn(chan_in, chan_out, scale_num=None, rotation_num=None, is_aug=False, is_dropout=False, res=256,
+               default_batch=24):
+    """models/asn_stacked_hg.py:441-444 (scale/rotation agent only)."""
+    from .asn import ASN
+    if not is_aug or is_dropout:
+        raise NotImplementedError('only the scale/rotation (is_aug) agent is on the hot path')
+    if chan_in != chan_out:
+        raise ValueError('the reference always builds the agent with chan_in == chan_out')
+    return ASN(chan_out, scale_num, rotation_num, res=res, default_batch=default_batch)

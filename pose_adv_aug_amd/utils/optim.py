@@ -1,0 +1,60 @@
+"""RMSprop on the engine's flat parameter buffer (reference: torch.optim.RMSprop(net.parameters(),
+lr, alpha=0.99, eps=1e-8, momentum=0, weight_decay=0), stack-hg.py:51-52) with the data-parallel
+gradient exchange folded in: ONE all-reduce of the flat gradient over RCCL per step (replaces
+nn.DataParallel's broadcast/gather/reduce_add, stack-hg.py:49)."""
+import torch
+import torch.distributed as dist
+
+from .._lib import lib, check, ptr, stream
+
+
+class RMSprop(object):
+    def __init__(self, net, lr=2.5e-4, alpha=0.99, eps=1e-8, momentum=0, weight_decay=0):
+        if momentum != 0 or weight_decay != 0:
+            raise ValueError('the reference uses momentum=0, weight_decay=0')
+        self.net = net
+        net._ensure_table()
+        self.param_groups = [{'lr': lr, 'alpha': alpha, 'eps': eps, 'momentum': 0, 'weight_decay': 0, 'centered': False}]
+        self.square_avg = torch.zeros_like(net.flat_params)
+        self.steps = 0
+
+    def zero_grad(self):
+        self.net.zero_grad()
+
+    def allreduce_grads(self):
+        """Sum the flat gradient over all ranks (RCCL when the process group backend is nccl)."""
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(self.net.flat_grads, op=dist.ReduceOp.SUM)
+            return 1.0 / dist.get_world_size()
+        return 1.0
+
+    def step(self):
+        g = self.param_groups[0]
+        gscale = self.allreduce_grads()
+        n = self.net.flat_params.numel()
+        check(lib().pa_rmsprop_step(ptr(self.net.flat_params), ptr(self.net.flat_grads), ptr(self.square_avg), n,
+                                    float(g['lr']), float(g['alpha']), float(g['eps']), float(gscale), stream()),
+              'pa_rmsprop_step')
+        self.steps += 1
+        self.net.weights_changed()
+        self.net._net(self.net._last_B or self.net.default_batch)      # refresh the bf16 weight copies now
+
+    # torch.optim-compatible (de)serialisation: per-parameter state keyed by index, in parameters() order
+    def state_dict(self):
+        state = {}
+        for i, (name, shape, off, numel, kind) in enumerate(t for t in self.net._table if t[4] == 0):
+            state[i] = {'step': self.steps, 'square_avg': self.square_avg[off:off + numel].view(shape).clone()}
+        pg = dict(self.param_groups[0])
+        pg['params'] = list(range(len(state)))
+        return {'state': state, 'param_groups': [pg]}
+
+    def load_state_dict(self, sd):
+        params = [t for t in self.net._table if t[4] == 0]
+        for i, (name, shape, off, numel, kind) in enumerate(params):
+            st = sd['state'].get(i)
+            if st is not None:
+                self.square_avg[off:off + numel] = torch.as_tensor(st['square_avg']).reshape(-1).to(self.square_avg.device)
+                self.steps = int(st.get('step', self.steps))
+        for k, v in sd['param_groups'][0].items():
+            if k != 'params':
+                self.param_groups[0][k] = v
