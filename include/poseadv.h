@@ -54,28 +54,28 @@ int pa_final_preds(const float* maps, const float* center, const float* scale, c
 int pa_pck(const float* pred, const float* gt, const float* norm, float boundary, const int32_t* idxs, int nidx,
            float thr, const float* vis, int B, int J, float* acc, float* person, float* dists, void* stream);
 
-/* HumanAug.GetTransform (pylib/HumanAug.py:10-35) for a batch: params [B][8] fp32 =
+/* HumanAug.GetTransform (pylib/HumanAug.py:10-35) for a batch: params [B][8] float64 =
  * {cx, cy, scale, rot_deg, flip, gain_r, gain_g, gain_b}; t_out [B][6] float64 = forward transform
  * at res_out (first two rows), tinv_in [B][6] = INVERSE transform at res_in (what the warp samples with). */
-int pa_affine_params(const float* params, int B, int res_in, int res_out, double* t_out, double* tinv_in, void* stream);
+int pa_affine_params(const double* params, int B, int res_in, int res_out, double* t_out, double* tinv_in, void* stream);
 
 /* HumanAug.TransformPts (pylib/HumanAug.py:45-54) + shufflelr (:236-257) + the invalid-joint rule of
  * data/mpii_for_mpii.py:142-146.  pts [B][J][2] fp32 image pixels -> out [B][J][2] float64 heat-map
  * coords (0 for invalid joints); pts_img (optional) = mirrored/swapped image-space joints. */
-int pa_transform_pts(const float* pts, const float* params, const double* t, int B, int J, float width,
+int pa_transform_pts(const float* pts, const double* params, const double* t, int B, int J, float width,
                      double* out, float* pts_img, void* stream);
 
 /* HumanAug.crop (pylib/HumanAug.py:117-176) + flip / colour gain of data/mpii_for_mpii.py:126-135 as
  * one inverse-affine bilinear gather.  src: uint8 [B][Hs][Ws][3]; out4: bf16 [B][res][res][4]
  * (network input layout, 4th channel 0) and/or outf: fp32 [B][3][res][res]; either may be NULL. */
-int pa_affine_warp_bilinear(const uint8_t* src, int Hs, int Ws, const double* tinv, const float* params,
+int pa_affine_warp_bilinear(const uint8_t* src, int Hs, int Ws, const double* tinv, const double* params,
                             int B, int res, void* out4, float* outf, void* stream);
 
 /* augmentation laws: mode 0 = data/mpii_for_mpii.py:119-135 (regular), 1 = agent bins
  * (data/joint_train_s_r_agent.py:15-16,33-36,134-139), 2 = agent scale only, 3 = agent rotation only.
  * meta [B][4] = {objpos_x, objpos_y, scale, frame_width}; params [B][8] as above. */
 int pa_sample_aug(const float* meta, const int32_t* scale_idx, const int32_t* rot_idx, int mode,
-                  uint64_t seed, uint64_t step, int B, float* params, void* stream);
+                  uint64_t seed, uint64_t step, int B, double* params, void* stream);
 
 /* softmax + np.random.choice(K, p) of joint-train-pose-s-r-agent.py:252-271.  logits [B][K];
  * probs [B][K] and idx int32 [B] may be NULL. */
@@ -95,6 +95,16 @@ int pa_rmsprop_step(float* param, const float* grad, float* square_avg, size_t n
 size_t pa_residual_workspace_bytes(int B, int H, int W, int C);
 int pa_residual_fwd_bwd(const float* x, const float* dy, const float* params, float* y, float* dx, float* grads,
                         float* buffers, int B, int C, int H, int W, void* ws, void* stream);
+
+/* One plain convolution (k = 1 or 3, stride 1, 'same'; nn.Conv2d of models/asn_stacked_hg.py:17-24)
+ * through the implicit-GEMM kernels, NCHW fp32 in/out, PyTorch-layout fp32 weights.
+ *   mode 0: out  = conv(a_in = x, w) + bias
+ *   mode 1: out  = data gradient for a_in = dy
+ *   mode 2: out  = weight gradient, out2 = bias gradient, for a_in = dy, b_in = x
+ * ws: pa_conv2d_workspace_bytes() bytes. */
+size_t pa_conv2d_workspace_bytes(int B, int Cin, int Cout, int H, int W, int k);
+int pa_conv2d(int mode, const float* a_in, const float* b_in, const float* w, const float* bias, float* out, float* out2,
+              int B, int Cin, int Cout, int H, int W, int k, void* ws, void* stream);
 
 /* NCHW fp32 <-> NHWC bf16 */
 int pa_nchw_to_nhwc(const float* src, void* dst_bf16, int B, int C, int H, int W, void* stream);
@@ -143,6 +153,12 @@ int pa_hg_backward(pa_net* net);
 /* Evaluation.accuracy (pylib/Evaluation.py:54-75) of stack i's heat maps against the Gaussian target
  * of the joints given to the last forward: acc [nidx+1]. */
 int pa_hg_accuracy(pa_net* net, int stack, const int32_t* idxs, int nidx, float* acc, float* scratch);
+
+/* Test hook: copy an internal activation (pending BatchNorm+ReLU applied) or, with grad != 0, its raw
+ * gradient buffer out as NCHW fp32; shape4 receives {B, C, H, W} (out may be NULL to query the shape).
+ * Names: "stem", "res1".."res3", "pool0", "hg<i>.skip<k>|pool<k>|down<k>|up<k>|merge<k>|neck" (k=1..4),
+ * "post<i>", "lin<i>", "xin<i>", optional suffix ".x1"/".x2" for a block's inner tensors. */
+int pa_hg_debug_tensor(pa_net* net, const char* which, int grad, float* out, int* shape4);
 
 #ifdef __cplusplus
 }

@@ -47,6 +47,8 @@ _PROTOS = {
     'pa_rmsprop_step': (_i, [_vp, _vp, _vp, _sz, _f, _f, _f, _f, _vp]),
     'pa_residual_workspace_bytes': (_sz, [_i, _i, _i, _i]),
     'pa_residual_fwd_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    'pa_conv2d_workspace_bytes': (_sz, [_i, _i, _i, _i, _i, _i]),
+    'pa_conv2d': (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     'pa_nchw_to_nhwc': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     'pa_nhwc_to_nchw': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     'pa_hg_create': (_vp, [_i, _i, _i, _i, _i]),
@@ -65,6 +67,7 @@ _PROTOS = {
     'pa_hg_heatmap_nchw': (_i, [_vp, _i, _vp]),
     'pa_hg_backward': (_i, [_vp]),
     'pa_hg_accuracy': (_i, [_vp, _i, _vp, _i, _vp, _vp]),
+    'pa_hg_debug_tensor': (_i, [_vp, C.c_char_p, _i, _vp, C.POINTER(_i)]),
 }
 
 EXPORTS = sorted(_PROTOS)

@@ -4,6 +4,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <new>
+#include <string>
 
 static thread_local char g_err[1024] = "";
 void pa_set_error(const char* what, hipError_t e, const char* file, int line) {
@@ -39,19 +40,19 @@ int pa_pck(const float* pred, const float* gt, const float* norm, float boundary
            const float* vis, int B, int J, float* acc, float* person, float* dists, void* s) {
     TRY(pa_launch_pck(pred, gt, norm, boundary, idxs, nidx, thr, vis, B, J, acc, person, dists, ST(s))); return 0;
 }
-int pa_affine_params(const float* params, int B, int res_in, int res_out, double* t_out, double* tinv_in, void* s) {
+int pa_affine_params(const double* params, int B, int res_in, int res_out, double* t_out, double* tinv_in, void* s) {
     TRY(pa_launch_affine_params(params, B, res_in, res_out, t_out, tinv_in, ST(s))); return 0;
 }
-int pa_transform_pts(const float* pts, const float* params, const double* t, int B, int J, float width, double* out,
+int pa_transform_pts(const float* pts, const double* params, const double* t, int B, int J, float width, double* out,
                      float* pts_img, void* s) {
     TRY(pa_launch_transform_pts(pts, params, t, B, J, width, out, pts_img, ST(s))); return 0;
 }
-int pa_affine_warp_bilinear(const uint8_t* src, int Hs, int Ws, const double* tinv, const float* params, int B, int res,
+int pa_affine_warp_bilinear(const uint8_t* src, int Hs, int Ws, const double* tinv, const double* params, int B, int res,
                             void* out4, float* outf, void* s) {
     TRY(pa_launch_warp(src, Hs, Ws, tinv, params, B, res, reinterpret_cast<bf16*>(out4), outf, ST(s))); return 0;
 }
 int pa_sample_aug(const float* meta, const int32_t* scale_idx, const int32_t* rot_idx, int mode, uint64_t seed, uint64_t step,
-                  int B, float* params, void* s) {
+                  int B, double* params, void* s) {
     TRY(pa_launch_sample_aug(meta, scale_idx, rot_idx, mode, seed, step, B, params, ST(s))); return 0;
 }
 int pa_sample_categorical(const float* logits, int B, int K, uint64_t seed, uint64_t step, unsigned slot, float* probs,
@@ -119,6 +120,68 @@ int pa_residual_fwd_bwd(const float* x, const float* dy, const float* params, fl
         TRY(pa_launch_nhwc_bf16_to_nchw_f32(pa_plain(op.in.grad), dx, B, C, H, W, n.st));
     }
     PA_CHECK(hipStreamSynchronize(n.st));
+    return 0;
+}
+
+// ---------------------------------------------------------------------------- single convolution ops
+// Plain conv2d (k = 1 or 3, stride 1, 'same') through the implicit-GEMM kernels: NCHW fp32 in/out,
+// PyTorch-layout fp32 weights; bf16 operands, fp32 accumulation.  mode: 0 forward (y = conv(x,w)+b),
+// 1 data gradient (dx = conv^T(dy, w)), 2 weight gradient (dw, db from dy and x).
+struct ConvOp {
+    Net n; ConvLayer c; bf16 *xin = nullptr, *yout = nullptr;
+    size_t build(int B, int H, int W, char* base) {
+        Arena a; a.base = base;
+        n.prep_jobs = a.get<PaPrepJob>(1); n.red_jobs = a.get<PaWgradReduceJob>(1); n.bneval_jobs = a.get<PaBnEvalJob>(1);
+        n.layout_conv(c, a, B * H * W);
+        xin = a.get<bf16>((size_t)B * H * W * c.pcin);
+        yout = a.get<bf16>((size_t)B * H * W * c.pcout);
+        a.take(0);
+        return a.off;
+    }
+};
+
+size_t pa_conv2d_workspace_bytes(int B, int Cin, int Cout, int H, int W, int k) {
+    ConvOp op; op.n.is_agent = true; op.n.declare_conv(op.c, "c", Cin, Cout, k, false);
+    return op.build(B, H, W, nullptr);
+}
+
+int pa_conv2d(int mode, const float* a_in, const float* b_in, const float* w, const float* bias, float* out, float* out2,
+              int B, int Cin, int Cout, int H, int W, int k, void* ws, void* s) {
+    g_err[0] = 0;
+    if (Cin % 64 || Cout % 64 || (k != 1 && k != 3)) { pa_set_error_msg("pa_conv2d: channels % 64 == 0, k in {1,3}"); return 1; }
+    ConvOp op; Net& n = op.n; n.is_agent = true; n.B = B; n.st = ST(s);
+    n.declare_conv(op.c, "c", Cin, Cout, k, false);
+    op.build(B, H, W, reinterpret_cast<char*>(ws));
+    // parameter block: [weight | bias] as declared
+    float* pbuf = nullptr; float* gbuf = nullptr;
+    PA_CHECK(hipMallocAsync((void**)&pbuf, n.n_params * sizeof(float) * 2 + 64, n.st));
+    gbuf = pbuf + ((n.n_params + 3) & ~(size_t)3);
+    PA_CHECK(hipMemsetAsync(pbuf, 0, n.n_params * sizeof(float) * 2 + 64, n.st));
+    PA_CHECK(hipMemcpyAsync(pbuf + op.c.p_w, w, (size_t)Cout * Cin * k * k * sizeof(float), hipMemcpyDeviceToDevice, n.st));
+    if (bias) PA_CHECK(hipMemcpyAsync(pbuf + op.c.p_b, bias, Cout * sizeof(float), hipMemcpyDeviceToDevice, n.st));
+    n.params = pbuf; n.grads = gbuf; n.buffers = pbuf;
+    TRY(n.upload_tables());
+    TRY(n.prepare_weights());
+    n.train_bn = false;
+    if (mode == 0) {
+        TRY(pa_launch_nchw_f32_to_nhwc_bf16(a_in, op.xin, B, Cin, H, W, n.st));
+        TRY(n.conv_fwd(op.c, pa_plain(op.xin), B, H, W, pa_none(), pa_none(), op.yout, nullptr));
+        TRY(pa_launch_nhwc_bf16_to_nchw_f32(pa_plain(op.yout), out, B, Cout, H, W, n.st));
+    } else if (mode == 1) {
+        PaEpilogue ep; memset(&ep, 0, sizeof ep); ep.mode = PA_OUT_PLAIN;
+        TRY(pa_launch_nchw_f32_to_nhwc_bf16(a_in, op.yout, B, Cout, H, W, n.st));
+        TRY(n.conv_dgrad(op.c, pa_plain(op.yout), B, H, W, pa_none(), pa_none(), ep, op.xin));
+        TRY(pa_launch_nhwc_bf16_to_nchw_f32(pa_plain(op.xin), out, B, Cin, H, W, n.st));
+    } else {
+        TRY(pa_launch_nchw_f32_to_nhwc_bf16(a_in, op.yout, B, Cout, H, W, n.st));
+        TRY(pa_launch_nchw_f32_to_nhwc_bf16(b_in, op.xin, B, Cin, H, W, n.st));
+        TRY(n.conv_wgrad(op.c, pa_plain(op.yout), pa_plain(op.xin), B, H, W));
+        TRY(n.reduce_grads());
+        PA_CHECK(hipMemcpyAsync(out, gbuf + op.c.p_w, (size_t)Cout * Cin * k * k * sizeof(float), hipMemcpyDeviceToDevice, n.st));
+        if (out2) PA_CHECK(hipMemcpyAsync(out2, gbuf + op.c.p_b, Cout * sizeof(float), hipMemcpyDeviceToDevice, n.st));
+    }
+    PA_CHECK(hipStreamSynchronize(n.st));
+    PA_CHECK(hipFree(pbuf));
     return 0;
 }
 
@@ -203,6 +266,52 @@ int pa_hg_accuracy(pa_net* net, int stack, const int32_t* idxs, int nidx, float*
     TRY(pa_launch_argmax(tgt, (long)J * H * H, (long)H * H, 1, B, J, H, H, gp, nullptr, n.st));
     TRY(pa_launch_fill(norm, (float)H / 10.f, B, n.st));
     TRY(pa_launch_pck(pp, gp, norm, 1.f, idxs, nidx, 0.5f, nullptr, B, J, acc, nullptr, nullptr, n.st));
+    return 0;
+}
+
+
+// debug / test hook: copy an internal activation (BatchNorm+ReLU applied) or its gradient buffer out as
+// NCHW fp32.  which: "stem", "res1", "pool0", "res2", "res3", "hg<i>.skip<k>", "hg<i>.pool<k>",
+// "hg<i>.down<k>", "hg<i>.neck", "hg<i>.up<k>", "hg<i>.merge<k>", "post<i>", "lin<i>", "xin<i>" (k = 1..4)
+// and "<name>.x1"/".x2" for the inner tensors of a residual block.  grad != 0 -> the raw gradient buffer.
+int pa_hg_debug_tensor(pa_net* net, const char* which, int grad, float* out, int* shape4) {
+    Net& n = net->n;
+    std::string w(which);
+    const Act* a = nullptr;
+    auto pick_res = [&](Residual& r, const std::string& rest) -> const Act* {
+        if (rest == ".x1") return &r.x1;
+        if (rest == ".x2") return &r.x2;
+        return &r.x3;
+    };
+    auto starts = [&](const char* p) { return w.rfind(p, 0) == 0; };
+    if (starts("stem")) a = &n.a0;
+    else if (starts("res1")) a = pick_res(n.res1, w.substr(4));
+    else if (starts("pool0")) a = &n.pool0;
+    else if (starts("res2")) a = pick_res(n.res2, w.substr(4));
+    else if (starts("res3")) a = pick_res(n.res3, w.substr(4));
+    else if (starts("post")) { int i = w[4] - '0'; a = pick_res(n.post[i], w.substr(5)); }
+    else if (starts("lin")) { int i = w[3] - '0'; a = &n.lin_out[i]; }
+    else if (starts("xin")) { int i = w[3] - '0'; a = &n.xin[i]; }
+    else if (starts("hg")) {
+        int i = w[2] - '0';
+        std::string r = w.substr(4);
+        Hourglass& h = n.hg[i];
+        if (r.rfind("neck", 0) == 0) a = pick_res(h.neck, r.substr(4));
+        else {
+            int k = r[r.find_first_of("1234")] - '1';
+            std::string rest = r.substr(r.find_first_of("1234") + 1);
+            if (r.rfind("skip", 0) == 0) a = pick_res(h.skip[k], rest);
+            else if (r.rfind("down", 0) == 0) a = pick_res(h.down[k], rest);
+            else if (r.rfind("up", 0) == 0) a = pick_res(h.up[k], rest);
+            else if (r.rfind("pool", 0) == 0) a = &h.pooled[k];
+            else if (r.rfind("merge", 0) == 0) a = &h.merged[k];
+        }
+    }
+    if (!a) { pa_set_error_msg("pa_hg_debug_tensor: unknown tensor name"); return 1; }
+    shape4[0] = a->B; shape4[1] = a->C; shape4[2] = a->H; shape4[3] = a->W;
+    if (!out) return 0;
+    PaOperand src = grad ? pa_plain(a->grad) : n.op(*a);
+    TRY(pa_launch_nhwc_bf16_to_nchw_f32(src, out, a->B, a->C, a->H, a->W, n.st));
     return 0;
 }
 

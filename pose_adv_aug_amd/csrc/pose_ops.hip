@@ -10,24 +10,32 @@
 // top-left corner is int(pt-3) (C-style truncation toward zero), clipped at the borders; joints with
 // x<=0 || y<=0 || x>W || y>H give an all-zero map.  Evaluated per pixel, never materialised on the
 // training path.
-struct GaussPatch { int ulx, uly, valid; };
+// float32(exp(-d/9)) for the integer squared distances d = 0..18 of a 7x7 patch (exact table, so the
+// map is bit-identical to numpy's float64 exp rounded to float32 by the reference's .float())
+__constant__ float pa_gauss_tab[19] = {0x1.0000000000000p+0f, 0x1.ca28620000000p-1f, 0x1.99fa400000000p-1f, 0x1.6edd320000000p-1f,
+                       0x1.4848cc0000000p-1f, 0x1.25c3020000000p-1f, 0x1.06de9c0000000p-1f, 0x1.d673ba0000000p-2f,
+                       0x1.a4fa9e0000000p-2f, 0x1.78b5640000000p-2f, 0x1.5117f80000000p-2f, 0x1.2da5060000000p-2f,
+                       0x1.0dec680000000p-2f, 0x1.e313860000000p-3f, 0x1.b046900000000p-3f, 0x1.82d1360000000p-3f,
+                       0x1.5a23a80000000p-3f, 0x1.35bd300000000p-3f, 0x1.152aaa0000000p-3f};
+struct GaussPatch { int ulx, uly, brx, bry, valid; };
 
 __device__ __forceinline__ GaussPatch gauss_patch(double px, double py, int H, int W) {
     GaussPatch g;
     g.valid = !(px <= 0.0 || py <= 0.0 || px > (double)W || py > (double)H);
     g.ulx = (int)(px - 3.0);
     g.uly = (int)(py - 3.0);
-    int brx = (int)(px + 3.0), bry = (int)(py + 3.0);
-    if (g.ulx >= W || g.uly >= H || brx < 0 || bry < 0) g.valid = 0;
+    g.brx = (int)(px + 3.0);
+    g.bry = (int)(py + 3.0);
+    if (g.ulx >= W || g.uly >= H || g.brx < 0 || g.bry < 0) g.valid = 0;
     return g;
 }
 
 __device__ __forceinline__ float gauss_value(const GaussPatch& g, int x, int y) {
     if (!g.valid) return 0.f;
     int gx = x - g.ulx, gy = y - g.uly;
-    if ((unsigned)gx > 6u || (unsigned)gy > 6u) return 0.f;
-    double d = (double)((gx - 3) * (gx - 3) + (gy - 3) * (gy - 3));
-    return (float)exp(-d / 9.0);
+    // the pasted region is [ul, br] inclusive (:102-115); after truncation toward zero br - ul can be 5
+    if ((unsigned)gx > 6u || (unsigned)gy > 6u || x > g.brx || y > g.bry) return 0.f;
+    return pa_gauss_tab[(gx - 3) * (gx - 3) + (gy - 3) * (gy - 3)];
 }
 
 // materialising variant (parity tests / API): out [B][J][H][W] fp32
@@ -348,33 +356,33 @@ int pa_launch_pck(const float* pred, const float* gt, const float* norm, float b
 // ------------------------------------------------------------------------------------------------
 // per-sample geometry: forward transform at heat-map resolution and inverse at input resolution
 //   params[b] = {cx, cy, scale, rot, flip, gain_r, gain_g, gain_b}  (cx already mirrored when flip)
-__global__ void affine_params_kernel(const float* params, int B, int res_in, int res_out, double* t_out, double* tinv_in) {
+__global__ void affine_params_kernel(const double* params, int B, int res_in, int res_out, double* t_out, double* tinv_in) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
-    const float* p = params + (size_t)b * 8;
+    const double* p = params + (size_t)b * 8;
     double t[6], ti[6];
-    make_transform((double)p[0], (double)p[1], (double)p[2], (double)p[3], (double)res_out, 200.0, t);
+    make_transform(p[0], p[1], p[2], p[3], (double)res_out, 200.0, t);
 #pragma unroll
     for (int i = 0; i < 6; ++i) t_out[(size_t)b * 6 + i] = t[i];
-    make_transform((double)p[0], (double)p[1], (double)p[2], (double)p[3], (double)res_in, 200.0, t);
+    make_transform(p[0], p[1], p[2], p[3], (double)res_in, 200.0, t);
     invert_affine(t, ti);
 #pragma unroll
     for (int i = 0; i < 6; ++i) tinv_in[(size_t)b * 6 + i] = ti[i];
 }
 
-int pa_launch_affine_params(const float* params, int B, int res_in, int res_out, double* t_out, double* tinv_in, hipStream_t st) {
+int pa_launch_affine_params(const double* params, int B, int res_in, int res_out, double* t_out, double* tinv_in, hipStream_t st) {
     hipLaunchKernelGGL(affine_params_kernel, dim3((B + 63) / 64), dim3(64), 0, st, params, B, res_in, res_out, t_out, tinv_in);
     return (int)hipGetLastError();
 }
 
 // joints -> heat-map coordinates (reference pylib/HumanAug.py:45-54 + data/mpii_for_mpii.py:126-147):
 // optional mirror (x <- width - x, left/right joints swapped), transform, invalid (x<=0||y<=0) -> 0
-__global__ void transform_pts_kernel(const float* pts, const float* params, const double* t, int B, int J, float width, double* out,
+__global__ void transform_pts_kernel(const float* pts, const double* params, const double* t, int B, int J, float width, double* out,
                                      float* pts_img) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B * J) return;
     const int b = i / J, j = i - b * J;
-    const bool flip = params[(size_t)b * 8 + 4] != 0.f;
+    const bool flip = params[(size_t)b * 8 + 4] != 0.0;
     int src = j;
     if (flip && J == 16) {
         // left/right pairs of pylib/HumanAug.py:241-244: (0,5) (1,4) (2,3) (10,15) (11,14) (12,13)
@@ -393,7 +401,7 @@ __global__ void transform_pts_kernel(const float* pts, const float* params, cons
     if (pts_img) { pts_img[(size_t)i * 2] = fxf; pts_img[(size_t)i * 2 + 1] = y; }
 }
 
-int pa_launch_transform_pts(const float* pts, const float* params, const double* t, int B, int J, float width, double* out,
+int pa_launch_transform_pts(const float* pts, const double* params, const double* t, int B, int J, float width, double* out,
                             float* pts_img, hipStream_t st) {
     hipLaunchKernelGGL(transform_pts_kernel, dim3((B * J + 63) / 64), dim3(64), 0, st, pts, params, t, B, J, width, out, pts_img);
     return (int)hipGetLastError();
@@ -403,7 +411,7 @@ int pa_launch_transform_pts(const float* pts, const float* params, const double*
 // reference pylib/HumanAug.py:117-176): out[b][v][u][c] = clamp(gain_c * bilinear(src_b, Tinv_b (u,v))),
 // zero outside the frame, optional mirror of the source frame, output NHWC with 4 channels (4th = 0).
 // src: uint8 [B][Hs][Ws][3].  out4: bf16 [B][res][res][4]; outf (optional): fp32 NCHW [B][3][res][res].
-__global__ void warp_kernel(const unsigned char* src, int Hs, int Ws, const double* tinv, const float* params, int B, int res,
+__global__ void warp_kernel(const unsigned char* src, int Hs, int Ws, const double* tinv, const double* params, int B, int res,
                             bf16* out4, float* outf) {
     const size_t total = (size_t)B * res * res;
     for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
@@ -411,8 +419,8 @@ __global__ void warp_kernel(const unsigned char* src, int Hs, int Ws, const doub
         const size_t r = t / res;
         const int v = (int)(r % res), b = (int)(r / res);
         const double* ti = tinv + (size_t)b * 6;
-        const float* p = params + (size_t)b * 8;
-        const bool flip = p[4] != 0.f;
+        const double* p = params + (size_t)b * 8;
+        const bool flip = p[4] != 0.0;
         const double sx = ti[0] * u + ti[1] * v + ti[2], sy = ti[3] * u + ti[4] * v + ti[5];
         const double fx0 = floor(sx), fy0 = floor(sy);
         const int x0 = (int)fx0, y0 = (int)fy0;
@@ -432,7 +440,7 @@ __global__ void warp_kernel(const unsigned char* src, int Hs, int Ws, const doub
         }
         float o[3];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) o[c] = (float)fmin(fmax(acc[c] * (double)p[5 + c], 0.0), 1.0);
+        for (int c = 0; c < 3; ++c) o[c] = (float)fmin(fmax(acc[c] * p[5 + c], 0.0), 1.0);
         if (out4) {
             bf16x4 ob = {(bf16)o[0], (bf16)o[1], (bf16)o[2], (bf16)0.f};
             *reinterpret_cast<bf16x4*>(out4 + t * 4) = ob;
@@ -446,7 +454,7 @@ __global__ void warp_kernel(const unsigned char* src, int Hs, int Ws, const doub
     }
 }
 
-int pa_launch_warp(const unsigned char* src, int Hs, int Ws, const double* tinv, const float* params, int B, int res,
+int pa_launch_warp(const unsigned char* src, int Hs, int Ws, const double* tinv, const double* params, int B, int res,
                    bf16* out4, float* outf, hipStream_t st) {
     size_t total = (size_t)B * res * res;
     int blocks = (int)((total + 255) / 256);
@@ -480,13 +488,13 @@ __device__ __forceinline__ double pa_normal(unsigned long long seed, unsigned lo
 // mode 0: regular law; mode 1: agent law with bins (scale_idx, rot_idx); mode 2/3: agent law, scale only / rotation only
 // meta[b] = {objpos_x, objpos_y, scale (already MPII-normalised), frame_width}
 __global__ void sample_aug_kernel(const float* meta, const int* scale_idx, const int* rot_idx, int mode, unsigned long long seed,
-                                  unsigned long long step, int B, float* params) {
+                                  unsigned long long step, int B, double* params) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     const float* m = meta + (size_t)b * 4;
     double s = (double)m[2], r = 0.0;
-    float cx = m[0];
-    float flip = 0.f, g0 = 1.f, g1 = 1.f, g2 = 1.f;
+    double cx = (double)m[0];
+    double flip = 0.0, g0 = 1.0, g1 = 1.0, g2 = 1.0;
     if (mode == 0) {
         const double zs = pa_normal(seed, step, b, 0), zr = pa_normal(seed, step, b, 2);
         s *= exp2(fmax(-0.5, fmin(0.5, zs * 0.25)));
@@ -504,17 +512,18 @@ __global__ void sample_aug_kernel(const float* meta, const int* scale_idx, const
         }
     }
     if (mode == 0 || mode == 1) {
-        if (pa_uniform(seed, step, b, 5) <= 0.5) { flip = 1.f; cx = m[3] - cx; }
-        g0 = (float)(0.6 + 0.8 * pa_uniform(seed, step, b, 6));
-        g1 = (float)(0.6 + 0.8 * pa_uniform(seed, step, b, 7));
-        g2 = (float)(0.6 + 0.8 * pa_uniform(seed, step, b, 8));
+        if (pa_uniform(seed, step, b, 5) <= 0.5) { flip = 1.0; cx = (double)m[3] - cx; }
+        g0 = 0.6 + 0.8 * pa_uniform(seed, step, b, 6);
+        g1 = 0.6 + 0.8 * pa_uniform(seed, step, b, 7);
+        g2 = 0.6 + 0.8 * pa_uniform(seed, step, b, 8);
     }
-    float* p = params + (size_t)b * 8;
-    p[0] = cx; p[1] = m[1]; p[2] = (float)s; p[3] = (float)r; p[4] = flip; p[5] = g0; p[6] = g1; p[7] = g2;
+    // centre and scale are fp32 quantities in the reference (torch tensors), the rotation a float64
+    double* p = params + (size_t)b * 8;
+    p[0] = (double)(float)cx; p[1] = (double)m[1]; p[2] = (double)(float)s; p[3] = r; p[4] = flip; p[5] = g0; p[6] = g1; p[7] = g2;
 }
 
 int pa_launch_sample_aug(const float* meta, const int* scale_idx, const int* rot_idx, int mode, unsigned long long seed,
-                         unsigned long long step, int B, float* params, hipStream_t st) {
+                         unsigned long long step, int B, double* params, hipStream_t st) {
     hipLaunchKernelGGL(sample_aug_kernel, dim3((B + 63) / 64), dim3(64), 0, st, meta, scale_idx, rot_idx, mode, seed, step, B, params);
     return (int)hipGetLastError();
 }

@@ -155,6 +155,10 @@ class _HipModule(object):
     def reset_parameters(self, seed=None):
         """The reference's initialisation (models/asn_stacked_hg.py:258-270): conv weight and bias
         U(+-1/sqrt(k*k*Cin)), BatchNorm gamma U(0,1), beta 0; Linear layers keep torch's default."""
+        if self._table is None:
+            self._net(self.default_batch)          # creates the buffers and calls back into this method
+            if seed is None:
+                return
         g = torch.Generator().manual_seed(int(seed) if seed is not None else torch.initial_seed() % (2 ** 31))
         bound = None
         for name, shape, off, numel, kind in self._table:

@@ -11,15 +11,15 @@ def _scalar(v):
 
 
 def make_params(center, scale, rot, flip=None, gain=None):
-    """[B][8] fp32 {cx, cy, scale, rot, flip, gain_r, gain_g, gain_b} (layout of include/poseadv.h)."""
+    """[B][8] float64 {cx, cy, scale, rot, flip, gain_r, gain_g, gain_b} (layout of include/poseadv.h)."""
     c = np.asarray(center, dtype=np.float64).reshape(-1, 2)
     B = c.shape[0]
-    p = np.zeros((B, 8), dtype=np.float32)
+    p = np.zeros((B, 8), dtype=np.float64)
     p[:, 0:2] = c
     p[:, 2] = np.asarray(scale, dtype=np.float64).reshape(-1)
     p[:, 3] = np.asarray(rot, dtype=np.float64).reshape(-1)
-    p[:, 4] = 0 if flip is None else np.asarray(flip, dtype=np.float32).reshape(-1)
-    p[:, 5:8] = 1 if gain is None else np.asarray(gain, dtype=np.float32).reshape(-1, 3)
+    p[:, 4] = 0 if flip is None else np.asarray(flip, dtype=np.float64).reshape(-1)
+    p[:, 5:8] = 1 if gain is None else np.asarray(gain, dtype=np.float64).reshape(-1, 3)
     return torch.from_numpy(p).to(dev())
 
 

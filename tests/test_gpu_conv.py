@@ -1,0 +1,85 @@
+"""GPU parity of the MFMA implicit-GEMM convolution kernels (forward, data gradient, weight gradient)
+against torch.nn.functional.conv2d in fp32 on bf16-rounded operands.  Tolerance: the kernels multiply
+bf16 operands exactly and accumulate in fp32, outputs are rounded to bf16 once: rel-rms <= 4e-3
+(= bf16 half-ulp 2^-9 ~ 2e-3 plus accumulation-order noise); weight gradients stay fp32: <= 1e-4."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests import inputs
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_rms(a, b):
+    a = a.double().flatten(); b = b.double().flatten()
+    return float((a - b).pow(2).mean().sqrt() / (b.pow(2).mean().sqrt() + 1e-30))
+
+
+def run_conv(mode, a, b, w, bias, B, Cin, Cout, H, W, k):
+    from pose_adv_aug_amd._lib import lib, check, ptr, stream
+    L = lib()
+    ws = torch.zeros(L.pa_conv2d_workspace_bytes(B, Cin, Cout, H, W, k), dtype=torch.uint8, device='cuda')
+    if mode == 0:
+        out = torch.empty((B, Cout, H, W), device='cuda'); out2 = None
+    elif mode == 1:
+        out = torch.empty((B, Cin, H, W), device='cuda'); out2 = None
+    else:
+        out = torch.empty((Cout, Cin, k, k), device='cuda'); out2 = torch.empty(Cout, device='cuda')
+    # keep the device copies alive across the call (a temporary's block would be recycled by the allocator)
+    ad = a.cuda().contiguous(); bd = b.cuda().contiguous() if b is not None else None
+    wd = w.cuda().contiguous(); biasd = bias.cuda() if bias is not None else None
+    check(L.pa_conv2d(mode, ptr(ad), ptr(bd), ptr(wd), ptr(biasd), ptr(out), ptr(out2),
+                      B, Cin, Cout, H, W, k, ptr(ws), stream()), 'pa_conv2d')
+    return out.cpu(), (out2.cpu() if out2 is not None else None)
+
+
+SHAPES = [
+    # B, Cin, Cout, H, W, k     (M = B*H*W)
+    (2, 64, 64, 8, 8, 1),        # single 64x64 tile, K = 64
+    (2, 128, 64, 16, 16, 1),     # two K steps
+    (1, 64, 128, 5, 7, 1),       # ragged M = 35
+    (2, 256, 128, 32, 32, 1),    # the bottleneck reduce conv
+    (2, 128, 128, 16, 16, 3),    # the 3x3 conv, borders everywhere
+    (3, 64, 64, 6, 10, 3),       # ragged M, non-square
+    (24, 128, 256, 64, 64, 1),   # full-size expand conv: M = 98304 -> 128x128 tiles
+    (24, 128, 128, 64, 64, 3),   # full-size 3x3 (BASELINE config 2 shape)
+]
+
+
+@pytest.mark.parametrize('B,Cin,Cout,H,W,k', SHAPES)
+def test_conv_forward(B, Cin, Cout, H, W, k):
+    g = inputs.rng(100, B, Cin, Cout, H, k)
+    x = torch.from_numpy(g.standard_normal((B, Cin, H, W)).astype(np.float32))
+    w = torch.from_numpy((g.standard_normal((Cout, Cin, k, k)) / np.sqrt(Cin * k * k)).astype(np.float32))
+    bias = torch.from_numpy(g.standard_normal(Cout).astype(np.float32))
+    y, _ = run_conv(0, x, None, w, bias, B, Cin, Cout, H, W, k)
+    ref = F.conv2d(x.bfloat16().float(), w.bfloat16().float(), bias, padding=k // 2)
+    assert rel_rms(y, ref) < 4e-3
+
+
+@pytest.mark.parametrize('B,Cin,Cout,H,W,k', SHAPES)
+def test_conv_dgrad(B, Cin, Cout, H, W, k):
+    g = inputs.rng(101, B, Cin, Cout, H, k)
+    dy = torch.from_numpy(g.standard_normal((B, Cout, H, W)).astype(np.float32))
+    w = torch.from_numpy((g.standard_normal((Cout, Cin, k, k)) / np.sqrt(Cin * k * k)).astype(np.float32))
+    dx, _ = run_conv(1, dy, None, w, None, B, Cin, Cout, H, W, k)
+    ref = F.conv_transpose2d(dy.bfloat16().float(), w.bfloat16().float(), padding=k // 2)
+    assert rel_rms(dx, ref) < 4e-3
+
+
+@pytest.mark.parametrize('B,Cin,Cout,H,W,k', SHAPES)
+def test_conv_wgrad(B, Cin, Cout, H, W, k):
+    g = inputs.rng(102, B, Cin, Cout, H, k)
+    dy = torch.from_numpy(g.standard_normal((B, Cout, H, W)).astype(np.float32))
+    x = torch.from_numpy(g.standard_normal((B, Cin, H, W)).astype(np.float32))
+    w = torch.zeros((Cout, Cin, k, k))
+    dw, db = run_conv(2, dy, x, w, None, B, Cin, Cout, H, W, k)
+    xr = x.bfloat16().float(); dyr = dy.bfloat16().float()
+    wr = torch.zeros((Cout, Cin, k, k), requires_grad=True)
+    br = torch.zeros(Cout, requires_grad=True)
+    torch.set_num_threads(8)
+    F.conv2d(xr, wr, br, padding=k // 2).backward(dyr)
+    assert rel_rms(dw, wr.grad) < 1e-4
+    assert rel_rms(db, br.grad) < 1e-4

@@ -1,0 +1,187 @@
+"""Local-consistency parity of the WHOLE training graph (forward and hand-written backward).
+
+An untrained 100-layer ReLU/BatchNorm network is chaotic: a 1-ulp bf16 difference in an early layer
+grows to several % at the output (measured: bf16-storage emulation vs fp32 oracle differ by ~8 % at the
+heat maps of the test net), so end-to-end tensor comparisons cannot have a tight tolerance.  Instead
+every operation of the graph is checked IN PLACE: its inputs are read back from the HIP engine
+(pa_hg_debug_tensor), the oracle's module with the engine's bf16 storage points (tests/bf16_emul.py,
+built on oracle/model.py) is evaluated on exactly those inputs, and the result is compared with what
+the engine stored.  The same for the backward: each op's upstream gradient is read back from the
+engine, autograd of the emulated op gives the expected parameter / input gradients.  If every node
+matches locally, the engine's graph IS the reference's graph (same wiring, same local arithmetic).
+
+Tolerances: forward rel-rms 1e-2 (one op's worth of bf16 rounding, 2^-9 ~ 2e-3, plus BatchNorm
+renormalisation); gradients rel-rms 4e-2 / cosine 0.999 (gradient tensors are stored in bf16 too)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import model as om
+from oracle import pylib as opl
+from tests import inputs, bf16_emul
+from tests.bf16_emul import R, emul_residual, _conv, _bn
+from tests.test_gpu_net import rel_rms, cosine, t, _hg_pair
+
+pytestmark = pytest.mark.gpu
+
+FWD_TOL = 1e-2
+GRAD_TOL, GRAD_COS = 4e-2, 0.999
+
+
+class Probe(object):
+    def __init__(self, net):
+        from pose_adv_aug_amd._lib import lib, check, ptr
+        self.net, self.lib, self.check, self.ptr = net, lib(), check, ptr
+        self.h = net._net(net._last_B)
+
+    def get(self, name, grad=0):
+        shp = (C.c_int * 4)()
+        self.check(self.lib.pa_hg_debug_tensor(self.h, name.encode(), grad, None, shp))
+        out = torch.empty(tuple(shp), device='cuda')
+        self.check(self.lib.pa_hg_debug_tensor(self.h, name.encode(), grad, self.ptr(out), shp))
+        return out.cpu()
+
+    def act(self, name):
+        return self.get(name, 0)
+
+    def grad(self, name):
+        return self.get(name, 1)
+
+
+def _close(errs, what, got, ref, tol, cos=None):
+    e = rel_rms(got, ref)
+    c = cosine(got, ref)
+    if not (e < tol and (cos is None or c > cos)):
+        errs.append((what, round(e, 4), round(c, 5)))
+
+
+def _leaf(x):
+    return x.clone().requires_grad_(True)
+
+
+def test_every_node_of_the_training_graph_matches_locally():
+    torch.set_num_threads(8)
+    stacks, B, res, chan = 2, 2, 256, 128
+    ref, net = _hg_pair(stacks, chan, B, res, seed=7)
+    img = t(inputs.images(8, B, res))
+    pts = inputs.heat_pts(9, B, res=res // 4)
+    heat_t = t(inputs.heatmaps_from_pts(pts, res=res // 4))
+    ref.train(); net.train()
+    loss, outs = net.loss_and_backward(img.cuda(), t(pts).cuda(), want_outputs=True)
+    P = Probe(net)
+    hip_grads = {n: g.cpu() for n, g in net.named_grads()}
+    errs = []
+    numel = float(B * 16 * (res // 4) ** 2)
+
+    def check_param_grads(prefix, module):
+        for n, p in module.named_parameters():
+            full = prefix + n
+            if full.endswith('bias') and p.grad is not None and float(hip_grads[full].abs().max()) == 0.0 \
+                    and float(p.grad.abs().max()) < 1e-3 * float(module.weight.grad.abs().max() if hasattr(module, 'weight')
+                                                                 else max(q.grad.abs().max() for q in module.parameters())):
+                continue        # bias in front of a BatchNorm: exactly zero in the engine, rounding noise in autograd
+            _close(errs, 'grad ' + full, hip_grads[full], p.grad, GRAD_TOL, GRAD_COS)
+
+    def residual_node(blk, prefix, in_name, out_name):
+        """forward + backward of one residual block at the engine's own operating point.
+        Returns the block's contribution to d(loss)/d(input activation)."""
+        a_in = _leaf(P.act(in_name))
+        tap = {}
+        a3 = emul_residual(blk, a_in, tap, out_name)
+        for k in ('.x1', '.x2', ''):
+            _close(errs, 'fwd ' + out_name + k, P.act(out_name + k), tap[out_name + k].detach(), FWD_TOL)
+        blk.zero_grad()
+        a3.backward(P.grad(out_name))           # the engine stores dz = da * [a > 0]; relu'(a) re-applies the same mask
+        check_param_grads(prefix, blk)
+        for k in ('.x1', '.x2'):
+            inner = tap[out_name + k]
+            _close(errs, 'dz ' + out_name + k, P.grad(out_name + k), inner.grad * (inner.detach() > 0).float(), GRAD_TOL, GRAD_COS)
+        return a_in.grad
+
+    def pool_contrib(in_name, pool_name):
+        a = _leaf(P.act(in_name))
+        p = R(F.max_pool2d(a, 2, 2))
+        _close(errs, 'fwd ' + pool_name, P.act(pool_name), p.detach(), FWD_TOL)
+        p.backward(P.grad(pool_name))
+        return a.grad
+
+    def node_grad(name, total, pending_bn=True):
+        exp = total * (P.act(name) > 0).float() if pending_bn else total
+        _close(errs, 'node-grad ' + name, P.grad(name), exp, GRAD_TOL, GRAD_COS)
+
+    # ---------------- stem
+    a_img = R(img)
+    stem = torch.relu(_bn(ref.bn1, R(_conv(ref.conv1, a_img))))
+    _close(errs, 'fwd stem', P.act('stem'), stem.detach(), FWD_TOL)
+    ref.zero_grad()
+    stem.backward(P.grad('stem'))
+    _close(errs, 'grad conv1.weight', hip_grads['conv1.weight'], ref.conv1.weight.grad, GRAD_TOL, GRAD_COS)
+    _close(errs, 'grad bn1.weight', hip_grads['bn1.weight'], ref.bn1.weight.grad, GRAD_TOL, GRAD_COS)
+    _close(errs, 'grad bn1.bias', hip_grads['bn1.bias'], ref.bn1.bias.grad, GRAD_TOL, GRAD_COS)
+    node_grad('stem', residual_node(ref.residual1, 'residual1.', 'stem', 'res1'))
+    node_grad('res1', pool_contrib('res1', 'pool0'))
+    node_grad('pool0', residual_node(ref.residual2, 'residual2.', 'pool0', 'res2'), pending_bn=False)
+    node_grad('res2', residual_node(ref.residual3, 'residual3.', 'res2', 'res3'))
+    _close(errs, 'fwd xin0', P.act('xin0'), P.act('res3'), 1e-6)
+
+    # ---------------- stacks
+    for i in range(stacks):
+        hg, hp = ref.hg[i], 'hg.%d.' % i
+        hn = 'hg%d' % i
+        x_names = ['xin%d' % i] + ['%s.down%d' % (hn, k) for k in (1, 2, 3, 4)]
+        contrib = {}
+        for k in (1, 2, 3, 4):
+            src = x_names[k - 1]
+            c_skip = residual_node(getattr(hg, 'skip%d' % k)[0], '%sskip%d.0.' % (hp, k), src, '%s.skip%d' % (hn, k))
+            c_pool = pool_contrib(src, '%s.pool%d' % (hn, k))
+            contrib[src] = c_skip + c_pool
+            c_down = residual_node(getattr(hg, 'down%d' % k)[0], '%sdown%d.0.' % (hp, k), '%s.pool%d' % (hn, k), '%s.down%d' % (hn, k))
+            node_grad('%s.pool%d' % (hn, k), c_down, pending_bn=False)
+        node_grad('%s.down4' % hn, residual_node(hg.neck[0], hp + 'neck.0.', '%s.down4' % hn, '%s.neck' % hn))
+        low = '%s.neck' % hn
+        for k in (4, 3, 2, 1):
+            c_up = residual_node(getattr(hg, 'up%d' % k)[0], '%sup%d.0.' % (hp, k), low, '%s.up%d' % (hn, k))
+            node_grad(low, c_up, pending_bn=(k == 4))
+            # merge_k = up2(up_k) + skip_k
+            a_up, a_sk = _leaf(P.act('%s.up%d' % (hn, k))), _leaf(P.act('%s.skip%d' % (hn, k)))
+            m = R(F.interpolate(a_up, scale_factor=2, mode='nearest') + a_sk)
+            _close(errs, 'fwd %s.merge%d' % (hn, k), P.act('%s.merge%d' % (hn, k)), m.detach(), FWD_TOL)
+            m.backward(P.grad('%s.merge%d' % (hn, k)))
+            node_grad('%s.up%d' % (hn, k), a_up.grad)
+            node_grad('%s.skip%d' % (hn, k), a_sk.grad)
+            low = '%s.merge%d' % (hn, k)
+        for k in (1, 2, 3):                      # down_k feeds skip_{k+1} and pool_{k+1}
+            node_grad('%s.down%d' % (hn, k), contrib['%s.down%d' % (hn, k)])
+        # post residual, linear, heads, re-injection
+        node_grad('%s.merge1' % hn, residual_node(ref.post_res[i][0], 'post_res.%d.0.' % i, '%s.merge1' % hn, 'post%d' % i),
+                  pending_bn=False)
+        a_post, a_x = _leaf(P.act('post%d' % i)), _leaf(P.act('xin%d' % i))
+        lin, lbn = ref.linear[i][0], ref.linear[i][1]
+        l = torch.relu(_bn(lbn, R(_conv(lin, a_post))))
+        _close(errs, 'fwd lin%d' % i, P.act('lin%d' % i), l.detach(), FWD_TOL)
+        heat = _conv(ref.out_conv[i], l)
+        _close(errs, 'fwd heat%d' % i, outs[i].cpu(), heat.detach(), FWD_TOL)
+        obj = ((heat - heat_t) ** 2).sum() / numel
+        inner = i + 1 < stacks
+        if inner:
+            tmp = R(_conv(ref.forth_conv[i], l) + a_x)
+            xn = R(_conv(ref.in_conv[i], heat) + tmp)
+            _close(errs, 'fwd xin%d' % (i + 1), P.act('xin%d' % (i + 1)), xn.detach(), FWD_TOL)
+            obj = obj + (xn * P.grad('xin%d' % (i + 1))).sum()
+        for m_ in (lin, lbn, ref.out_conv[i]) + ((ref.forth_conv[i], ref.in_conv[i]) if inner else ()):
+            m_.zero_grad()
+        obj.backward()
+        check_param_grads('linear.%d.0.' % i, lin)
+        check_param_grads('linear.%d.1.' % i, lbn)
+        check_param_grads('out_conv.%d.' % i, ref.out_conv[i])
+        if inner:
+            check_param_grads('forth_conv.%d.' % i, ref.forth_conv[i])
+            check_param_grads('in_conv.%d.' % i, ref.in_conv[i])
+        node_grad('post%d' % i, a_post.grad)
+        # the stack input: skip1 + pool1 (+ identity into the next stack's input)
+        total = contrib['xin%d' % i] + (a_x.grad if inner else 0)
+        node_grad('xin%d' % i, total, pending_bn=(i == 0))
+    assert not errs, '%d local mismatches, first: %s' % (len(errs), errs[:15])
