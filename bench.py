@@ -1,0 +1,177 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/sec of the full stage-1 training step of the 2-stack hourglass
+(BASELINE.json configs[1]: bs = 24 per GPU, 256x256 MPII-shape synthetic input, bf16 storage):
+
+    on-device augmentation law + bilinear warp  ->  forward  ->  Gaussian-target MSE  ->  hand-written
+    backward  ->  ONE all-reduce of the flat gradient (RCCL, N > 1)  ->  fused RMSprop + bf16 weight
+    re-pack  ->  PCKh (heat-map space and original resolution) on the device
+
+    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+
+Prints ONE JSON line on rank 0 (contract in the task description).  `roofline` comes from HIP events
+recorded around every launch of the MFMA kernels on the engine's own stream during a second pass of K
+steps right after the timed region (same inputs, same code path; the events are kept out of the timed
+region so that they do not perturb `value`).  `cpu_baseline` is the CPU oracle (PyTorch fp32
+restatement of stack-hg.py:153-180) timed on this box's host cores on a bounded sample."""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PROF_NAMES = ['conv_fwd_1x1', 'conv_fwd_3x3', 'conv_dgrad_1x1', 'conv_dgrad_3x3', 'conv_wgrad_1x1', 'conv_wgrad_3x3',
+              'stem_fwd_7x7', 'stem_wgrad_7x7']
+HBM_PEAK = 8.0e12          # B/s   (MI355X_MICROARCH.md)
+MFMA_PEAK = 2.5e15         # FLOP/s dense bf16
+
+
+def cpu_baseline(stacks, chan, B, res, budget_s=25.0):
+    """The CPU oracle's train step (forward, sum-over-stacks MSE, backward, RMSprop, heat-map PCK) on the host."""
+    from oracle import model as om, step as ostep
+    from tests import inputs
+    # PyTorch's CPU convolutions stop scaling (and collapse when oversubscribed) well before the core
+    # count of a GPU host: 32 threads is the measured sweet spot region; the count used is reported.
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    net = om.create_hg(stacks, 1, 16, chan)
+    om.deterministic_fill_(net, seed=0)
+    opt = ostep.make_optimizer(net)
+
+    def batch(b):
+        return (torch.from_numpy(inputs.images(1, b, res)),
+                torch.from_numpy(inputs.heatmaps_from_pts(inputs.heat_pts(2, b, res=res // 4), res=res // 4)))
+    img, heat = batch(2)
+    ostep.pose_train_step(net, opt, img, heat)            # warm-up (allocations, oneDNN primitive caches)
+    t0 = time.time()
+    ostep.pose_train_step(net, opt, img, heat)
+    per_img = (time.time() - t0) / 2
+    if per_img * B > budget_s:                            # bounded sample: shrink the batch, keep the workload
+        B = max(2, int(budget_s / per_img / 2))
+    img, heat = batch(B)
+    n, t1 = 0, time.time()
+    while n < 1 or (time.time() - t1 < budget_s and n < 3):
+        ostep.pose_train_step(net, opt, img, heat)
+        n += 1
+    dt = (time.time() - t1) / n
+    return {'value': B / dt, 'unit': 'images/sec', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': '%d timed step(s) after 1 warm-up of the fp32 PyTorch-CPU oracle (oracle/step.py), %d-stack chan %d, '
+                      'B=%d, %dx%d, %.2f s/step' % (n, stacks, chan, B, res, res, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=30)
+    ap.add_argument('--warmup', type=int, default=8)
+    ap.add_argument('--bs', type=int, default=24, help='per-GPU batch (BASELINE config: 24)')
+    ap.add_argument('--stacks', type=int, default=2)
+    ap.add_argument('--chan', type=int, default=256)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    args = ap.parse_args()
+
+    from pose_adv_aug_amd import _lib
+    from pose_adv_aug_amd.stack_hg import init_distributed, broadcast_parameters, train_step
+    from pose_adv_aug_amd.data import Augmenter, DeviceBatch
+    from pose_adv_aug_amd.models.asn_stacked_hg import create_hg
+    from pose_adv_aug_amd.utils.optim import RMSprop
+
+    _lib.require_gpu()
+    rank, world, local = init_distributed()
+    if world != args.gpus:
+        raise SystemExit('bench.py --gpus %d needs WORLD_SIZE=%d (launch N > 1 with torch.distributed.run)' % (args.gpus, args.gpus))
+    dev = torch.device('cuda', torch.cuda.current_device())
+    B, res = args.bs, 256
+    net = create_hg(args.stacks, 1, 16, args.chan, res=res, default_batch=B)
+    net.reset_parameters(seed=0)
+    broadcast_parameters(net)
+    opt = RMSprop(net, lr=2.5e-4, alpha=0.99, eps=1e-8)
+    aug = Augmenter(seed=100 + rank)
+    batches = [DeviceBatch.synthetic(B, seed=rank * 100 + k) for k in range(2)]       # resident in HBM
+    net.train()
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def run(n):
+        out = None
+        for i in range(n):
+            out = train_step(net, opt, aug, batches[i % len(batches)])
+        return out
+
+    run(args.warmup)
+    sync()
+    t0 = time.perf_counter()
+    loss, pckh, pckh_o = run(args.steps)
+    sync()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax[0])
+    value = world * B * args.steps / dt
+
+    roofline = None
+    if not args.no_roofline:
+        h = net._net(B)
+        _lib.check(_lib.lib().pa_net_profile_begin(h))
+        run(args.steps)
+        rep = (C.c_double * 32)()
+        _lib.check(_lib.lib().pa_net_profile_report(h, rep))
+        rows = []
+        for i, name in enumerate(PROF_NAMES):
+            ms, cnt, by, fl = rep[4 * i], rep[4 * i + 1], rep[4 * i + 2], rep[4 * i + 3]
+            if cnt > 0:
+                rows.append({'kernel': name, 'ms_total': ms, 'launches': int(cnt), 'avg_us': 1e3 * ms / cnt,
+                             'bytes': by, 'flops': fl})
+        dom = max(rows, key=lambda r: r['ms_total'])
+        ai = dom['flops'] / dom['bytes']
+        bound = 'mfma' if ai > MFMA_PEAK / HBM_PEAK else 'hbm'
+        secs = dom['ms_total'] * 1e-3
+        if bound == 'mfma':
+            ach, peak, unit = dom['flops'] / secs / 1e12, MFMA_PEAK / 1e12, 'TFLOP/s'
+        else:
+            ach, peak, unit = dom['bytes'] / secs / 1e9, HBM_PEAK / 1e9, 'GB/s'
+        conv_ms = sum(r['ms_total'] for r in rows) / args.steps
+        roofline = {'bound': bound, 'achieved': round(ach, 2), 'peak': peak, 'unit': unit, 'frac': round(ach / peak, 4),
+                    'traffic': None, 'kernel': dom['kernel'], 'avg_launch_us': round(dom['avg_us'], 2),
+                    'launches_per_step': dom['launches'] // args.steps,
+                    'alg_bytes_per_launch': dom['bytes'] / dom['launches'], 'alg_flops_per_launch': dom['flops'] / dom['launches'],
+                    'mfma_kernels_ms_per_step': round(conv_ms, 3),
+                    'classes': {r['kernel']: {'ms_per_step': round(r['ms_total'] / args.steps, 3),
+                                              'tflops': round(r['flops'] / (r['ms_total'] * 1e-3) / 1e12, 1),
+                                              'gbps': round(r['bytes'] / (r['ms_total'] * 1e-3) / 1e9, 1)} for r in rows},
+                    'whole_step': {'hbm_frac': round(value / world * 380.5e6 / HBM_PEAK, 4),
+                                   'mfma_frac': round(value / world * 50.0e9 / MFMA_PEAK, 4)}}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args.stacks, args.chan, B, res)
+
+    if rank == 0:
+        line = {'metric': 'images/sec, 2-stack HG 256x256 bs=24 per GPU, full training step', 'value': round(value, 2),
+                'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+                'ms_per_step': round(1e3 * dt / args.steps, 3), 'higher_is_better': True, 'scaling': 'weak',
+                'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+                'config': {'workload': 'BASELINE configs[1]: %d-stack hourglass chan %d, bs=%d/GPU, 256x256 MPII-shape synthetic frames '
+                                       '(720x1280 uint8 resident in HBM), on-device HumanAug warp, heat-map MSE, RMSprop, PCKh'
+                                       % (args.stacks, args.chan, B),
+                           'global_batch': world * B, 'parallelism': 'dp%d' % world,
+                           'loss': float(loss), 'pckh': float(pckh), 'pckh_origin_res': float(pckh_o)},
+                'roofline': roofline, 'cpu_baseline': cpu}
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

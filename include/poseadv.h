@@ -154,6 +154,20 @@ int pa_hg_backward(pa_net* net);
  * of the joints given to the last forward: acc [nidx+1]. */
 int pa_hg_accuracy(pa_net* net, int stack, const int32_t* idxs, int nidx, float* acc, float* scratch);
 
+/* Evaluation.accuracy_origin_res (pylib/Evaluation.py:77-97) and, when person != NULL,
+ * per_person_pckh (:99-167) of stack i's heat maps of the last forward, read in place (NHWC fp32).
+ * center [B][2], scale [B], rot [B], gt_pts [B][16][2], norm [B] fp32; idxs int32 [nidx];
+ * acc [nidx+1] or NULL; person [B] or NULL; scratch: 6*B*16 (+ B*16*(res/4)^2 if person) floats. */
+int pa_hg_pckh(pa_net* net, int stack, const float* center, const float* scale, const float* rot, const float* gt_pts,
+               const float* norm, const int32_t* idxs, int nidx, float* acc, float* person, float* scratch);
+
+/* Per-launch HIP-event timing of the MFMA kernels on the net's stream (bench.py's `roofline`).
+ * begin: start recording; report: synchronise, fill out[8][4] = {total ms, launches, algorithmic
+ * bytes, flops} for the classes 0 fwd 1x1, 1 fwd 3x3, 2 dgrad 1x1, 3 dgrad 3x3, 4 wgrad 1x1,
+ * 5 wgrad 3x3, 6 stem fwd, 7 stem wgrad, and stop recording.  out is a HOST array. */
+int pa_net_profile_begin(pa_net* net);
+int pa_net_profile_report(pa_net* net, double* out_host);
+
 /* Test hook: copy an internal activation (pending BatchNorm+ReLU applied) or, with grad != 0, its raw
  * gradient buffer out as NCHW fp32; shape4 receives {B, C, H, W} (out may be NULL to query the shape).
  * Names: "stem", "res1".."res3", "pool0", "hg<i>.skip<k>|pool<k>|down<k>|up<k>|merge<k>|neck" (k=1..4),

@@ -75,7 +75,7 @@ struct ResidualOp {
     Net n; Residual r; Act in;
     size_t build(int B, int H, int W, int C, char* base) {
         Arena a; a.base = base;
-        for (BNLayer* b : n.bns) { b->stats = a.get<float>(2 * b->C); b->bstats = a.get<float>(2 * b->C); }
+        n.loss_dev = a.get<float>(64);
         a.take(0);
         n.stats_arena = reinterpret_cast<float*>(base); n.stats_arena_floats = a.off / sizeof(float);
         n.prep_jobs = a.get<PaPrepJob>(n.convs.size());
@@ -185,6 +185,65 @@ int pa_conv2d(int mode, const float* a_in, const float* b_in, const float* w, co
     return 0;
 }
 
+// micro-benchmark of ONE conv launch (tools/bench_conv.py): variant bits select what the launch does
+//   bit0: input transform BNRELU (fwd) / LIN2 (dgrad, wgrad dy)      bit1: epilogue STATS (fwd) / BWD (dgrad)
+//   bit2: one residual addend                                         bit3 (wgrad): x operand BNRELU
+// Returns the average milliseconds per launch over `iters` launches (HIP events on the stream).
+int pa_conv2d_time(int mode, int variant, int B, int Cin, int Cout, int H, int W, int k, int iters, void* ws, float* ms_out, void* s) {
+    g_err[0] = 0;
+    ConvOp op; Net& n = op.n; n.is_agent = true; n.B = B; n.st = ST(s);
+    n.declare_conv(op.c, "c", Cin, Cout, k, false);
+    BNLayer bn_in, bn_out;
+    n.declare_bn(bn_in, "bi", mode == 0 ? Cin : Cout);
+    n.declare_bn(bn_out, "bo", mode == 0 ? Cout : Cin);
+    Arena a; a.base = reinterpret_cast<char*>(ws);
+    a.off = op.build(B, H, W, a.base);
+    for (BNLayer* b : n.bns) n.layout_bn(*b, a, B * H * W);
+    const size_t M = (size_t)B * H * W;
+    bf16* extra = a.get<bf16>(M * (Cin > Cout ? Cin : Cout));      // residual addend / xref / second LIN2 operand
+    bf16* extra2 = a.get<bf16>(M * (Cin > Cout ? Cin : Cout));
+    float* pbuf = a.get<float>(2 * (n.n_params + 8));
+    n.params = pbuf; n.grads = pbuf + n.n_params + 8; n.buffers = pbuf;
+    TRY(n.upload_tables());
+    auto mk = [&](const bf16* p, BNLayer& b, int md) { PaOperand o = pa_plain(p); o.mode = md; o.q = extra2; o.k0 = b.scale; o.k1 = b.shift; o.k2 = b.kA; return o; };
+    hipEvent_t e0, e1;
+    PA_CHECK(hipEventCreate(&e0)); PA_CHECK(hipEventCreate(&e1));
+    auto once = [&]() -> int {
+        if (mode == 0) {
+            PaConvArgs c; memset(&c, 0, sizeof c);
+            c.in = mk(op.xin, bn_in, (variant & 1) ? PA_LD_BNRELU : PA_LD_PLAIN); c.w = op.c.wf; c.bias = pbuf; c.out = op.yout;
+            c.add1 = (variant & 4) ? pa_plain(extra) : pa_none(); c.add2 = pa_none();
+            c.B = B; c.H = H; c.W = W; c.Cin = Cin; c.Cout = Cout; c.taps = k * k;
+            c.ep.mode = (variant & 2) ? PA_OUT_STATS : PA_OUT_PLAIN; c.ep.stats = bn_out.stats;
+            return pa_launch_conv(c, n.st);
+        } else if (mode == 1) {
+            PaConvArgs c; memset(&c, 0, sizeof c);
+            c.in = mk(op.yout, bn_in, (variant & 1) ? PA_LD_LIN2 : PA_LD_PLAIN); c.w = op.c.wb; c.out = op.xin;
+            c.add1 = (variant & 4) ? pa_plain(extra) : pa_none(); c.add2 = pa_none();
+            c.B = B; c.H = H; c.W = W; c.Cin = Cout; c.Cout = Cin; c.taps = k * k;
+            c.ep.mode = (variant & 2) ? PA_OUT_BWD : PA_OUT_PLAIN; c.ep.stats = bn_out.bstats; c.ep.xref = extra;
+            c.ep.scale = bn_out.scale; c.ep.shift = bn_out.shift; c.ep.mean = bn_out.mean; c.ep.invstd = bn_out.invstd;
+            return pa_launch_conv(c, n.st);
+        } else {
+            PaWgradArgs g; memset(&g, 0, sizeof g);
+            g.dy = mk(op.yout, bn_in, (variant & 1) ? PA_LD_LIN2 : PA_LD_PLAIN);
+            g.x = mk(op.xin, bn_out, (variant & 8) ? PA_LD_BNRELU : PA_LD_PLAIN);
+            g.part = op.c.part; g.dbpart = nullptr; g.B = B; g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout; g.taps = k * k; g.splits = op.c.splits;
+            return pa_launch_wgrad(g, n.st);
+        }
+    };
+    for (int i = 0; i < 3; ++i) TRY(once());
+    PA_CHECK(hipEventRecord(e0, n.st));
+    for (int i = 0; i < iters; ++i) TRY(once());
+    PA_CHECK(hipEventRecord(e1, n.st));
+    PA_CHECK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    PA_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    *ms_out = ms / iters;
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    return 0;
+}
+
 // ---------------------------------------------------------------------------- networks
 pa_net* pa_hg_create(int num_stacks, int num_classes, int chan, int B, int res) {
     g_err[0] = 0;
@@ -269,6 +328,38 @@ int pa_hg_accuracy(pa_net* net, int stack, const int32_t* idxs, int nidx, float*
     return 0;
 }
 
+
+// Evaluation.accuracy_origin_res (pylib/Evaluation.py:77-97) and per_person_pckh (:99-167) of stack i's
+// heat maps, straight from the engine's NHWC fp32 maps (no layout copy, no host sync)
+int pa_hg_pckh(pa_net* net, int stack, const float* center, const float* scale, const float* rot, const float* gt_pts,
+               const float* norm, const int32_t* idxs, int nidx, float* acc, float* person, float* scratch) {
+    g_err[0] = 0;
+    Net& n = net->n;
+    const int H = n.res / 4, J = 16, B = n.B;
+    float* pp = scratch;                          // [B][16][2] arg-max
+    float* fp = pp + (size_t)B * J * 2;           // [B][16][2] back-projected predictions
+    float* vis = fp + (size_t)B * J * 2;          // [B][16][2] arg-max of the augmented target
+    float* tgt = vis + (size_t)B * J * 2;         // [B][16][H][H] (only when person != NULL)
+    TRY(pa_launch_argmax(n.heat[stack], (long)H * H * 16, 1, 16, B, J, H, H, pp, nullptr, n.st));
+    TRY(pa_launch_final_preds(n.heat[stack], (long)H * H * 16, 1, 16, pp, center, scale, rot, B, J, H, H, fp, n.st));
+    if (person) {
+        TRY(pa_launch_gaussian_heatmap(n.pts_dev, tgt, B, J, H, H, n.st));
+        TRY(pa_launch_argmax(tgt, (long)J * H * H, (long)H * H, 1, B, J, H, H, vis, nullptr, n.st));
+    }
+    TRY(pa_launch_pck(fp, gt_pts, norm, 0.f, idxs, nidx, 0.5f, person ? vis : nullptr, B, J, acc, person, nullptr, n.st));
+    return 0;
+}
+
+// per-launch HIP-event timing of the MFMA kernels (bench.py roofline): enable, run steps, then report.
+// out[8][4] = {total ms, launches, algorithmic bytes, flops} per class: 0 fwd 1x1, 1 fwd 3x3, 2 dgrad 1x1,
+// 3 dgrad 3x3, 4 wgrad 1x1, 5 wgrad 3x3, 6 stem fwd, 7 stem wgrad.  Reporting synchronises and disables.
+int pa_net_profile_begin(pa_net* net) { net->n.prof.used = 0; net->n.prof.on = true; return 0; }
+int pa_net_profile_report(pa_net* net, double* out) {
+    net->n.prof.on = false;
+    int r = net->n.prof.report(out);
+    if (r) pa_set_error("profile report", (hipError_t)r, __FILE__, __LINE__);
+    return r;
+}
 
 // debug / test hook: copy an internal activation (BatchNorm+ReLU applied) or its gradient buffer out as
 // NCHW fp32.  which: "stem", "res1", "pool0", "res2", "res3", "hg<i>.skip<k>", "hg<i>.pool<k>",

@@ -49,12 +49,13 @@ enum { PA_OUT_PLAIN = 0, PA_OUT_STATS = 1, PA_OUT_BWD = 2 };
 
 struct PaEpilogue {
     int mode;
-    float* stats;          // [2][C] accumulators (atomicAdd), zeroed by the caller
+    float* stats;          // partial rows [grid.x][C][2]: every workgroup writes its own row (no atomics)
     const bf16* xref;      // BWD: raw conv output of the tensor this gradient belongs to
     const float* scale;    // BWD: s
     const float* shift;    // BWD: t
     const float* mean;     // BWD
     const float* invstd;   // BWD
+    int* rows_out;         // HOST pointer (ignored on the device): the launcher stores the number of partial rows here
 };
 
 __device__ __forceinline__ float bf2f(bf16 v) { return (float)v; }

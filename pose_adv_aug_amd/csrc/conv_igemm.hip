@@ -232,6 +232,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(PaConvArgs a) {
         }
     }
     if (a.ep.mode != PA_OUT_PLAIN) {
+        // per-workgroup partial row of the two per-channel reductions: no atomics (a float atomicAdd per
+        // channel per wave cost 6-10x the whole conv); the BatchNorm finalize kernel sums the rows.
+        float* red = reinterpret_cast<float*>(lds);          // [2 (wm)][BN][2]; the operand tiles are dead here
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
 #pragma unroll
@@ -240,11 +243,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(PaConvArgs a) {
 #pragma unroll
                 for (int o = 1; o < 16; o <<= 1) { x1 += __shfl_xor(x1, o, 64); x2 += __shfl_xor(x2, o, 64); }
                 if ((lane & 15) == 0) {
-                    const int n = n0 + wn * (BN / 2) + ni * 16 + (lane >> 4) * 4 + j;
-                    atomicAdd(a.ep.stats + n, x1);
-                    atomicAdd(a.ep.stats + N + n, x2);
+                    const int col = wn * (BN / 2) + ni * 16 + (lane >> 4) * 4 + j;
+                    red[(wm * BN + col) * 2] = x1;
+                    red[(wm * BN + col) * 2 + 1] = x2;
                 }
             }
+        }
+        __syncthreads();
+        for (int c = tid; c < BN; c += 256) {
+            f32x2 v = {red[c * 2] + red[(BN + c) * 2], red[c * 2 + 1] + red[(BN + c) * 2 + 1]};
+            *reinterpret_cast<f32x2*>(a.ep.stats + ((size_t)blockIdx.x * N + n0 + c) * 2) = v;
         }
     }
 }
@@ -264,18 +272,21 @@ static void launch_taps(const PaConvArgs& a, dim3 grid, hipStream_t st) {
     else launch_ld<BM, BN, 9>(a, grid, st);
 }
 
-int pa_launch_stem_conv(const PaConvArgs& a, hipStream_t st) {
+int pa_launch_stem_conv(const PaConvArgs& a, hipStream_t st, int* stat_rows) {
     // a.in.p = img4 [B][2H][2W][4]; a.w = [64][256]; a.Cin must be 256 (virtual), a.Cout 64
     if (a.Cin != 256 || a.Cout != 64 || a.in.mode != PA_LD_PLAIN) { pa_set_error_msg("pa_launch_stem_conv: bad arguments"); return 1; }
     const int M = a.B * a.H * a.W;
-    if (M >= 128 * 256)
+    const int bm = (M >= 128 * 256) ? 128 : 64;
+    if (stat_rows) *stat_rows = (M + bm - 1) / bm;
+    if (a.ep.rows_out) *a.ep.rows_out = (M + bm - 1) / bm;
+    if (bm == 128)
         hipLaunchKernelGGL((conv_igemm_kernel<128, 64, PA_LD_PLAIN, 1, true>), dim3((M + 127) / 128, 1), dim3(256), 0, st, a);
     else
         hipLaunchKernelGGL((conv_igemm_kernel<64, 64, PA_LD_PLAIN, 1, true>), dim3((M + 63) / 64, 1), dim3(256), 0, st, a);
     return (int)hipGetLastError();
 }
 
-int pa_launch_conv(const PaConvArgs& a, hipStream_t st) {
+int pa_launch_conv(const PaConvArgs& a, hipStream_t st, int* stat_rows) {
     if ((a.taps != 1 && a.taps != 9) || a.Cin % 64 != 0 || a.Cout % 64 != 0) {
         pa_set_error_msg("pa_launch_conv: channel counts must be multiples of 64 and taps 1 or 9");
         return 1;
@@ -284,6 +295,8 @@ int pa_launch_conv(const PaConvArgs& a, hipStream_t st) {
     // small problems get the 64-row tile so that the grid still covers the 256 CUs
     const bool bigM = M >= 128 * 256;
     const bool bigN = (a.Cout % 128 == 0);
+    if (stat_rows) *stat_rows = bigM ? (M + 127) / 128 : (M + 63) / 64;
+    if (a.ep.rows_out) *a.ep.rows_out = bigM ? (M + 127) / 128 : (M + 63) / 64;
     if (bigM && bigN) launch_taps<128, 128>(a, dim3((M + 127) / 128, a.Cout / 128), st);
     else if (bigM) launch_taps<128, 64>(a, dim3((M + 127) / 128, a.Cout / 64), st);
     else if (bigN && M >= 64 * 256) launch_taps<64, 128>(a, dim3((M + 63) / 64, a.Cout / 128), st);

@@ -9,13 +9,41 @@
 // ------------------------------------------------------------------------------------------------
 // BatchNorm bookkeeping (reference semantics: torch.nn.BatchNorm2d, eps 1e-5, momentum 0.1,
 // biased variance for normalisation, unbiased for the running estimate).
-__global__ void bn_finalize_kernel(const float* stats, const float* gamma, const float* beta, float* rmean, float* rvar,
-                                   float* scale, float* shift, float* mean, float* invstd, int C, float count,
-                                   float momentum, float eps, int update_running) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
+// Sum `rows` partial rows [rows][C][2] for the 32 channels of this workgroup: 1024 threads =
+// 32 channels x 32 row slices, float2 loads, LDS tree over the slices.  Result in LDS sums[32][2].
+__device__ __forceinline__ void reduce_partial_rows(const float* part, int rows, int C, int c0, float (*sums)[2]) {
+    __shared__ float red[32][33][2];
+    const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    float a = 0.f, b = 0.f;
+    if (c0 + cl < C) {
+        for (int r = sl; r < rows; r += 32) {
+            f32x2 v = *reinterpret_cast<const f32x2*>(part + ((size_t)r * C + c0 + cl) * 2);
+            a += v[0]; b += v[1];
+        }
+    }
+    red[sl][cl][0] = a; red[sl][cl][1] = b;
+    __syncthreads();
+    if (sl == 0) {
+        float x = 0.f, y = 0.f;
+#pragma unroll 8
+        for (int s = 0; s < 32; ++s) { x += red[s][cl][0]; y += red[s][cl][1]; }
+        sums[cl][0] = x; sums[cl][1] = y;
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* stats, int rows, const float* gamma, const float* beta,
+                                                           float* rmean, float* rvar, float* scale, float* shift, float* mean,
+                                                           float* invstd, int C, float count, float momentum, float eps,
+                                                           int update_running) {
+    __shared__ float sums[32][2];
+    const int c0 = blockIdx.x * 32;
+    reduce_partial_rows(stats, rows, C, c0, sums);
+    if (threadIdx.x >= 32) return;
+    const int c = c0 + threadIdx.x;
     if (c >= C) return;
-    float mu = stats[c] / count;
-    float var = fmaxf(stats[C + c] / count - mu * mu, 0.f);
+    float mu = sums[threadIdx.x][0] / count;
+    float var = fmaxf(sums[threadIdx.x][1] / count - mu * mu, 0.f);
     float is = rsqrtf(var + eps);
     float s = gamma[c] * is;
     scale[c] = s;
@@ -29,10 +57,10 @@ __global__ void bn_finalize_kernel(const float* stats, const float* gamma, const
     }
 }
 
-int pa_launch_bn_finalize(const float* stats, const float* gamma, const float* beta, float* rmean, float* rvar,
+int pa_launch_bn_finalize(const float* stats, int rows, const float* gamma, const float* beta, float* rmean, float* rvar,
                           float* scale, float* shift, float* mean, float* invstd, int C, float count,
                           float momentum, float eps, int update_running, hipStream_t st) {
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, st, stats, gamma, beta, rmean, rvar, scale,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 31) / 32), dim3(1024), 0, st, stats, rows, gamma, beta, rmean, rvar, scale,
                        shift, mean, invstd, C, count, momentum, eps, update_running);
     return (int)hipGetLastError();
 }
@@ -53,11 +81,16 @@ int pa_launch_bn_eval(const PaBnEvalJob* jobs_dev, int njobs, float eps, hipStre
 }
 
 // dx = s*(dz - S1/M - xhat*S2/M) = kA*dz + kB*x + kC    (per channel)
-__global__ void bn_bwd_finalize_kernel(const float* bstats, const float* scale, const float* mean, const float* invstd,
-                                       float* kA, float* kB, float* kC, float* dgamma, float* dbeta, int C, float count) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* bstats, int rows, const float* scale, const float* mean,
+                                                               const float* invstd, float* kA, float* kB, float* kC,
+                                                               float* dgamma, float* dbeta, int C, float count) {
+    __shared__ float sums[32][2];
+    const int c0 = blockIdx.x * 32;
+    reduce_partial_rows(bstats, rows, C, c0, sums);
+    if (threadIdx.x >= 32) return;
+    const int c = c0 + threadIdx.x;
     if (c >= C) return;
-    float S1 = bstats[c], S2 = bstats[C + c];
+    float S1 = sums[threadIdx.x][0], S2 = sums[threadIdx.x][1];
     float s = scale[c], is = invstd[c], mu = mean[c];
     kA[c] = s;
     float b = -s * is * S2 / count;
@@ -67,10 +100,10 @@ __global__ void bn_bwd_finalize_kernel(const float* bstats, const float* scale, 
     if (dbeta) dbeta[c] = S1;
 }
 
-int pa_launch_bn_bwd_finalize(const float* bstats, const float* scale, const float* mean, const float* invstd,
+int pa_launch_bn_bwd_finalize(const float* bstats, int rows, const float* scale, const float* mean, const float* invstd,
                               float* kA, float* kB, float* kC, float* dgamma, float* dbeta, int C, float count,
                               hipStream_t st) {
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, st, bstats, scale, mean, invstd, kA, kB,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 31) / 32), dim3(1024), 0, st, bstats, rows, scale, mean, invstd, kA, kB,
                        kC, dgamma, dbeta, C, count);
     return (int)hipGetLastError();
 }
@@ -114,7 +147,8 @@ __device__ __forceinline__ bf16x8 epilogue8(const PaEpilogue& ep, size_t idx, in
     return o;
 }
 
-// block-level flush of per-thread channel partials: LDS float atomics, then one global atomic per channel
+// block-level flush of per-thread channel partials: LDS float atomics, then this workgroup's own
+// partial row gstats[blockIdx.x][C][2] (plain stores; the BatchNorm finalize kernels sum the rows)
 __device__ __forceinline__ void flush_stats(float* red /* [2*C] LDS, zeroed */, float* gstats, int C, int c,
                                             const float (&s1)[8], const float (&s2)[8], bool active) {
     if (active) {
@@ -122,7 +156,11 @@ __device__ __forceinline__ void flush_stats(float* red /* [2*C] LDS, zeroed */, 
         for (int j = 0; j < 8; ++j) { atomicAdd(red + c + j, s1[j]); atomicAdd(red + C + c + j, s2[j]); }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) atomicAdd(gstats + i, red[i]);
+    float* row = gstats + (size_t)blockIdx.x * C * 2;
+    for (int i = threadIdx.x; i < C; i += blockDim.x) {
+        f32x2 v = {red[i], red[C + i]};
+        *reinterpret_cast<f32x2*>(row + i * 2) = v;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -212,11 +250,13 @@ __global__ void maxpool_bwd_kernel(const bf16* dout, PaOperand in, PaOperand add
 }
 
 int pa_launch_maxpool_bwd(const bf16* dout, const PaOperand& in, const PaOperand& add, const PaEpilogue& ep, bf16* din,
-                          int B, int H, int W, int C, hipStream_t st) {
+                          int B, int H, int W, int C, hipStream_t st, int* stat_rows) {
     size_t total = (size_t)B * (H / 2) * (W / 2) * (C / 8);
     int blocks = (int)((total + 255) / 256);
-    if (blocks > 2048) blocks = 2048;
+    if (blocks > 512) blocks = 512;          // one partial-statistics row per workgroup
     if (blocks < 1) blocks = 1;
+    if (stat_rows) *stat_rows = blocks;
+    if (ep.rows_out) *ep.rows_out = blocks;
     hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(blocks), dim3(256), 2 * C * sizeof(float), st, dout, in, add, ep, din, B, H, W, C);
     return (int)hipGetLastError();
 }
@@ -293,18 +333,27 @@ __global__ void upadd_bwd_kernel(const bf16* dout, PaEpilogue epl, bf16* dlow, P
         for (int j = 0; j < 8; ++j) { atomicAdd(red + 2 * C + c + j, k1[j]); atomicAdd(red + 3 * C + c + j, k2[j]); }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) {
-        if (epl.mode != PA_OUT_PLAIN) atomicAdd(epl.stats + i, red[i]);
-        if (eps.mode != PA_OUT_PLAIN) atomicAdd(eps.stats + i, red[2 * C + i]);
+    for (int i = threadIdx.x; i < C; i += blockDim.x) {
+        if (epl.mode != PA_OUT_PLAIN) {
+            f32x2 v = {red[i], red[C + i]};
+            *reinterpret_cast<f32x2*>(epl.stats + ((size_t)blockIdx.x * C + i) * 2) = v;
+        }
+        if (eps.mode != PA_OUT_PLAIN) {
+            f32x2 v = {red[2 * C + i], red[3 * C + i]};
+            *reinterpret_cast<f32x2*>(eps.stats + ((size_t)blockIdx.x * C + i) * 2) = v;
+        }
     }
 }
 
 int pa_launch_upadd_bwd(const bf16* dout, const PaEpilogue& ep_low, bf16* dlow, const PaEpilogue& ep_skip, bf16* dskip,
-                        int B, int H, int W, int C, hipStream_t st) {
+                        int B, int H, int W, int C, hipStream_t st, int* stat_rows) {
     size_t total = (size_t)B * (H / 2) * (W / 2) * (C / 8);
     int blocks = (int)((total + 255) / 256);
-    if (blocks > 2048) blocks = 2048;
+    if (blocks > 512) blocks = 512;
     if (blocks < 1) blocks = 1;
+    if (stat_rows) *stat_rows = blocks;
+    if (ep_low.rows_out) *ep_low.rows_out = blocks;
+    if (ep_skip.rows_out) *ep_skip.rows_out = blocks;
     hipLaunchKernelGGL(upadd_bwd_kernel, dim3(blocks), dim3(256), 4 * C * sizeof(float), st, dout, ep_low, dlow, ep_skip, dskip,
                        B, H, W, C);
     return (int)hipGetLastError();
@@ -496,11 +545,13 @@ __global__ void ep_apply_kernel(PaOperand g, PaEpilogue ep, bf16* out, size_t M,
     if (ep.mode != PA_OUT_PLAIN) flush_stats(red, ep.stats, C, c, s1, s2, true);
 }
 
-int pa_launch_ep_apply(const PaOperand& g, const PaEpilogue& ep, bf16* out, size_t M, int C, hipStream_t st) {
+int pa_launch_ep_apply(const PaOperand& g, const PaEpilogue& ep, bf16* out, size_t M, int C, hipStream_t st, int* stat_rows) {
     size_t total = M * (C / 8);
     int blocks = (int)((total + 255) / 256);
-    if (blocks > 2048) blocks = 2048;
+    if (blocks > 512) blocks = 512;
     if (blocks < 1) blocks = 1;
+    if (stat_rows) *stat_rows = blocks;
+    if (ep.rows_out) *ep.rows_out = blocks;
     hipLaunchKernelGGL(ep_apply_kernel, dim3(blocks), dim3(256), 2 * C * sizeof(float), st, g, ep, out, M, C);
     return (int)hipGetLastError();
 }

@@ -12,7 +12,10 @@ struct PaConvArgs {
     bf16* out;           // [M][Cout]
     int B, H, W, Cin, Cout, taps;
 };
-int pa_launch_conv(const PaConvArgs& a, hipStream_t st);
+// stat_rows (optional) receives the number of partial-statistics rows the launch writes (= grid.x)
+int pa_launch_conv(const PaConvArgs& a, hipStream_t st, int* stat_rows = nullptr);
+// upper bound of stat rows any conv / elementwise launch writes for a tensor with M pixels
+inline int pa_max_stat_rows(int M) { int r = (M + 63) / 64; return r < 512 ? 512 : r; }
 
 // Weight gradient: dw[n][tap][c] = sum_m dy(m)[n] * x(pixel(m)+tap)[c], split over m into `splits`
 // deterministic partial slabs part[split][Cout][taps*Cin] (fp32); optional bias-gradient partials
@@ -36,15 +39,16 @@ struct PaWgradReduceJob {
 int pa_launch_wgrad_reduce(const PaWgradReduceJob* jobs_dev, int njobs, int max_elems, hipStream_t st);
 
 // ---- BatchNorm bookkeeping
-// forward: stats[2][C] (sum, sumsq over `count` values) -> scale/shift/mean/invstd, running stats update
-int pa_launch_bn_finalize(const float* stats, const float* gamma, const float* beta, float* rmean, float* rvar,
+// forward: partial rows stats[rows][C][2] (sum, sumsq; over `count` values in total) -> scale/shift/mean/invstd,
+// running stats update
+int pa_launch_bn_finalize(const float* stats, int rows, const float* gamma, const float* beta, float* rmean, float* rvar,
                           float* scale, float* shift, float* mean, float* invstd, int C, float count,
                           float momentum, float eps, int update_running, hipStream_t st);
 // eval: scale/shift from running stats, for `n` BatchNorms described by a device table
 struct PaBnEvalJob { const float* gamma; const float* beta; const float* rmean; const float* rvar; float* scale; float* shift; int C; };
 int pa_launch_bn_eval(const PaBnEvalJob* jobs_dev, int njobs, float eps, hipStream_t st);
-// backward: bstats[2][C] (sum dz, sum dz*xhat) -> LIN2 coefficients (A,B,C), dgamma, dbeta
-int pa_launch_bn_bwd_finalize(const float* bstats, const float* scale, const float* mean, const float* invstd,
+// backward: partial rows bstats[rows][C][2] (sum dz, sum dz*xhat) -> LIN2 coefficients (A,B,C), dgamma, dbeta
+int pa_launch_bn_bwd_finalize(const float* bstats, int rows, const float* scale, const float* mean, const float* invstd,
                               float* kA, float* kB, float* kC, float* dgamma, float* dbeta, int C, float count,
                               hipStream_t st);
 
@@ -52,15 +56,15 @@ int pa_launch_bn_bwd_finalize(const float* bstats, const float* scale, const flo
 int pa_launch_maxpool_fwd(const PaOperand& in, bf16* out, int B, int H, int W, int C, hipStream_t st);
 // grad of 2x2 max pool routed to the arg-max (first max in scan order), + optional addend, then epilogue
 int pa_launch_maxpool_bwd(const bf16* dout, const PaOperand& in, const PaOperand& add, const PaEpilogue& ep, bf16* din,
-                          int B, int H, int W, int C, hipStream_t st);
+                          int B, int H, int W, int C, hipStream_t st, int* stat_rows = nullptr);
 // out = nearest_up2(low) + skip        (low: [B][H/2][W/2][C], skip/out: [B][H][W][C])
 int pa_launch_upadd_fwd(const PaOperand& low, const PaOperand& skip, bf16* out, int B, int H, int W, int C, hipStream_t st);
 int pa_launch_upadd_bwd(const bf16* dout, const PaEpilogue& ep_low, bf16* dlow, const PaEpilogue& ep_skip, bf16* dskip,
-                        int B, int H, int W, int C, hipStream_t st);
+                        int B, int H, int W, int C, hipStream_t st, int* stat_rows = nullptr);
 
 // ---- stem 7x7 stride-2 conv as a K=256 GEMM over the 4-channel-padded NHWC bf16 image
 // (in.p / x.p = img4 [B][2H][2W][4], Cin = 256 virtual patch length, Cout = 64, H/W = OUTPUT dims)
-int pa_launch_stem_conv(const PaConvArgs& a, hipStream_t st);
+int pa_launch_stem_conv(const PaConvArgs& a, hipStream_t st, int* stat_rows = nullptr);
 int pa_launch_stem_wgrad(const PaWgradArgs& a, hipStream_t st);
 // reduce the stem's partial slabs [splits][64][256] into PyTorch layout dst[64][3][7][7]
 int pa_launch_stem_wgrad_reduce(const float* part, int splits, float* dst, hipStream_t st);
@@ -76,5 +80,5 @@ int pa_launch_nhwc_to_nchw_f32(const float* src, float* dst, int B, int H, int W
 int pa_launch_nchw_f32_to_nhwc_bf16(const float* src, bf16* dst, int B, int C, int H, int W, hipStream_t st);
 int pa_launch_nhwc_bf16_to_nchw_f32(const PaOperand& src, float* dst, int B, int C, int H, int W, hipStream_t st);
 
-int pa_launch_ep_apply(const PaOperand& g, const PaEpilogue& ep, bf16* out, size_t M, int C, hipStream_t st);
+int pa_launch_ep_apply(const PaOperand& g, const PaEpilogue& ep, bf16* out, size_t M, int C, hipStream_t st, int* stat_rows = nullptr);
 int pa_launch_fill(float* p, float v, size_t n, hipStream_t st);

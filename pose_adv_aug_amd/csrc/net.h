@@ -33,7 +33,8 @@ struct TensorInfo {          // one state_dict entry
 struct BNLayer {
     int C = 0;
     size_t p_gamma = 0, p_beta = 0, b_rmean = 0, b_rvar = 0;
-    float *stats = nullptr, *bstats = nullptr;                 // [2C] each, zeroed at the start of a step
+    float *stats = nullptr, *bstats = nullptr;                 // partial rows [rows][C][2] (forward stats / backward reductions)
+    int stat_rows = 0, bstat_rows = 0, max_rows = 0;
     float *scale = nullptr, *shift = nullptr, *mean = nullptr, *invstd = nullptr;
     float *kA = nullptr, *kB = nullptr, *kC = nullptr;
 };
@@ -59,6 +60,19 @@ struct Act {                 // NHWC bf16 activation; `bn` != null means BatchNo
 };
 
 struct Net;
+
+// optional per-launch timing of the MFMA kernels with HIP events (bench.py's roofline object)
+enum { PA_PROF_FWD1 = 0, PA_PROF_FWD3, PA_PROF_DGRAD1, PA_PROF_DGRAD3, PA_PROF_WGRAD1, PA_PROF_WGRAD3, PA_PROF_STEM_FWD,
+       PA_PROF_STEM_WGRAD, PA_PROF_NCLS };
+struct ProfEntry { hipEvent_t e0, e1; int cls; double bytes, flops; };
+struct Prof {
+    bool on = false;
+    std::vector<ProfEntry> entries;
+    size_t used = 0;
+    ProfEntry* begin(int cls, double bytes, double flops, hipStream_t st);
+    void end(ProfEntry* e, hipStream_t st);
+    int report(double* out /* [PA_PROF_NCLS][4] = total ms, launches, algorithmic bytes, flops */);
+};
 
 struct Residual {
     ConvLayer c1, c2, c3, ad;
@@ -108,6 +122,7 @@ struct Net {
     PaBnEvalJob* bneval_jobs = nullptr; int n_bneval = 0;
     // run state
     hipStream_t st = nullptr;
+    Prof prof;
     bool train_bn = true;
     float momentum = 0.1f, eps = 1e-5f;
 
@@ -131,7 +146,7 @@ struct Net {
     void declare_conv(ConvLayer& c, const std::string& name, int cin, int cout, int k, bool bn_after);
     void declare_bn(BNLayer& b, const std::string& name, int C);
     void layout_conv(ConvLayer& c, Arena& a, int M);
-    void layout_bn(BNLayer& b, Arena& a);
+    void layout_bn(BNLayer& b, Arena& a, int M);
     Act new_act(Arena& a, int B, int H, int W, int C, BNLayer* bn, bool need_grad);
 
     void declare_pose();

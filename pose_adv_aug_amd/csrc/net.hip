@@ -107,7 +107,10 @@ void Net::layout_conv(ConvLayer& c, Arena& a, int M) {
     c.dbpart = c.has_bn_after ? nullptr : a.get<float>((size_t)c.splits * c.pcout);
 }
 
-void Net::layout_bn(BNLayer& b, Arena& a) {
+void Net::layout_bn(BNLayer& b, Arena& a, int M) {
+    b.max_rows = pa_max_stat_rows(M);
+    b.stats = a.get<float>((size_t)b.max_rows * b.C * 2);
+    b.bstats = a.get<float>((size_t)b.max_rows * b.C * 2);
     b.scale = a.get<float>(b.C); b.shift = a.get<float>(b.C); b.mean = a.get<float>(b.C); b.invstd = a.get<float>(b.C);
     b.kA = a.get<float>(b.C); b.kB = a.get<float>(b.C); b.kC = a.get<float>(b.C);
 }
@@ -122,7 +125,7 @@ Act Net::new_act(Arena& a, int B_, int H, int W, int C, BNLayer* bn, bool need_g
 void Residual::layout(Net& n, Arena& a, int B, int H, int W, bool need_grad) {
     const int M = B * H * W, mid = cout / 2;
     n.layout_conv(c1, a, M); n.layout_conv(c2, a, M); n.layout_conv(c3, a, M);
-    n.layout_bn(b1, a); n.layout_bn(b2, a); n.layout_bn(b3, a);
+    n.layout_bn(b1, a, M); n.layout_bn(b2, a, M); n.layout_bn(b3, a, M);
     x1 = n.new_act(a, B, H, W, mid, &b1, need_grad);
     x2 = n.new_act(a, B, H, W, mid, &b2, need_grad);
     x3 = n.new_act(a, B, H, W, cout, &b3, need_grad);
@@ -152,7 +155,6 @@ size_t Net::layout_all(char* base) {
     Arena a; a.base = base;
     // region zeroed at the start of every step: BatchNorm statistic accumulators + per-stack loss
     size_t zero_begin = a.off;
-    for (BNLayer* b : bns) { b->stats = a.get<float>(2 * b->C); b->bstats = a.get<float>(2 * b->C); }
     loss_dev = a.get<float>(64);
     a.take(0);
     stats_arena = base ? reinterpret_cast<float*>(base + zero_begin) : nullptr;
@@ -166,7 +168,7 @@ size_t Net::layout_all(char* base) {
     img4 = a.get<bf16>((size_t)B * res * res * 4);
     pts_dev = a.get<double>((size_t)B * classes * 2);
     layout_conv(stem_conv, a, B * H2 * H2);
-    layout_bn(stem_bn, a);
+    layout_bn(stem_bn, a, B * H2 * H2);
     a0 = new_act(a, B, H2, H2, 64, &stem_bn, true);
     res1.layout(*this, a, B, H2, H2, true);
     pool0 = new_act(a, B, H4, H4, 128, nullptr, true);
@@ -178,7 +180,7 @@ size_t Net::layout_all(char* base) {
     for (int i = 0; i < stacks; ++i) {
         hg[i].layout(*this, a, B, H4, H4, true);
         post[i].layout(*this, a, B, H4, H4, true);
-        layout_conv(lin[i], a, M); layout_bn(lin_bn[i], a);
+        layout_conv(lin[i], a, M); layout_bn(lin_bn[i], a, M);
         lin_out[i] = new_act(a, B, H4, H4, chan, &lin_bn[i], true);
         layout_conv(outc[i], a, M);
         heat[i] = a.get<float>((size_t)M * 16);
@@ -227,6 +229,45 @@ int Net::upload_tables() {
 }
 
 // ------------------------------------------------------------------------------------------------
+// per-launch HIP-event timing (off unless bench.py asks for it)
+ProfEntry* Prof::begin(int cls, double bytes, double flops, hipStream_t st) {
+    if (!on) return nullptr;
+    if (used == entries.size()) {
+        ProfEntry e; e.cls = 0; e.bytes = e.flops = 0;
+        if (hipEventCreate(&e.e0) != hipSuccess || hipEventCreate(&e.e1) != hipSuccess) return nullptr;
+        entries.push_back(e);
+    }
+    ProfEntry* e = &entries[used++];
+    e->cls = cls; e->bytes = bytes; e->flops = flops;
+    hipEventRecord(e->e0, st);
+    return e;
+}
+
+void Prof::end(ProfEntry* e, hipStream_t st) { if (e) hipEventRecord(e->e1, st); }
+
+int Prof::report(double* out) {
+    for (int i = 0; i < PA_PROF_NCLS * 4; ++i) out[i] = 0.0;
+    for (size_t i = 0; i < used; ++i) {
+        ProfEntry& e = entries[i];
+        hipError_t r = hipEventSynchronize(e.e1);
+        if (r != hipSuccess) return (int)r;
+        float ms = 0.f;
+        r = hipEventElapsedTime(&ms, e.e0, e.e1);
+        if (r != hipSuccess) return (int)r;
+        out[e.cls * 4 + 0] += (double)ms; out[e.cls * 4 + 1] += 1.0; out[e.cls * 4 + 2] += e.bytes; out[e.cls * 4 + 3] += e.flops;
+    }
+    used = 0;
+    return 0;
+}
+
+// algorithmic work of one conv launch: every activation element read once / written once (2-byte
+// elements), weights once; 2*M*N*K flops
+static void conv_work(int M, int cin, int cout, int taps, bool wgrad, double& bytes, double& flops) {
+    bytes = 2.0 * M * ((double)cin + cout) + (wgrad ? 4.0 : 2.0) * (double)cout * taps * cin;
+    flops = 2.0 * M * (double)cout * taps * cin;
+}
+
+// ------------------------------------------------------------------------------------------------
 // runtime helpers
 PaOperand Net::op(const Act& a) const {
     PaOperand o = pa_plain(a.raw);
@@ -243,7 +284,7 @@ PaOperand Net::gradop(const Act& a) const {
 PaEpilogue Net::final_ep(const Act& a) const {
     PaEpilogue e = ep_plain();
     if (a.bn) {
-        e.mode = PA_OUT_BWD; e.stats = a.bn->bstats; e.xref = a.raw; e.scale = a.bn->scale; e.shift = a.bn->shift;
+        e.mode = PA_OUT_BWD; e.stats = a.bn->bstats; e.rows_out = &a.bn->bstat_rows; e.xref = a.raw; e.scale = a.bn->scale; e.shift = a.bn->shift;
         e.mean = a.bn->mean; e.invstd = a.bn->invstd;
     }
     return e;
@@ -252,7 +293,7 @@ PaEpilogue Net::final_ep(const Act& a) const {
 int Net::finish_grad(const Act& a) {
     if (!a.bn) return 0;
     BNLayer* b = a.bn;
-    return pa_launch_bn_bwd_finalize(b->bstats, b->scale, b->mean, b->invstd, b->kA, b->kB, b->kC, grads + b->p_gamma,
+    return pa_launch_bn_bwd_finalize(b->bstats, b->bstat_rows, b->scale, b->mean, b->invstd, b->kA, b->kB, b->kC, grads + b->p_gamma,
                                      grads + b->p_beta, b->C, (float)a.M(), st);
 }
 
@@ -262,11 +303,15 @@ int Net::conv_fwd(ConvLayer& c, const PaOperand& in, int B_, int H, int W, const
     a.in = in; a.w = c.wf; a.bias = params + c.p_b; a.add1 = add1; a.add2 = add2; a.out = out;
     a.B = B_; a.H = H; a.W = W; a.Cin = c.pcin; a.Cout = c.pcout; a.taps = c.k == 7 ? 1 : c.taps();
     a.ep = ep_plain();
-    if (bn_after && train_bn) { a.ep.mode = PA_OUT_STATS; a.ep.stats = bn_after->stats; }
-    if (c.k == 7) TRY(pa_launch_stem_conv(a, st));
-    else TRY(pa_launch_conv(a, st));
+    if (bn_after && train_bn) { a.ep.mode = PA_OUT_STATS; a.ep.stats = bn_after->stats; a.ep.rows_out = &bn_after->stat_rows; }
+    double wb, wf; conv_work(B_ * H * W, c.k == 7 ? 147 : c.Cin, c.Cout, c.k == 7 ? 1 : c.taps(), false, wb, wf);
+    if (c.k == 7) wb = 2.0 * B_ * (4.0 * H * W * 4 + (double)H * W * 64) + 2.0 * 64 * 147;      // image read once (4-ch padded) + output
+    ProfEntry* pe = prof.begin(c.k == 7 ? PA_PROF_STEM_FWD : (c.k == 3 ? PA_PROF_FWD3 : PA_PROF_FWD1), wb, wf, st);
+    int rc = (c.k == 7) ? pa_launch_stem_conv(a, st) : pa_launch_conv(a, st);
+    prof.end(pe, st);
+    TRY(rc);
     if (bn_after && train_bn)
-        TRY(pa_launch_bn_finalize(bn_after->stats, params + bn_after->p_gamma, params + bn_after->p_beta,
+        TRY(pa_launch_bn_finalize(bn_after->stats, bn_after->stat_rows, params + bn_after->p_gamma, params + bn_after->p_beta,
                                   buffers + bn_after->b_rmean, buffers + bn_after->b_rvar, bn_after->scale, bn_after->shift,
                                   bn_after->mean, bn_after->invstd, bn_after->C, (float)(B_ * H * W), momentum, eps, 1, st));
     return 0;
@@ -277,15 +322,23 @@ int Net::conv_dgrad(ConvLayer& c, const PaOperand& dy, int B_, int H, int W, con
     PaConvArgs a; memset(&a, 0, sizeof a);
     a.in = dy; a.w = c.wb; a.bias = nullptr; a.add1 = add1; a.add2 = add2; a.out = out; a.ep = ep;
     a.B = B_; a.H = H; a.W = W; a.Cin = c.pcout; a.Cout = c.pcin; a.taps = c.taps();
-    return pa_launch_conv(a, st);
+    double wb, wf; conv_work(B_ * H * W, c.Cin, c.Cout, c.taps(), false, wb, wf);
+    ProfEntry* pe = prof.begin(c.k == 3 ? PA_PROF_DGRAD3 : PA_PROF_DGRAD1, wb, wf, st);
+    int rc = pa_launch_conv(a, st);
+    prof.end(pe, st);
+    return rc;
 }
 
 int Net::conv_wgrad(ConvLayer& c, const PaOperand& dy, const PaOperand& x, int B_, int H, int W) {
     PaWgradArgs a; memset(&a, 0, sizeof a);
     a.dy = dy; a.x = x; a.part = c.part; a.dbpart = c.dbpart;
     a.B = B_; a.H = H; a.W = W; a.Cin = c.pcin; a.Cout = c.pcout; a.taps = c.k == 7 ? 1 : c.taps(); a.splits = c.splits;
-    if (c.k == 7) return pa_launch_stem_wgrad(a, st);
-    return pa_launch_wgrad(a, st);
+    double wb, wf; conv_work(B_ * H * W, c.k == 7 ? 147 : c.Cin, c.Cout, c.k == 7 ? 1 : c.taps(), true, wb, wf);
+    if (c.k == 7) wb = 2.0 * B_ * (4.0 * H * W * 4 + (double)H * W * 64) + 4.0 * 64 * 147;
+    ProfEntry* pe = prof.begin(c.k == 7 ? PA_PROF_STEM_WGRAD : (c.k == 3 ? PA_PROF_WGRAD3 : PA_PROF_WGRAD1), wb, wf, st);
+    int rc = (c.k == 7) ? pa_launch_stem_wgrad(a, st) : pa_launch_wgrad(a, st);
+    prof.end(pe, st);
+    return rc;
 }
 
 // ------------------------------------------------------------------------------------------------

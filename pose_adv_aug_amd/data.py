@@ -1,0 +1,84 @@
+"""On-device augmentation front end: replaces the reference's DataLoader workers
+(data/mpii_for_mpii.py, data/joint_train_pose.py, data/joint_train_s_r_agent.py) for frames that are
+already resident in HBM.  Everything below runs as HIP kernels; the host only sequences them.
+
+A `DeviceBatch` holds MPII-shape annotations for B people:
+  frames  uint8  [B][Hs][Ws][3]   source images
+  meta    fp32   [B][4]           objpos_x, objpos_y, scale (already MPII-normalised: c.y += 15 s; s *= 1.25,
+                                  data/mpii_for_mpii.py:101-104), frame width
+  joints  fp32   [B][16][2]       joint_self in image pixels (<= 0 means not annotated)
+  normalizer fp32 [B]             0.6 * head size
+"""
+import torch
+
+from ._lib import lib, check, ptr, stream, require_gpu
+from .pylib import HumanAug
+
+
+class DeviceBatch(object):
+    def __init__(self, frames, objpos, scale, joints, normalizer):
+        require_gpu()
+        dev = torch.device('cuda', torch.cuda.current_device())
+        self.frames = frames.to(dev).contiguous()
+        B, Hs, Ws, _ = self.frames.shape
+        self.B, self.Hs, self.Ws = B, Hs, Ws
+        meta = torch.zeros(B, 4, dtype=torch.float32)
+        meta[:, 0:2] = torch.as_tensor(objpos, dtype=torch.float32)
+        meta[:, 2] = torch.as_tensor(scale, dtype=torch.float32).reshape(-1)
+        meta[:, 3] = float(Ws)
+        self.meta = meta.to(dev)
+        self.joints = torch.as_tensor(joints, dtype=torch.float32).to(dev).contiguous()
+        self.normalizer = torch.as_tensor(normalizer, dtype=torch.float32).to(dev).contiguous()
+        self.params = torch.zeros(B, 8, dtype=torch.float64, device=dev)
+
+    @staticmethod
+    def synthetic(B, seed=0, Hs=720, Ws=1280):
+        """MPII-shape synthetic people."""
+        g = torch.Generator().manual_seed(seed)
+        frames = torch.randint(0, 256, (B, Hs, Ws, 3), generator=g, dtype=torch.uint8)
+        objpos = torch.stack([Ws / 2 + (torch.rand(B, generator=g) * 200 - 100), Hs / 2 + (torch.rand(B, generator=g) * 200 - 100)], 1)
+        sp = 1.5 + 2.0 * torch.rand(B, generator=g)
+        objpos[:, 1] += 15 * sp
+        scale = sp * 1.25
+        joints = objpos[:, None, :] + torch.randn(B, 16, 2, generator=g) * (60 * sp)[:, None, None]
+        joints[..., 0].clamp_(1, Ws - 1); joints[..., 1].clamp_(1, Hs - 1)
+        joints[torch.rand(B, 16, generator=g) < 0.1] = 0
+        normalizer = (40 + 80 * torch.rand(B, generator=g)) * 0.6
+        return DeviceBatch(frames, objpos, scale, joints, normalizer)
+
+
+class Augmenter(object):
+    """Draw augmentation parameters by the reference's laws and produce the network input + targets."""
+
+    def __init__(self, seed=0, inp_res=256, out_res=64):
+        self.seed, self.inp_res, self.out_res = int(seed), inp_res, out_res
+        self.step = 0
+
+    def _finish(self, batch, want_nchw=False):
+        t_out, tinv = HumanAug.affine_params(batch.params, self.inp_res, self.out_res)
+        img4, imgf = HumanAug.warp_batch(batch.frames, tinv, batch.params, res=self.inp_res, want_nchw=want_nchw)
+        pts_heat, pts_img = HumanAug.transform_pts_batch(batch.joints, batch.params, t_out, batch.Ws)
+        return {'img4': img4, 'img': imgf, 'pts': pts_heat, 'grnd_pts': pts_img,
+                'c': batch.params[:, 0:2].float().contiguous(), 's': batch.params[:, 2].float().contiguous(),
+                'r': batch.params[:, 3].float().contiguous(), 'normalizer': batch.normalizer}
+
+    def regular(self, batch, want_nchw=False):
+        """data/mpii_for_mpii.py:119-135."""
+        check(lib().pa_sample_aug(ptr(batch.meta), None, None, 0, self.seed, self.step, batch.B, ptr(batch.params), stream()))
+        self.step += 1
+        return self._finish(batch, want_nchw)
+
+    def agent(self, batch, scale_idx, rot_idx, mode=1, want_nchw=False):
+        """data/joint_train_s_r_agent.py:134-177: mode 1 = both bins (+flip, colour), 2 = scale only, 3 = rotation only."""
+        check(lib().pa_sample_aug(ptr(batch.meta), ptr(scale_idx), ptr(rot_idx), mode, self.seed, self.step, batch.B,
+                                  ptr(batch.params), stream()))
+        self.step += 1
+        return self._finish(batch, want_nchw)
+
+    def standard(self, batch, want_nchw=False):
+        """un-augmented crop (inp_std, data/joint_train_s_r_agent.py:160): scale as annotated, no rotation / flip / jitter."""
+        p = batch.params
+        p.zero_()
+        p[:, 0:3] = batch.meta[:, 0:3].double()
+        p[:, 5:8] = 1.0
+        return self._finish(batch, want_nchw)

@@ -264,6 +264,27 @@ class HourglassNet(_HipModule):
         return acc
 
 
+    def pckh_origin_res(self, center, scale, rot, grnd_pts, normalizers, stack=-1, per_person=False):
+        """Evaluation.accuracy_origin_res (pylib/Evaluation.py:77-97) -- and per_person_pckh (:99-167) when
+        per_person -- of the last forward's heat maps, on the device.  Returns (acc[15], person[B] or None)."""
+        from ..pylib.Evaluation import PCKH_JOINTS
+        B = self._last_B
+        h = self._net(B)
+        stack = stack % self.num_stacks
+        Hh = self.res // 4
+        dev = self.flat_params.device
+        if not hasattr(self, '_pckh_idx'):
+            self._pckh_idx = torch.as_tensor(PCKH_JOINTS, dtype=torch.int32, device=dev)
+        scratch = torch.empty(6 * B * 16 + (B * 16 * Hh * Hh if per_person else 0) + 16, dtype=torch.float32, device=dev)
+        acc = torch.zeros(len(PCKH_JOINTS) + 1, dtype=torch.float32, device=dev)
+        person = torch.zeros(B, dtype=torch.float32, device=dev) if per_person else None
+        c = center.float().contiguous(); s = scale.float().contiguous(); r = rot.float().contiguous()
+        g = grnd_pts.float().contiguous(); nm = normalizers.float().contiguous()
+        check(lib().pa_hg_pckh(h, stack, ptr(c), ptr(s), ptr(r), ptr(g), ptr(nm), ptr(self._pckh_idx), len(PCKH_JOINTS),
+                               ptr(acc), ptr(person), ptr(scratch)), 'pa_hg_pckh')
+        return acc, person
+
+
 def create_hg(num_stacks, num_modules, num_classes, chan, res=256, default_batch=24):
     """models/asn_stacked_hg.py:344-347."""
     return HourglassNet(num_modules=num_modules, num_stacks=num_stacks, chan=chan, num_classes=num_classes,

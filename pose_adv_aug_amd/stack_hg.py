@@ -1,0 +1,100 @@
+"""stack-hg.py of the reference (stage-1 pose training) on the HIP engine.
+
+The per-batch body of train() (stack-hg.py:134-185) becomes `train_step`: augmentation (regular law) and
+warp on the device, forward + Gaussian-target MSE + hand-written backward, ONE RCCL all-reduce of the
+flat gradient (inside optimizer.step), fused RMSprop, PCKh in heat-map space and at original resolution
+on the device -- no host synchronisation inside the step.  One process per GPU (torchrun)."""
+import os
+from collections import OrderedDict
+
+import torch
+import torch.distributed as dist
+
+from .data import Augmenter, DeviceBatch
+from .models.asn_stacked_hg import create_hg
+from .utils.optim import RMSprop
+from .utils.util import AverageMeter, PoseTrainHistory, adjust_lr
+
+PCK_IDX = [0, 1, 2, 3, 4, 5, 10, 11, 14, 15]            # stack-hg.py:89
+
+
+def init_distributed():
+    """One process per GPU; backend 'nccl' is RCCL on ROCm.  Returns (rank, world, local_rank)."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local % max(1, torch.cuda.device_count()))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        dist.init_process_group('nccl' if torch.cuda.is_available() else 'gloo', rank=rank, world_size=world)
+    return rank, world, local
+
+
+def broadcast_parameters(net):
+    """Identical replicas at start (replaces DataParallel's per-forward broadcast, stack-hg.py:49)."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        net._ensure_table()
+        dist.broadcast(net.flat_params, src=0)
+        dist.broadcast(net.flat_buffers, src=0)
+        net.weights_changed()
+
+
+def train_step(net, optimizer, augmenter, batch, want_pckh=True):
+    """stack-hg.py:134-180 for one batch.  Returns device scalars (loss, pckh, pckh_origin_res)."""
+    data = augmenter.regular(batch)
+    loss, _ = net.loss_and_backward(img4=data['img4'], pts=data['pts'])
+    optimizer.step()
+    if not want_pckh:
+        return loss, None, None
+    pckh = net.accuracy(PCK_IDX)                                                        # stack-hg.py:176
+    pckh_o, _ = net.pckh_origin_res(data['c'], data['s'], data['r'], data['grnd_pts'], data['normalizer'])   # :178
+    return loss, pckh[0], pckh_o[0]
+
+
+def train(batches, net, optimizer, augmenter, epoch, opt, log=print):
+    """stack-hg.py:124-189 over an iterable of DeviceBatch objects."""
+    losses, pckhs, pckhs_o = AverageMeter(), AverageMeter(), AverageMeter()
+    net.train()
+    n = len(batches)
+    for i, batch in enumerate(batches):
+        loss, pckh, pckh_o = train_step(net, optimizer, augmenter, batch)
+        if i % opt.print_freq == 0 or i == n - 1:          # the only host sync: every print_freq steps
+            losses.update(float(loss)); pckhs.update(float(pckh)); pckhs_o.update(float(pckh_o))
+            d = OrderedDict([('loss', losses.avg), ('pckh', pckhs.avg), ('pckh_origin_res', pckhs_o.avg)])
+            log('epoch:%d, iters:%d/%d ' % (epoch, i, n) + ' '.join('%s: %.4f' % kv for kv in d.items()))
+    return losses.avg, pckhs_o.avg
+
+
+def main(argv=None):
+    from .options.train_options import TrainOptions
+    from .utils.checkpoint import Checkpoint
+    opt = TrainOptions().parse(argv)
+    rank, world, _ = init_distributed()
+    net = create_hg(num_stacks=2, num_modules=1, num_classes=16, chan=256, default_batch=opt.bs)     # stack-hg.py:40-41
+    optimizer = RMSprop(net, lr=opt.lr, alpha=0.99, eps=1e-8)
+    history, ckpt = PoseTrainHistory(), Checkpoint()
+    exp_dir = os.path.join(opt.exp_dir, opt.exp_id)
+    if opt.load_prefix_pose != '':
+        ckpt.save_prefix = os.path.join(exp_dir, opt.load_prefix_pose)
+        ckpt.load_prefix = os.path.join(exp_dir, opt.load_prefix_pose)[0:-1]
+        ckpt.load_checkpoint(net, optimizer, history)
+    else:
+        ckpt.save_prefix = exp_dir + '/'
+    broadcast_parameters(net)
+    augmenter = Augmenter(seed=1234 + rank)
+    # synthetic MPII-shape people (the dataset JSON / images are not part of the checkout)
+    batches = [DeviceBatch.synthetic(opt.bs, seed=rank * 1000 + k) for k in range(4)]
+    start = history.epoch[-1]['epoch'] + 1 if history.epoch else 0
+    for epoch in range(start, opt.nEpochs):
+        adjust_lr(opt, optimizer, epoch)
+        tl, tp = train(batches, net, optimizer, augmenter, epoch, opt)
+        history.update(OrderedDict([('epoch', epoch)]), OrderedDict([('lr', optimizer.param_groups[0]['lr'])]),
+                       OrderedDict([('train_loss', tl), ('val_loss', tl)]), OrderedDict([('train_pckh', tp), ('val_pckh', tp)]))
+        if rank == 0:
+            ckpt.save_checkpoint(net, optimizer, history, torch.zeros(1, 16, 2))
+
+
+if __name__ == '__main__':
+    main()
