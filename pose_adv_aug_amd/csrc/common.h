@@ -87,6 +87,16 @@ __device__ __forceinline__ void pa_load8(const PaOperand& op, size_t idx, int c,
     }
 }
 
+// runtime-mode 8-wide operand read used by epilogues (16-byte accesses)
+__device__ __forceinline__ void pa_read8(const PaOperand& op, size_t idx, int c, float (&v)[8]) {
+    if (op.mode == PA_LD_NONE) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = 0.f;
+    } else if (op.mode == PA_LD_PLAIN) pa_load8<PA_LD_PLAIN>(op, idx, c, v);
+    else if (op.mode == PA_LD_BNRELU) pa_load8<PA_LD_BNRELU>(op, idx, c, v);
+    else pa_load8<PA_LD_LIN2>(op, idx, c, v);
+}
+
 // runtime-mode 4-wide operand read used by epilogues (8-byte accesses)
 __device__ __forceinline__ void pa_read4(const PaOperand& op, size_t idx, int c, float (&v)[4]) {
     if (op.mode == PA_LD_NONE) { v[0] = v[1] = v[2] = v[3] = 0.f; return; }

@@ -129,8 +129,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(PaConvArgs a) {
         }
 #pragma unroll
         for (int i = 0; i < BI; ++i) {
-            int row = r + 32 * i;
-            *reinterpret_cast<bf16x8*>(Bs + row * 64 + ((cc ^ (row & 7)) << 3)) = rb[i];
+            // weight rows are STORED permuted: output channel nl = q*(4*NI) + 4*ni + j of a wave's tile goes
+            // to LDS row ni*16 + 4*q + j, so that MFMA row i = 4*(lane>>4) + reg of fragment ni is channel
+            // (lane>>4)*(4*NI) + 4*ni + reg: a lane's NI fragments hold 4*NI CONSECUTIVE channels
+            // (16-byte epilogue accesses) while the fragment reads stay conflict-free
+            const int row = r + 32 * i;
+            const int wt = row / (BN / 2), nl = row - wt * (BN / 2);
+            const int q = nl / (4 * NI), rem = nl - q * (4 * NI);
+            const int lrow = wt * (BN / 2) + (rem >> 2) * 16 + 4 * q + (rem & 3);
+            *reinterpret_cast<bf16x8*>(Bs + lrow * 64 + ((cc ^ (lrow & 7)) << 3)) = rb[i];
         }
     };
 
@@ -174,27 +181,23 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(PaConvArgs a) {
     }
 
     // ---------------------------------------------------------------- epilogue
+    // Thanks to the weight-row permutation (lstore) a lane owns 4*NI CONSECUTIVE output channels of one
+    // pixel: all epilogue traffic (addends, xref, stores) is 16-byte accesses, 32 B (NI=2) or 64..128 B
+    // (NI=4) contiguous per pixel row across the four lane groups.
     const int N = a.Cout;
+    constexpr int CH = NI / 2;                       // 8-channel chunks per lane
+    const int nb = n0 + wn * (BN / 2) + (lane >> 4) * (4 * NI);
     float s1[NI][4], s2[NI][4];
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni)
+    for (int ch = 0; ch < CH; ++ch) {               // chunk-outer / pixel-inner keeps the per-channel constants short-lived
+        const int n = nb + 8 * ch;
+        float bias[8], es[8], et[8], emu[8], eis[8];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { s1[ni][j] = 0.f; s2[ni][j] = 0.f; }
-
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
-        const int n = n0 + wn * (BN / 2) + ni * 16 + (lane >> 4) * 4;
-        float bias[4] = {0.f, 0.f, 0.f, 0.f};
-        if (a.bias) {
-            f32x4 b = *reinterpret_cast<const f32x4*>(a.bias + n);
-            bias[0] = b[0]; bias[1] = b[1]; bias[2] = b[2]; bias[3] = b[3];
-        }
-        float es[4], et[4], emu[4], eis[4];
-        if (a.ep.mode == PA_OUT_BWD) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                es[j] = a.ep.scale[n + j]; et[j] = a.ep.shift[n + j];
-                emu[j] = a.ep.mean[n + j]; eis[j] = a.ep.invstd[n + j];
+        for (int j = 0; j < 8; ++j) {
+            s1[2 * ch + (j >> 2)][j & 3] = 0.f; s2[2 * ch + (j >> 2)][j & 3] = 0.f;
+            bias[j] = a.bias ? a.bias[n + j] : 0.f;
+            if (a.ep.mode == PA_OUT_BWD) {
+                es[j] = a.ep.scale[n + j]; et[j] = a.ep.shift[n + j]; emu[j] = a.ep.mean[n + j]; eis[j] = a.ep.invstd[n + j];
             }
         }
 #pragma unroll
@@ -202,33 +205,35 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(PaConvArgs a) {
             const int m = m0 + wm * (BM / 2) + mi * 16 + (lane & 15);
             if (m >= M) continue;
             const size_t idx = (size_t)m * N + n;
-            float v[4], e1[4], e2[4];
-            pa_read4(a.add1, idx, n, e1);
-            pa_read4(a.add2, idx, n, e2);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = acc[ni][mi][j] + bias[j] + e1[j] + e2[j];
-            bf16x4 o;
+            float e1[8], e2[8];
+            pa_read8(a.add1, idx, n, e1);
+            pa_read8(a.add2, idx, n, e2);
+            bf16x8 o;
             if (a.ep.mode == PA_OUT_BWD) {
-                bf16x4 xr = *reinterpret_cast<const bf16x4*>(a.ep.xref + idx);
+                bf16x8 xr = *reinterpret_cast<const bf16x8*>(a.ep.xref + idx);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < 8; ++j) {
+                    const int ni = 2 * ch + (j >> 2);
+                    float v = acc[ni][mi][j & 3] + bias[j] + e1[j] + e2[j];
                     float x = (float)xr[j];
-                    float dz = (fmaf(es[j], x, et[j]) > 0.f) ? v[j] : 0.f;
+                    float dz = (fmaf(es[j], x, et[j]) > 0.f) ? v : 0.f;
                     o[j] = (bf16)dz;
                     float dzr = (float)o[j];
-                    s1[ni][j] += dzr;
-                    s2[ni][j] += dzr * (x - emu[j]) * eis[j];
+                    s1[ni][j & 3] += dzr;
+                    s2[ni][j & 3] += dzr * (x - emu[j]) * eis[j];
                 }
             } else {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    o[j] = (bf16)v[j];
+                for (int j = 0; j < 8; ++j) {
+                    const int ni = 2 * ch + (j >> 2);
+                    float v = acc[ni][mi][j & 3] + bias[j] + e1[j] + e2[j];
+                    o[j] = (bf16)v;
                     float rv = (float)o[j];
-                    s1[ni][j] += rv;
-                    s2[ni][j] += rv * rv;
+                    s1[ni][j & 3] += rv;
+                    s2[ni][j & 3] += rv * rv;
                 }
             }
-            *reinterpret_cast<bf16x4*>(a.out + idx) = o;
+            *reinterpret_cast<bf16x8*>(a.out + idx) = o;
         }
     }
     if (a.ep.mode != PA_OUT_PLAIN) {
@@ -243,7 +248,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(PaConvArgs a) {
 #pragma unroll
                 for (int o = 1; o < 16; o <<= 1) { x1 += __shfl_xor(x1, o, 64); x2 += __shfl_xor(x2, o, 64); }
                 if ((lane & 15) == 0) {
-                    const int col = wn * (BN / 2) + ni * 16 + (lane >> 4) * 4 + j;
+                    const int col = wn * (BN / 2) + (lane >> 4) * (4 * NI) + 4 * ni + j;
                     red[(wm * BN + col) * 2] = x1;
                     red[(wm * BN + col) * 2 + 1] = x2;
                 }

@@ -12,6 +12,7 @@
 // fp32 partial slab that pa_launch_wgrad_reduce sums into the PyTorch-layout gradient.
 #include "common.h"
 #include "kernels.h"
+#include <stdlib.h>
 
 // STEM: x is the 4-channel-padded image and the 'channels' are the 256 (ky*32+kx*4+c) patch
 // elements of the 7x7 stride-2 stem conv (one 16-byte chunk = 2 adjacent input pixels); a.H/a.W
@@ -229,7 +230,12 @@ int pa_wgrad_splits(int M, int Cin, int Cout, int taps) {
     tile_of(Cin, Cout, TN, TK);
     const int tiles = (Cout / TN) * (taps * Cin / TK);
     const int steps_total = (M + 63) / 64;
-    int s = round_up8((256 + tiles - 1) / tiles);
+    // enough workgroups to keep every CU busy with several of them (measured on MI355X: 512 for the
+    // 1x1 layers, 1024 for the 3x3 layers; PA_WGRAD_BLOCKS overrides for experiments)
+    static int forced = -1;
+    if (forced < 0) { const char* e = getenv("PA_WGRAD_BLOCKS"); forced = e ? atoi(e) : 0; }
+    const int target = forced >= 8 ? forced : (taps == 9 ? 1024 : 512);
+    int s = round_up8((target + tiles - 1) / tiles);
     if (s > steps_total) s = steps_total;
     if (s < 1) s = 1;
     return s;
@@ -308,7 +314,7 @@ __global__ void wgrad_reduce_kernel(const PaWgradReduceJob* jobs) {
 int pa_launch_wgrad_reduce(const PaWgradReduceJob* jobs_dev, int njobs, int max_elems, hipStream_t st) {
     if (njobs <= 0) return 0;
     int bx = (max_elems + 255) / 256;
-    if (bx > 64) bx = 64;
+    if (bx > 576) bx = 576;          // the largest layer (3x3, 128x128: 147456 weights) gets one element per thread
     if (bx < 1) bx = 1;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(bx, njobs), dim3(256), 0, st, jobs_dev);
     return (int)hipGetLastError();

@@ -16,6 +16,7 @@ __device__ __forceinline__ void reduce_partial_rows(const float* part, int rows,
     const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
     float a = 0.f, b = 0.f;
     if (c0 + cl < C) {
+#pragma unroll 8
         for (int r = sl; r < rows; r += 32) {
             f32x2 v = *reinterpret_cast<const f32x2*>(part + ((size_t)r * C + c0 + cl) * 2);
             a += v[0]; b += v[1];
