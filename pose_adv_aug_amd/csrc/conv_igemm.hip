@@ -28,8 +28,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(PaConvArgs a) {
     constexpr int AI = BM / 32, BI = BN / 32;      // staged 16-byte chunks per thread (A / B tile)
     constexpr int MI = BM / 32, NI = BN / 32;      // 16x16 fragments per wave (wave tile BM/2 x BN/2)
     __shared__ __attribute__((aligned(16))) bf16 lds[(BM + BN) * 64];
+    __shared__ float kst[LDMODE == PA_LD_PLAIN ? 4 : 3 * 512];      // per-channel constants of the input transform
     bf16* As = lds;
     bf16* Bs = lds + BM * 64;
+    if (LDMODE != PA_LD_PLAIN) {
+        for (int c = threadIdx.x; c < a.Cin; c += 256) {
+            kst[c] = a.in.k0[c]; kst[512 + c] = a.in.k1[c];
+            if (LDMODE == PA_LD_LIN2) kst[1024 + c] = a.in.k2[c];
+        }
+    }
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave & 1, wn = wave >> 1;
@@ -100,10 +107,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(PaConvArgs a) {
         float k0[8], k1[8], k2[8];
         if (LDMODE != PA_LD_PLAIN) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { k0[j] = a.in.k0[cur_c + j]; k1[j] = a.in.k1[cur_c + j]; }
+            for (int j = 0; j < 8; ++j) { k0[j] = kst[cur_c + j]; k1[j] = kst[512 + cur_c + j]; }
             if (LDMODE == PA_LD_LIN2) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) k2[j] = a.in.k2[cur_c + j];
+                for (int j = 0; j < 8; ++j) k2[j] = kst[1024 + cur_c + j];
             }
         }
 #pragma unroll
@@ -148,6 +155,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(PaConvArgs a) {
         for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     gload(0);
+    __syncthreads();            // kst visible
     lstore();
     __syncthreads();
 
@@ -292,7 +300,7 @@ int pa_launch_stem_conv(const PaConvArgs& a, hipStream_t st, int* stat_rows) {
 }
 
 int pa_launch_conv(const PaConvArgs& a, hipStream_t st, int* stat_rows) {
-    if ((a.taps != 1 && a.taps != 9) || a.Cin % 64 != 0 || a.Cout % 64 != 0) {
+    if ((a.taps != 1 && a.taps != 9) || a.Cin % 64 != 0 || a.Cout % 64 != 0 || a.Cin > 512) {
         pa_set_error_msg("pa_launch_conv: channel counts must be multiples of 64 and taps 1 or 9");
         return 1;
     }

@@ -299,6 +299,7 @@ __global__ void wgrad_reduce_kernel(const PaWgradReduceJob* jobs) {
             const int tap = r / j.real_cin, c = r - tap * j.real_cin;
             const float* src = j.part + (size_t)n * K + tap * j.Cin + c;
             float s = 0.f;
+#pragma unroll 8
             for (int sp = 0; sp < j.splits; ++sp) s += src[(size_t)sp * j.Cout * K];
             j.dst[((size_t)n * j.real_cin + c) * j.taps + tap] = s;
         } else if (j.dbdst) {

@@ -1,0 +1,146 @@
+"""CPU-only checks of the host layer: the C-ABI library loads and exports every symbol that
+include/poseadv.h declares (no compute calls without a GPU), option parsing, checkpoint file naming /
+round trip, histories, LR schedule and the vectorised reward shaping against the oracle."""
+import os
+import re
+import types
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    import pose_adv_aug_amd as P
+    if not os.path.isfile(P.LIB_PATH):
+        P.build()
+    hdr = open(os.path.join(ROOT, 'include', 'poseadv.h')).read()
+    declared = sorted(set(re.findall(r'\b(pa_[a-z0-9_]+)\s*\(', hdr)))
+    assert len(declared) >= 35
+    l = P.lib()
+    missing = [n for n in declared if not hasattr(l, n)]
+    assert not missing, missing
+    assert l.pa_version() >= 1
+    # every symbol the Python layer binds is declared in the header
+    assert set(P.EXPORTS) <= set(declared), sorted(set(P.EXPORTS) - set(declared))
+
+
+def test_no_cpu_fallback_without_gpu():
+    import pose_adv_aug_amd as P
+    from pose_adv_aug_amd.models.asn_stacked_hg import create_hg
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    net = create_hg(2, 1, 16, 256)
+    with pytest.raises(P.PoseAdvError):
+        net(torch.zeros(1, 3, 256, 256))
+    with pytest.raises(P.PoseAdvError):
+        from pose_adv_aug_amd.pylib import HumanPts
+        HumanPts.pts2heatmap(np.ones((16, 2)), [64, 64])
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, 'pose_adv_aug_amd')
+    for d, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith('.py') or f.endswith('.hip') or f.endswith('.h'):
+                src = open(os.path.join(d, f)).read()
+                assert not re.search(r'^\s*(from|import)\s+oracle\b', src, re.M), os.path.join(d, f)
+                assert 'from tests' not in src, os.path.join(d, f)
+
+
+def test_options_and_prefix_normalisation(tmp_path, capsys):
+    from pose_adv_aug_amd.options.train_options import TrainOptions
+    opt = TrainOptions().parse(['--exp_dir', str(tmp_path), '--exp_id', 'e1', '--bs', '24', '--is_train', 'false',
+                                '--load_prefix_pose', 'lr-0.00025-10.pth.tar'])
+    assert opt.bs == 24 and opt.lr == 2.5e-4 and opt.agent_lr == 5e-5 and opt.nEpochs == 100 and opt.print_freq == 10
+    assert opt.is_train is True                       # type=bool quirk of the reference: any non-empty string is True
+    assert opt.load_prefix_pose == 'lr-0.00025-10-'   # what options/base_options.py:62-65 intends
+    assert opt.load_prefix_pose[0:-1] == 'lr-0.00025-10'          # stack-hg.py:59 strips the '-' again
+    assert os.path.isfile(os.path.join(str(tmp_path), 'e1', 'opt.txt'))
+    with pytest.raises(SystemExit):
+        TrainOptions().parse(['--exp_dir', str(tmp_path)])       # missing --exp_id
+
+
+def test_histories_meter_and_lr_schedule():
+    from pose_adv_aug_amd.utils.util import PoseTrainHistory, ASNTrainHistory, AverageMeter, adjust_lr
+    from oracle import pylib as opl
+    h = PoseTrainHistory()
+    h.update({'epoch': 0}, {'lr': 2.5e-4}, {'train_loss': 1., 'val_loss': 1.}, {'train_pckh': .1, 'val_pckh': .2})
+    assert h.is_best and h.best_pckh == .2
+    h.update({'epoch': 1}, {'lr': 2.5e-4}, {'train_loss': 1., 'val_loss': 1.}, {'train_pckh': .1, 'val_pckh': .1})
+    assert not h.is_best
+    h2 = PoseTrainHistory(); h2.load_state_dict(h.state_dict())
+    assert h2.epoch[-1]['epoch'] == 1 and h2.best_pckh == .2
+    a = ASNTrainHistory(); a.update({'epoch': 0}, {'lr': 5e-5}, {'train_loss': 3.0})
+    assert a.is_best and a.lowest_loss == 3.0
+    m = AverageMeter(); m.update(2.0); m.update(4.0)
+    assert m.avg == 3.0 and m.val == 4.0
+    opt = types.SimpleNamespace(lr=2.5e-4)
+    o = types.SimpleNamespace(param_groups=[{'lr': 2.5e-4}])
+    lr = 2.5e-4
+    for epoch in range(0, 150):
+        adjust_lr(opt, o, epoch)
+        lr = opl.adjust_lr_value(lr, epoch)
+        assert abs(o.param_groups[0]['lr'] - lr) < 1e-12
+    assert abs(lr - 2.5e-4 * 0.2 * 0.5) < 1e-12
+
+
+def test_gen_groundtruth_matches_oracle():
+    from pose_adv_aug_amd.utils.util import gen_groundtruth
+    from oracle import pylib as opl
+    from tests.test_oracle_golden import load, t
+    g = load('pylib.npz')
+    out = gen_groundtruth(t(g['gg_p']), t(g['gg_idx']), t(g['gg_reg']), t(g['gg_agent']))
+    assert np.allclose(out.numpy(), g['gg_out'], atol=1e-7)
+    rng = np.random.default_rng(0)
+    for _ in range(100):
+        p = torch.softmax(torch.tensor(rng.normal(0, 2.5, (24, 7)), dtype=torch.float32), 1)
+        idx = torch.tensor(rng.integers(0, 7, (24, 1)))
+        a = torch.tensor(rng.random(24), dtype=torch.float32); b = torch.tensor(rng.random(24), dtype=torch.float32)
+        assert torch.allclose(gen_groundtruth(p, idx, a, b), opl.gen_groundtruth(p, idx, a, b), atol=1e-6)
+
+
+class _FakeNet(object):
+    """state_dict / load_state_dict surface of the engine's modules on CPU tensors (checkpoint plumbing only)."""
+
+    def __init__(self):
+        self.w = {'conv1.weight': torch.arange(12.).view(2, 2, 1, 3), 'bn1.running_mean': torch.zeros(2)}
+
+    def state_dict(self, prefix=''):
+        return {prefix + k: v for k, v in self.w.items()}
+
+    def load_state_dict(self, sd, strict=True):
+        unexpected = []
+        for k, v in sd.items():
+            kk = k[7:] if k.startswith('module.') else k
+            if kk in self.w:
+                self.w[kk] = v.clone()
+            else:
+                unexpected.append(k)
+        return [], unexpected
+
+
+def test_checkpoint_names_and_round_trip(tmp_path):
+    from pose_adv_aug_amd.utils.checkpoint import Checkpoint
+    from pose_adv_aug_amd.utils.util import PoseTrainHistory
+    net = _FakeNet()
+    opt = types.SimpleNamespace(state_dict=lambda: {'state': {}, 'param_groups': [{'lr': 2.5e-4}]}, load_state_dict=lambda sd: None)
+    h = PoseTrainHistory()
+    h.update({'epoch': 10}, {'lr': 2.5e-4}, {'train_loss': 1., 'val_loss': 1.}, {'train_pckh': .1, 'val_pckh': .2})
+    ck = Checkpoint(); ck.save_prefix = str(tmp_path) + '/'
+    path = ck.save_checkpoint(net, opt, h, torch.zeros(3, 16, 2))
+    assert os.path.basename(path) == 'lr-0.00025-10.pth.tar'                      # utils/checkpoint.py:15-16
+    for f in ('lr-0.00025-10-preds.mat', 'lr-0.00025-10-model-best.pth.tar', 'lr-0.00025-10-preds-best.mat'):
+        assert os.path.isfile(os.path.join(str(tmp_path), f)), f
+    saved = torch.load(path, weights_only=False)
+    assert list(saved['state_dict'].keys())[0] == 'module.conv1.weight'            # DataParallel prefix kept
+    saved['state_dict']['module.not_in_net'] = torch.zeros(1)
+    torch.save(saved, path)
+    net2 = _FakeNet(); net2.w['conv1.weight'] = torch.zeros(2, 2, 1, 3)
+    h2 = PoseTrainHistory()
+    ck2 = Checkpoint(); ck2.load_prefix = os.path.join(str(tmp_path), 'lr-0.00025-10')
+    assert ck2.load_checkpoint(net2, opt, h2)
+    assert torch.equal(net2.w['conv1.weight'], net.w['conv1.weight']) and h2.epoch[-1]['epoch'] == 10
+    assert not Checkpoint().load_checkpoint(net2)                                   # missing file: message, no exception
