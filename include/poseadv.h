@@ -150,6 +150,22 @@ int pa_hg_heatmap_nchw(pa_net* net, int stack, float* out);
 /* loss.backward() (stack-hg.py:164): fills the flat gradient array bound with pa_net_bind */
 int pa_hg_backward(pa_net* net);
 
+/* Half-hourglass forward (models/asn_stacked_hg.py:300-304 with is_half_hg): stem + the down path of
+ * hg[0] up to the neck -- everything the agent reads.  train != 0 updates the BatchNorm running
+ * statistics of those layers, as the reference does on the agent-augmentation steps (Appendix A.9). */
+int pa_hg_forward_half(pa_net* net, const float* img, const void* img4, int train);
+
+/* ASN.forward (models/asn_stacked_hg.py:401-436) on the pose net's detached features of the last
+ * (half or full) forward (:159-164): logits [B][scale_num] and [B][rotation_num] (device, may be NULL).
+ * train selects the agent's BatchNorm mode. */
+int pa_asn_forward(pa_net* asn, pa_net* pose, int train, float* logits_scale, float* logits_rot);
+/* softmax of the last pa_asn_forward's logits: [B][scale_num + rotation_num] (scale first), in the workspace */
+const float* pa_asn_probs(const pa_net* asn);
+/* KL loss of joint-train-pose-s-r-agent.py:399-407 against the target distributions (gen_groundtruth,
+ * utils/util.py:147) + backward into the agent's flat gradient; no gradient reaches the pose net.
+ * target_* [B][K] fp32 device; loss: device fp32 scalar or NULL. */
+int pa_asn_backward(pa_net* asn, pa_net* pose, const float* target_scale, const float* target_rot, float* loss);
+
 /* Evaluation.accuracy (pylib/Evaluation.py:54-75) of stack i's heat maps against the Gaussian target
  * of the joints given to the last forward: acc [nidx+1]. */
 int pa_hg_accuracy(pa_net* net, int stack, const int32_t* idxs, int nidx, float* acc, float* scratch);
@@ -173,6 +189,10 @@ int pa_net_profile_report(pa_net* net, double* out_host);
  * Names: "stem", "res1".."res3", "pool0", "hg<i>.skip<k>|pool<k>|down<k>|up<k>|merge<k>|neck" (k=1..4),
  * "post<i>", "lin<i>", "xin<i>", optional suffix ".x1"/".x2" for a block's inner tensors. */
 int pa_hg_debug_tensor(pa_net* net, const char* which, int grad, float* out, int* shape4);
+
+/* The same hook for the agent: "in<k>" (k = 0..4: residual_skip1-4, residual_neck), "pa<k>", "merge<k>"
+ * (k = 0..3), "deep<k>" (k = 0..2), optional suffix ".x1"/".x2". */
+int pa_asn_debug_tensor(pa_net* net, const char* which, int grad, float* out, int* shape4);
 
 #ifdef __cplusplus
 }

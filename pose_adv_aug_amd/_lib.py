@@ -67,10 +67,15 @@ _PROTOS = {
     'pa_hg_heatmap_nchw': (_i, [_vp, _i, _vp]),
     'pa_hg_backward': (_i, [_vp]),
     'pa_hg_accuracy': (_i, [_vp, _i, _vp, _i, _vp, _vp]),
+    'pa_hg_forward_half': (_i, [_vp, _vp, _vp, _i]),
+    'pa_asn_forward': (_i, [_vp, _vp, _i, _vp, _vp]),
+    'pa_asn_probs': (_vp, [_vp]),
+    'pa_asn_backward': (_i, [_vp, _vp, _vp, _vp, _vp]),
     'pa_hg_pckh': (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
     'pa_net_profile_begin': (_i, [_vp]),
     'pa_net_profile_report': (_i, [_vp, C.POINTER(C.c_double)]),
     'pa_hg_debug_tensor': (_i, [_vp, C.c_char_p, _i, _vp, C.POINTER(_i)]),
+    'pa_asn_debug_tensor': (_i, [_vp, C.c_char_p, _i, _vp, C.POINTER(_i)]),
 }
 
 EXPORTS = sorted(_PROTOS)

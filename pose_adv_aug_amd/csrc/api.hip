@@ -261,10 +261,46 @@ pa_net* pa_hg_create(int num_stacks, int num_classes, int chan, int B, int res) 
 }
 
 pa_net* pa_asn_create(int chan, int scale_num, int rotation_num, int B, int res) {
-    (void)chan; (void)scale_num; (void)rotation_num; (void)B; (void)res;
-    pa_set_error_msg("pa_asn_create: not built yet");
-    return nullptr;
+    g_err[0] = 0;
+    if (chan % 128 != 0 || chan > 512 || res % 64 != 0 || B < 1 || scale_num < 1 || rotation_num < 1 || scale_num + rotation_num > 64) {
+        pa_set_error_msg("pa_asn_create: need chan % 128 == 0, res % 64 == 0, scale_num + rotation_num <= 64");
+        return nullptr;
+    }
+    pa_net* p = new (std::nothrow) pa_net;
+    if (!p) return nullptr;
+    Net& n = p->n;
+    n.chan = chan; n.B = B; n.res = res; n.scale_num = scale_num; n.rot_num = rotation_num; n.stacks = 0;
+    n.declare_asn();
+    n.workspace_bytes = n.layout_asn(nullptr);
+    return p;
 }
+
+int pa_hg_forward_half(pa_net* net, const float* img, const void* img4, int train) {
+    g_err[0] = 0;
+    if (!img && !img4) { pa_set_error_msg("pa_hg_forward_half: need img or img4"); return 1; }
+    TRY(net->n.forward_half(img, reinterpret_cast<const bf16*>(img4), train != 0));
+    return 0;
+}
+
+int pa_asn_forward(pa_net* asn, pa_net* pose, int train, float* logits_scale, float* logits_rot) {
+    g_err[0] = 0;
+    if (!asn->n.is_agent || pose->n.is_agent || asn->n.B != pose->n.B || asn->n.chan != pose->n.chan || asn->n.res != pose->n.res) {
+        pa_set_error_msg("pa_asn_forward: agent and pose net must be built for the same batch, width and resolution");
+        return 1;
+    }
+    asn->n.bn_update = (train == 2) ? 0 : 1;       // train == 2: batch statistics, running estimates untouched
+    TRY(asn->n.asn_forward(pose->n, train != 0, logits_scale, logits_rot));
+    asn->n.bn_update = 1;
+    return 0;
+}
+
+int pa_asn_backward(pa_net* asn, pa_net* pose, const float* target_scale, const float* target_rot, float* loss) {
+    g_err[0] = 0;
+    TRY(asn->n.asn_backward(pose->n, target_scale, target_rot, loss));
+    return 0;
+}
+
+const float* pa_asn_probs(const pa_net* asn) { return asn->n.asn_probs; }
 
 void pa_net_destroy(pa_net* net) { delete net; }
 
@@ -288,7 +324,7 @@ int pa_net_bind(pa_net* net, float* params, float* grads, float* buffers, void* 
     g_err[0] = 0;
     Net& n = net->n;
     n.params = params; n.grads = grads; n.buffers = buffers; n.workspace = reinterpret_cast<char*>(workspace); n.st = ST(s);
-    n.layout_all(n.workspace);
+    if (n.is_agent) n.layout_asn(n.workspace); else n.layout_all(n.workspace);
     TRY(n.upload_tables());
     return n.prepare_weights();
 }
@@ -399,6 +435,31 @@ int pa_hg_debug_tensor(pa_net* net, const char* which, int grad, float* out, int
         }
     }
     if (!a) { pa_set_error_msg("pa_hg_debug_tensor: unknown tensor name"); return 1; }
+    shape4[0] = a->B; shape4[1] = a->C; shape4[2] = a->H; shape4[3] = a->W;
+    if (!out) return 0;
+    PaOperand src = grad ? pa_plain(a->grad) : n.op(*a);
+    TRY(pa_launch_nhwc_bf16_to_nchw_f32(src, out, a->B, a->C, a->H, a->W, n.st));
+    return 0;
+}
+
+
+// test hook for the agent, like pa_hg_debug_tensor: names "in<k>" (k=0..4: residual_skip1-4, residual_neck),
+// "pa<k>", "merge<k>" (k=0..3), "deep<k>" (k=0..2), optional ".x1"/".x2"
+int pa_asn_debug_tensor(pa_net* net, const char* which, int grad, float* out, int* shape4) {
+    Net& n = net->n;
+    std::string w(which);
+    const Act* a = nullptr;
+    auto pick = [&](Residual& r, const std::string& rest) -> const Act* {
+        if (rest == ".x1") return &r.x1;
+        if (rest == ".x2") return &r.x2;
+        return &r.x3;
+    };
+    auto starts = [&](const char* p) { return w.rfind(p, 0) == 0; };
+    if (starts("in")) a = pick(n.asn_in[w[2] - '0'], w.substr(3));
+    else if (starts("pa")) a = &n.asn_pa[w[2] - '0'];
+    else if (starts("merge")) a = pick(n.asn_merge[w[5] - '0'], w.substr(6));
+    else if (starts("deep")) a = pick(n.asn_deep[w[4] - '0'], w.substr(5));
+    if (!a) { pa_set_error_msg("pa_asn_debug_tensor: unknown tensor name"); return 1; }
     shape4[0] = a->B; shape4[1] = a->C; shape4[2] = a->H; shape4[3] = a->W;
     if (!out) return 0;
     PaOperand src = grad ? pa_plain(a->grad) : n.op(*a);

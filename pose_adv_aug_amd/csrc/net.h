@@ -124,6 +124,7 @@ struct Net {
     hipStream_t st = nullptr;
     Prof prof;
     bool train_bn = true;
+    int bn_update = 1;                         // 0: use batch statistics without touching the running estimates
     float momentum = 0.1f, eps = 1e-5f;
 
     // ---- pose net modules
@@ -170,6 +171,20 @@ struct Net {
     int forward_pose(const float* img_nchw, const bf16* img4_in, const double* pts, bool train, float* loss_out_dev);
     int backward_pose();
     int reduce_grads();
+    int forward_half(const float* img_nchw, const bf16* img4_in, bool train);     // stem + hg[0] down path (agent features)
+
+    // ---- ASN scale/rotation agent (is_agent == true): reference models/asn_stacked_hg.py:349-439
+    int scale_num = 7, rot_num = 7;
+    Residual asn_in[5];                            // residual_skip1..4, residual_neck
+    Residual asn_merge[4];
+    Residual asn_deep[3];
+    size_t p_fcs_w = 0, p_fcs_b = 0, p_fcr_w = 0, p_fcr_b = 0;
+    Act asn_pa[4];                                 // maxpool(previous) + lower feature
+    float *asn_feat = nullptr, *asn_logits = nullptr, *asn_probs = nullptr, *asn_dlogits = nullptr;   // [B][C], [B][2K] ...
+    void declare_asn();
+    size_t layout_asn(char* base);
+    int asn_forward(Net& pose, bool train, float* logits_s, float* logits_r);
+    int asn_backward(Net& pose, const float* target_s, const float* target_r, float* loss_out);
 };
 
 PaOperand pa_plain(const bf16* p);

@@ -313,7 +313,7 @@ int Net::conv_fwd(ConvLayer& c, const PaOperand& in, int B_, int H, int W, const
     if (bn_after && train_bn)
         TRY(pa_launch_bn_finalize(bn_after->stats, bn_after->stat_rows, params + bn_after->p_gamma, params + bn_after->p_beta,
                                   buffers + bn_after->b_rmean, buffers + bn_after->b_rvar, bn_after->scale, bn_after->shift,
-                                  bn_after->mean, bn_after->invstd, bn_after->C, (float)(B_ * H * W), momentum, eps, 1, st));
+                                  bn_after->mean, bn_after->invstd, bn_after->C, (float)(B_ * H * W), momentum, eps, bn_update, st));
     return 0;
 }
 

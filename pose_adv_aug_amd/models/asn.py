@@ -1,0 +1,57 @@
+"""ASN scale/rotation agent of the reference (models/asn_stacked_hg.py:349-439, aug branch) on the HIP engine."""
+import torch
+
+from .._lib import lib, check, ptr
+from .asn_stacked_hg import _HipModule
+
+
+class ASN(_HipModule):
+    def __init__(self, chan, scale_num, rotation_num, res=256, default_batch=24):
+        super().__init__()
+        self.chan, self.scale_num, self.rotation_num, self.res = chan, scale_num, rotation_num, res
+        self.default_batch = default_batch
+        self._last_B = None
+        self._last_pose = None
+
+    def _create(self, B):
+        return lib().pa_asn_create(self.chan, self.scale_num, self.rotation_num, B, self.res)
+
+    def _forward_from_pose(self, pose, x=None, img4=None, is_half_hg=True, update_running=True):
+        """hg(img, asn, is_half_hg=True, is_aug=True) of the reference (models/asn_stacked_hg.py:300-304): the
+        pose net runs its stem + first hourglass down path in ITS current mode, the agent (in its own mode) maps the
+        detached features to (scale_logits [B][S], rotation_logits [B][R])."""
+        if not is_half_hg:
+            raise NotImplementedError('the joint loop only uses the half-hourglass agent forward')
+        B = x.shape[0] if x is not None else img4.shape[0]
+        hp, ha = pose._net(B), self._net(B)
+        pose._last_B = B
+        xin = x.contiguous().float() if x is not None else None
+        check(lib().pa_hg_forward_half(hp, ptr(xin), ptr(img4), 1 if pose.training else 0), 'pa_hg_forward_half')
+        if pose.training:
+            pose._nbt += 1
+        return self.forward_features(pose, update_running)
+
+    def forward_features(self, pose, update_running=True):
+        """agent forward on the features of the pose net's last (half or full) forward"""
+        B = pose._last_B
+        hp, ha = pose._net(B), self._net(B)
+        dev = self.flat_params.device
+        ls = torch.empty((B, self.scale_num), dtype=torch.float32, device=dev)
+        lr = torch.empty((B, self.rotation_num), dtype=torch.float32, device=dev)
+        mode = (1 if update_running else 2) if self.training else 0
+        check(lib().pa_asn_forward(ha, hp, mode, ptr(ls), ptr(lr)), 'pa_asn_forward')
+        if self.training and update_running:
+            self._nbt += 1
+        self._last_B, self._last_pose = B, pose
+        return ls, lr
+
+    def loss_and_backward(self, grnd_scale_distri, grnd_rotation_distri):
+        """KL(log(softmax + 1e-7) || target) * K for both heads (joint-train-pose-s-r-agent.py:399-407) and its
+        gradient w.r.t. the agent's parameters (flat_grads).  Returns the loss as a 0-d GPU tensor."""
+        B, pose = self._last_B, self._last_pose
+        dev = self.flat_params.device
+        ts = grnd_scale_distri.to(dev, torch.float32).contiguous()
+        tr = grnd_rotation_distri.to(dev, torch.float32).contiguous()
+        loss = torch.zeros(1, dtype=torch.float32, device=dev)
+        check(lib().pa_asn_backward(self._net(B), pose._net(B), ptr(ts), ptr(tr), ptr(loss)), 'pa_asn_backward')
+        return loss[0]

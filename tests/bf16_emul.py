@@ -88,6 +88,26 @@ def R(x):
     return x + (x.bfloat16().float() - x).detach()
 
 
+class _GradRound(torch.autograd.Function):
+    """identity in the forward pass, rounds the GRADIENT to bf16 in the backward pass -- placed where the engine
+    stores a gradient tensor in bf16 (the masked gradient dz) or stages one as a bf16 MFMA operand"""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.bfloat16().float()
+
+
+ROUND_GRADS = False          # set True to emulate the engine's bf16 gradient storage as well
+
+
+def GR(x):
+    return _GradRound.apply(x) if ROUND_GRADS else x
+
+
 def _bn(bn, x):
     return F.batch_norm(x, bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.training, bn.momentum, bn.eps)
 
@@ -97,13 +117,16 @@ def _conv(conv, a):
 
 
 def emul_residual(blk, a, tap=None, name=''):
-    x1 = R(_conv(blk.conv1, a))
-    a1 = torch.relu(_bn(blk.bn1, x1))
-    x2 = R(_conv(blk.conv2, a1))
-    a2 = torch.relu(_bn(blk.bn2, x2))
-    sc = a if blk.adapter is None else R(_conv(blk.adapter, a))
-    x3 = R(_conv(blk.conv3, a2) + sc)
-    a3 = torch.relu(_bn(blk.bn3, x3))
+    # GR(...) marks the engine's bf16 gradient roundings: the masked gradient in front of every ReLU and the
+    # BatchNorm-backward result staged as the MFMA operand of each conv's dgrad / wgrad (the shortcut addend
+    # of conv3 stays fp32 in the epilogue)
+    x1 = R(GR(_conv(blk.conv1, a)))
+    a1 = torch.relu(GR(_bn(blk.bn1, x1)))
+    x2 = R(GR(_conv(blk.conv2, a1)))
+    a2 = torch.relu(GR(_bn(blk.bn2, x2)))
+    sc = a if blk.adapter is None else R(GR(_conv(blk.adapter, a)))
+    x3 = R(GR(_conv(blk.conv3, a2)) + sc)
+    a3 = torch.relu(GR(_bn(blk.bn3, x3)))
     if tap is not None:
         tap[name + '.x1'] = a1; tap[name + '.x2'] = a2; tap[name] = a3
         for v in (a1, a2, a3):

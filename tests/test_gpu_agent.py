@@ -1,0 +1,153 @@
+"""GPU parity of the ASN scale/rotation agent and of the joint-training steps (reference
+models/asn_stacked_hg.py:349-439, joint-train-pose-s-r-agent.py:195-467)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import model as om
+from oracle import pylib as opl
+from oracle import step as ostep
+from tests import inputs, bf16_emul
+from tests.test_gpu_net import rel_rms, cosine, t
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(chan, B, res, seed):
+    from pose_adv_aug_amd.models.asn_stacked_hg import create_hg, create_asn
+    ref = om.create_hg(2, 1, 16, chan); om.deterministic_fill_(ref, seed=seed)
+    ragent = om.create_asn(chan, chan, 7, 7, is_aug=True); om.deterministic_fill_(ragent, seed=seed + 1)
+    net = create_hg(2, 1, 16, chan, res=res, default_batch=B); net.load_state_dict(ref.state_dict())
+    agent = create_asn(chan, chan, 7, 7, is_aug=True, res=res, default_batch=B)
+    assert list(agent.state_dict().keys()) == list(ragent.state_dict().keys())
+    for (k, a), (_, b) in zip(agent.state_dict().items(), ragent.state_dict().items()):
+        assert tuple(a.shape) == tuple(b.shape), k
+    agent.load_state_dict(ragent.state_dict())
+    return ref, ragent, net, agent
+
+
+def test_agent_graph_matches_locally():
+    """Half-hourglass (eval) + agent (train), node by node at the engine's own operating point (the method
+    of tests/test_gpu_local.py): every residual block of the agent, the pool+add merges, the average-pool /
+    Linear head, the KL loss and every parameter gradient."""
+    import ctypes as C
+    import torch.nn.functional as F
+    from pose_adv_aug_amd._lib import lib, check, ptr
+    from tests.test_gpu_local import _close, _leaf, FWD_TOL, GRAD_TOL, GRAD_COS
+    torch.set_num_threads(8)
+    bf16_emul.ROUND_GRADS = True        # the engine stages gradient operands in bf16 (standard mixed precision)
+    B, res, chan = 4, 256, 128
+    ref, ragent, net, agent = _pair(chan, B, res, seed=41)
+    img = t(inputs.images(141, B, res))
+    net.eval(); agent.train(); ref.eval(); ragent.train()
+    ls, lr = net(img.cuda(), asn=agent, is_half_hg=True, is_aug=True)
+    hp, ha = net._net(B), agent._net(B)
+
+    def get(fn, h, name, grad=0):
+        shp = (C.c_int * 4)()
+        check(fn(h, name.encode(), grad, None, shp))
+        out = torch.empty(tuple(shp), device='cuda')
+        check(fn(h, name.encode(), grad, ptr(out), shp))
+        return out.cpu()
+    L = lib()
+    feats = [get(L.pa_hg_debug_tensor, hp, n) for n in ('hg0.skip1', 'hg0.skip2', 'hg0.skip3', 'hg0.skip4', 'hg0.neck')]
+    act = lambda n: get(L.pa_asn_debug_tensor, ha, n, 0)
+    grd = lambda n: get(L.pa_asn_debug_tensor, ha, n, 1)
+    # coarse end-to-end sanity against the fp32 oracle (chaotic, see test_gpu_local): features within 15 %
+    with torch.no_grad():
+        f_ref, _, _ = ref.hg[0].agent_features(ref.stem(img))
+    assert rel_rms(feats[0], f_ref['skip1']) < 0.15
+    errs = []
+    # ---- forward, node by node
+    in_blocks = [ragent.residual_skip1, ragent.residual_skip2, ragent.residual_skip3, ragent.residual_skip4, ragent.residual_neck]
+    for k in range(5):
+        _close(errs, 'fwd in%d' % k, act('in%d' % k), bf16_emul.emul_residual(in_blocks[k], feats[k]).detach(), FWD_TOL)
+    merges = [ragent.merge1, ragent.merge2, ragent.merge3, ragent.merge4]
+    for k in range(4):
+        hi = act('in0') if k == 0 else act('merge%d' % (k - 1))
+        pa = bf16_emul.R(F.max_pool2d(hi, 2, 2) + act('in%d' % (k + 1)))
+        _close(errs, 'fwd pa%d' % k, act('pa%d' % k), pa, FWD_TOL)
+        _close(errs, 'fwd merge%d' % k, act('merge%d' % k), bf16_emul.emul_residual(merges[k], act('pa%d' % k)).detach(), FWD_TOL)
+    for k in range(3):
+        src = act('merge3') if k == 0 else act('deep%d' % (k - 1))
+        _close(errs, 'fwd deep%d' % k, act('deep%d' % k), bf16_emul.emul_residual(ragent.deep_merge[k], src).detach(), FWD_TOL)
+    top = _leaf(act('deep2'))
+    x = F.avg_pool2d(top, 4).flatten(1)
+    es, er = ragent.fc_scale(x), ragent.fc_rotation(x)
+    _close(errs, 'logits scale', ls.cpu(), es.detach(), 2e-3)
+    _close(errs, 'logits rotation', lr.cpu(), er.detach(), 2e-3)
+    # ---- loss + backward
+    g = inputs.rng(43)
+    ps, pr = torch.softmax(ls.cpu(), 1), torch.softmax(lr.cpu(), 1)
+    gs = opl.gen_groundtruth(ps, t(g.integers(0, 7, (B, 1))), t(g.random(B).astype(np.float32)), t(g.random(B).astype(np.float32)))
+    gr = opl.gen_groundtruth(pr, t(g.integers(0, 7, (B, 1))), t(g.random(B).astype(np.float32)), t(g.random(B).astype(np.float32)))
+    loss = agent.loss_and_backward(gs, gr)
+    hip_grads = {n: gg.cpu() for n, gg in agent.named_grads()}
+    loss_ref = ostep.agent_kl_loss(es, er, gs, gr)
+    ragent.zero_grad(); loss_ref.backward()
+    assert abs(float(loss) - float(loss_ref)) / max(1e-6, abs(float(loss_ref))) < 2e-3, (float(loss), float(loss_ref))
+    for n in ('fc_scale.weight', 'fc_scale.bias', 'fc_rotation.weight', 'fc_rotation.bias'):
+        _close(errs, 'grad ' + n, hip_grads[n], dict(ragent.named_parameters())[n].grad, 1e-2, 0.9999)
+    _close(errs, 'node-grad deep2', grd('deep2'), top.grad * (top.detach() > 0).float(), GRAD_TOL, GRAD_COS)
+
+    def block_bwd(blk, prefix, a_in, out_name, conv1_tol=(GRAD_TOL, GRAD_COS)):
+        a = _leaf(a_in)
+        a3 = bf16_emul.emul_residual(blk, a)
+        blk.zero_grad()
+        a3.backward(grd(out_name))
+        for n, p in blk.named_parameters():
+            full = prefix + n
+            if n.endswith('.bias') and 'bn' not in n and float(hip_grads[full].abs().max()) == 0.0:
+                continue
+            tol, cs = conv1_tol if n == 'conv1.weight' else (GRAD_TOL, GRAD_COS)
+            _close(errs, 'grad ' + full, hip_grads[full], p.grad, tol, cs)
+        return a.grad
+    c = block_bwd(ragent.deep_merge[2], 'deep_merge.2.', act('deep1'), 'deep2')
+    _close(errs, 'node-grad deep1', grd('deep1'), c * (act('deep1') > 0).float(), GRAD_TOL, GRAD_COS)
+    c = block_bwd(ragent.deep_merge[1], 'deep_merge.1.', act('deep0'), 'deep1')
+    _close(errs, 'node-grad deep0', grd('deep0'), c * (act('deep0') > 0).float(), GRAD_TOL, GRAD_COS)
+    c = block_bwd(ragent.deep_merge[0], 'deep_merge.0.', act('merge3'), 'deep0')
+    _close(errs, 'node-grad merge3', grd('merge3'), c * (act('merge3') > 0).float(), GRAD_TOL, GRAD_COS)
+    for k in (3, 2, 1, 0):
+        c = block_bwd(merges[k], 'merge%d.' % (k + 1), act('pa%d' % k), 'merge%d' % k)
+        _close(errs, 'node-grad pa%d' % k, grd('pa%d' % k), c, GRAD_TOL, GRAD_COS)
+        hi_name = 'in0' if k == 0 else 'merge%d' % (k - 1)
+        hi, lo = _leaf(act(hi_name)), _leaf(act('in%d' % (k + 1)))
+        (F.max_pool2d(hi, 2, 2) + lo).backward(grd('pa%d' % k))
+        _close(errs, 'node-grad ' + hi_name, grd(hi_name), hi.grad * (hi.detach() > 0).float(), GRAD_TOL, GRAD_COS)
+        _close(errs, 'node-grad in%d' % (k + 1), grd('in%d' % (k + 1)), lo.grad * (lo.detach() > 0).float(), GRAD_TOL, GRAD_COS)
+    names = ['residual_skip1.', 'residual_skip2.', 'residual_skip3.', 'residual_skip4.', 'residual_neck.']
+    # conv1 of the five input blocks: dW = sum_m g[m] * a[m] with g zero-mean per channel (BatchNorm backward) and
+    # `a` the pose net's all-positive features with a large mean -> the sum cancels almost completely, and the
+    # bf16 rounding of g (its instance differs between engine and emulation) is amplified by mean(a)/std(a)/corr.
+    # Ill-conditioned in ANY bf16 mixed-precision implementation; bounded here at 25 % / cosine 0.97.
+    for k in range(5):
+        block_bwd(in_blocks[k], names[k], feats[k], 'in%d' % k, conv1_tol=(0.25, 0.97))
+    assert not errs, '%d local mismatches, first: %s' % (len(errs), errs[:12])
+    assert float(net.flat_grads.abs().max()) == 0.0          # the features are detached: nothing reaches the pose net
+
+
+def test_joint_training_steps_run_and_learn():
+    """train_hg (regular / agent-augmented alternation) and train_agent_sr at the BASELINE batch size, finite and sane."""
+    from pose_adv_aug_amd.models.asn_stacked_hg import create_hg, create_asn
+    from pose_adv_aug_amd.utils.optim import RMSprop
+    from pose_adv_aug_amd.data import Augmenter, DeviceBatch
+    from pose_adv_aug_amd import joint_train_pose_s_r_agent as J
+    B = 8
+    hg = create_hg(2, 1, 16, 256, default_batch=B); hg.reset_parameters(seed=1)
+    agent = create_asn(256, 256, 7, 7, is_aug=True, default_batch=B); agent.reset_parameters(seed=2)
+    assert agent.num_params() == 2577934 and hg.num_params() == 6570784
+    opt_hg, opt_sr = RMSprop(hg, lr=2.5e-4), RMSprop(agent, lr=5e-5)
+    aug = Augmenter(seed=3)
+    batch = DeviceBatch.synthetic(B, seed=4)
+    kinds, losses = [], []
+    for i in range(4):
+        kind, loss, pckh = J.train_hg_step(i, hg, opt_hg, agent, aug, batch, seed=0)
+        kinds.append(kind); losses.append(float(loss))
+        assert np.isfinite(float(loss)) and 0.0 <= float(pckh) <= 1.0
+    assert kinds == ['regular', 'agent', 'regular', 'agent']
+    before = agent.flat_params.clone()
+    l = J.train_agent_sr(batch, hg, agent, opt_sr, aug, epoch_sr=0, seed=0)
+    assert np.isfinite(float(l)) and float(l) >= -1e-6          # a KL divergence
+    assert float((agent.flat_params - before).abs().max()) > 0  # the agent moved
+    assert bool(torch.isfinite(agent.flat_params).all()) and bool(torch.isfinite(hg.flat_params).all())
