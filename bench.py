@@ -141,8 +141,16 @@ def main():
         else:
             ach, peak, unit = dom['bytes'] / secs / 1e9, HBM_PEAK / 1e9, 'GB/s'
         conv_ms = sum(r['ms_total'] for r in rows) / args.steps
+        # HBM bytes per launch of that kernel class from the PMC counters (FETCH_SIZE x2 + WRITE_SIZE, collected in
+        # separate rocprofv3 --pmc passes by tools/prof_pmc.sh and committed under profiles/); null if not collected
+        traffic = None
+        pmc_path = os.path.join(ROOT, 'profiles', 'round1_pmc.json')
+        if os.path.isfile(pmc_path):
+            pmc = json.load(open(pmc_path))
+            if dom['kernel'] in pmc:
+                traffic = round(pmc[dom['kernel']]['hbm_bytes_per_launch'], 1)
         roofline = {'bound': bound, 'achieved': round(ach, 2), 'peak': peak, 'unit': unit, 'frac': round(ach / peak, 4),
-                    'traffic': None, 'kernel': dom['kernel'], 'avg_launch_us': round(dom['avg_us'], 2),
+                    'traffic': traffic, 'kernel': dom['kernel'], 'avg_launch_us': round(dom['avg_us'], 2),
                     'launches_per_step': dom['launches'] // args.steps,
                     'alg_bytes_per_launch': dom['bytes'] / dom['launches'], 'alg_flops_per_launch': dom['flops'] / dom['launches'],
                     'mfma_kernels_ms_per_step': round(conv_ms, 3),

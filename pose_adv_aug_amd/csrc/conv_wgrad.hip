@@ -20,9 +20,13 @@
 template <int TN, int TK, int PMODE, int QMODE, int TAPS, bool STEM = false>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(PaWgradArgs a) {
     constexpr int NI = TN / 32, KI = TK / 32;          // fragments per wave (wave tile TN/2 x TK/2)
-    __shared__ __attribute__((aligned(16))) bf16 lds[(TN + TK) * 64];
-    bf16* Pt = lds;                 // [TN][64 pixels]
-    bf16* Qt = lds + TN * 64;       // [TK][64 pixels]
+    // pixels per step: 64, or 128 for the 64x64 tile so that all 256 threads stage an 8x8 block each
+    constexpr int MS = (TN + TK <= 128) ? 128 : 64;
+    constexpr int MG = MS / 8;                         // 8-pixel groups per step
+    constexpr int NP = MG * TN / 8, NQ = MG * TK / 8;  // staging threads for P / Q
+    __shared__ __attribute__((aligned(16))) bf16 lds[(TN + TK) * MS];
+    bf16* Pt = lds;                 // [TN][MS pixels]
+    bf16* Qt = lds + TN * MS;       // [TK][MS pixels]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn = wave & 1, wk = wave >> 1;
@@ -35,15 +39,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(PaWgradArgs a) {
     const int nbase = blockIdx.z * TN;
     const int dy = (TAPS == 9) ? tap / 3 - 1 : 0, dx = (TAPS == 9) ? tap - (tap / 3) * 3 - 1 : 0;
 
-    const int steps_total = (M + 63) / 64;
+    const int steps_total = (M + MS - 1) / MS;
     const int steps_per = (steps_total + a.splits - 1) / a.splits;
     const int step0 = split * steps_per;
     const int step1 = min(step0 + steps_per, steps_total);
 
     // staging role of this thread: one 8x8 block of P (dy) or of Q (x)
-    const bool isP = tid < TN, isQ = !isP && tid < TN + TK;
-    const int bid = isP ? tid : tid - TN;
-    const int mg = bid & 7, cg = bid >> 3;
+    const bool isP = tid < NP, isQ = !isP && tid < NP + NQ;
+    const int bid = isP ? tid : tid - NP;
+    const int mg = bid % MG, cg = bid / MG;
     const int chan = isP ? nbase + cg * 8 : cbase + cg * 8;
     float k0[8], k1[8], k2[8];
 #pragma unroll
@@ -66,7 +70,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(PaWgradArgs a) {
 
     auto gload = [&](int step) {
         okmask = 0;
-        const int mfirst = step * 64 + mg * 8;
+        const int mfirst = step * MS + mg * 8;
         if (isP) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -153,7 +157,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(PaWgradArgs a) {
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             int row = cg * 8 + c;
-            *reinterpret_cast<bf16x8*>(T + row * 64 + ((mg ^ (row & 7)) << 3)) = o[c];
+            *reinterpret_cast<bf16x8*>(T + row * MS + ((mg ^ (row & (MG - 1))) << 3)) = o[c];
         }
     };
 
@@ -171,17 +175,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(PaWgradArgs a) {
         for (int step = step0; step < step1; ++step) {
             if (step + 1 < step1) gload(step + 1);
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
+            for (int kk = 0; kk < MS / 32; ++kk) {
                 bf16x8 fp[NI], fq[KI];
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni) {
                     int row = wn * (TN / 2) + ni * 16 + frow;
-                    fp[ni] = *reinterpret_cast<const bf16x8*>(Pt + row * 64 + (((fchk + 4 * kk) ^ (row & 7)) << 3));
+                    fp[ni] = *reinterpret_cast<const bf16x8*>(Pt + row * MS + (((fchk + 4 * kk) ^ (row & (MG - 1))) << 3));
                 }
 #pragma unroll
                 for (int ki = 0; ki < KI; ++ki) {
                     int row = wk * (TK / 2) + ki * 16 + frow;
-                    fq[ki] = *reinterpret_cast<const bf16x8*>(Qt + row * 64 + (((fchk + 4 * kk) ^ (row & 7)) << 3));
+                    fq[ki] = *reinterpret_cast<const bf16x8*>(Qt + row * MS + (((fchk + 4 * kk) ^ (row & (MG - 1))) << 3));
                 }
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni)
@@ -213,6 +217,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(PaWgradArgs a) {
         for (int c = 0; c < 8; ++c) {
             float s = colsum[c];
             s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+            if (MG == 16) s += __shfl_xor(s, 8, 64);
             if (mg == 0) a.dbpart[(size_t)split * a.Cout + chan + c] = s;
         }
     }
@@ -229,7 +234,8 @@ int pa_wgrad_splits(int M, int Cin, int Cout, int taps) {
     int TN, TK;
     tile_of(Cin, Cout, TN, TK);
     const int tiles = (Cout / TN) * (taps * Cin / TK);
-    const int steps_total = (M + 63) / 64;
+    const int ms = (TN + TK <= 128) ? 128 : 64;
+    const int steps_total = (M + ms - 1) / ms;
     // enough workgroups to keep every CU busy with several of them (measured on MI355X: 512 for the
     // 1x1 layers, 1024 for the 3x3 layers; PA_WGRAD_BLOCKS overrides for experiments)
     static int forced = -1;
