@@ -83,6 +83,7 @@ struct ResidualOp {
         n.bneval_jobs = a.get<PaBnEvalJob>(n.bns.size());
         in = n.new_act(a, B, H, W, C, nullptr, true);
         r.layout(n, a, B, H, W, true);
+        n.layout_shared(a);
         a.take(0);
         return a.off;
     }
@@ -135,6 +136,7 @@ struct ConvOp {
         n.layout_conv(c, a, B * H * W);
         xin = a.get<bf16>((size_t)B * H * W * c.pcin);
         yout = a.get<bf16>((size_t)B * H * W * c.pcout);
+        n.layout_shared(a);
         a.take(0);
         return a.off;
     }

@@ -175,6 +175,7 @@ size_t Net::layout_asn(char* base) {
     asn_logits = a.get<float>((size_t)B * (scale_num + rot_num));
     asn_probs = a.get<float>((size_t)B * (scale_num + rot_num));
     asn_dlogits = a.get<float>((size_t)B * (scale_num + rot_num));
+    layout_shared(a);
     a.take(0);
     return a.off;
 }

@@ -103,8 +103,22 @@ void Net::layout_conv(ConvLayer& c, Arena& a, int M) {
     c.wf = a.get<bf16>(wn);
     c.wb = (c.k == 7) ? nullptr : a.get<bf16>(wn);
     c.splits = pa_wgrad_splits(M, c.pcin, c.pcout, c.k == 7 ? 1 : c.taps());
-    c.part = a.get<float>((size_t)c.splits * wn);
-    c.dbpart = c.has_bn_after ? nullptr : a.get<float>((size_t)c.splits * c.pcout);
+    c.part_floats = (size_t)c.splits * wn;
+    c.db_floats = c.has_bn_after ? 0 : (size_t)c.splits * c.pcout;
+    if (immediate_reduce) {                   // shared slab: remember the largest request, bind after the layout pass
+        if (c.part_floats > shared_part_floats) shared_part_floats = c.part_floats;
+        if (c.db_floats > shared_db_floats) shared_db_floats = c.db_floats;
+        c.part = nullptr; c.dbpart = nullptr;
+    } else {
+        c.part = a.get<float>(c.part_floats);
+        c.dbpart = c.db_floats ? a.get<float>(c.db_floats) : nullptr;
+    }
+}
+
+void Net::layout_shared(Arena& a) {
+    if (!immediate_reduce) return;
+    shared_part = a.get<float>(shared_part_floats);
+    shared_db = a.get<float>(shared_db_floats > 0 ? shared_db_floats : 1);
 }
 
 void Net::layout_bn(BNLayer& b, Arena& a, int M) {
@@ -195,6 +209,7 @@ size_t Net::layout_all(char* base) {
         if (i == 0) xin[0] = res3.x3;
         if (i + 1 < stacks) xin[i + 1] = new_act(a, B, H4, H4, chan, nullptr, true);
     }
+    layout_shared(a);
     a.take(0);
     return a.off;
 }
@@ -203,6 +218,7 @@ int Net::upload_tables() {
     std::vector<PaPrepJob> pj; std::vector<PaWgradReduceJob> rj; std::vector<PaBnEvalJob> bj;
     prep_max = 0; red_max = 0;
     for (ConvLayer* c : convs) {
+        if (immediate_reduce) { c->part = shared_part; c->dbpart = c->db_floats ? shared_db : nullptr; }
         PaPrepJob p; p.w = params + c->p_w; p.wf = c->wf; p.wb = c->wb; p.Cout = c->Cout; p.Cin = c->Cin;
         p.taps = c->k == 7 ? 49 : c->taps(); p.pad_cout = c->pcout; p.pad_cin = c->pcin;
         pj.push_back(p);
@@ -211,6 +227,7 @@ int Net::upload_tables() {
         if (c->k == 7) continue;
         PaWgradReduceJob r; r.part = c->part; r.dst = grads + c->p_w; r.dbpart = c->dbpart; r.dbdst = grads + c->p_b;
         r.Cout = c->pcout; r.Cin = c->pcin; r.taps = c->taps(); r.splits = c->splits; r.real_cout = c->Cout; r.real_cin = c->Cin;
+        c->red_index = (int)rj.size();
         rj.push_back(r);
         int re = c->Cout * c->Cin * c->taps() + c->Cout;
         if (re > red_max) red_max = re;
@@ -338,7 +355,16 @@ int Net::conv_wgrad(ConvLayer& c, const PaOperand& dy, const PaOperand& x, int B
     ProfEntry* pe = prof.begin(c.k == 7 ? PA_PROF_STEM_WGRAD : (c.k == 3 ? PA_PROF_WGRAD3 : PA_PROF_WGRAD1), wb, wf, st);
     int rc = (c.k == 7) ? pa_launch_stem_wgrad(a, st) : pa_launch_wgrad(a, st);
     prof.end(pe, st);
-    return rc;
+    if (rc) return rc;
+    if (immediate_reduce) {
+        if (c.k == 7) {
+            TRY(pa_launch_stem_wgrad_reduce(c.part, c.splits, grads + c.p_w, st));
+            PA_CHECK(hipMemsetAsync(grads + c.p_b, 0, 64 * sizeof(float), st));
+        } else {
+            TRY(pa_launch_wgrad_reduce(red_jobs + c.red_index, 1, c.Cout * c.Cin * c.taps() + c.Cout, st));
+        }
+    }
+    return 0;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -512,6 +538,7 @@ int Net::backward_pose() {
 }
 
 int Net::reduce_grads() {
+    if (immediate_reduce) return 0;             // every layer was reduced right after its weight-gradient launch
     TRY(pa_launch_wgrad_reduce(red_jobs, n_red, red_max, st));
     if (!is_agent) {
         TRY(pa_launch_stem_wgrad_reduce(stem_conv.part, stem_conv.splits, grads + stem_conv.p_w, st));
