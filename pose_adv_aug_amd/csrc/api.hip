@@ -133,7 +133,7 @@ struct ConvOp {
     size_t build(int B, int H, int W, char* base) {
         Arena a; a.base = base;
         n.prep_jobs = a.get<PaPrepJob>(1); n.red_jobs = a.get<PaWgradReduceJob>(1); n.bneval_jobs = a.get<PaBnEvalJob>(1);
-        n.layout_conv(c, a, B * H * W);
+        n.layout_conv(c, a, B * H * W, H, W);
         xin = a.get<bf16>((size_t)B * H * W * c.pcin);
         yout = a.get<bf16>((size_t)B * H * W * c.pcout);
         n.layout_shared(a);

@@ -19,6 +19,7 @@
 // one pixel (8-byte bf16x4 stores, per-channel reductions over the 16 pixel lanes by DPP shuffles).
 #include "common.h"
 #include "kernels.h"
+#include "conv_epilogue.h"
 
 // STEM: the A operand is the 4-channel-padded input image and the kernel computes the 7x7 stride-2
 // stem conv (reference models/asn_stacked_hg.py:223) as a K=256 GEMM: k = ky*32 + kx*4 + c, i.e. one
@@ -188,86 +189,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(PaConvArgs a) {
         }
     }
 
-    // ---------------------------------------------------------------- epilogue
-    // Thanks to the weight-row permutation (lstore) a lane owns 4*NI CONSECUTIVE output channels of one
-    // pixel: all epilogue traffic (addends, xref, stores) is 16-byte accesses, 32 B (NI=2) or 64..128 B
-    // (NI=4) contiguous per pixel row across the four lane groups.
-    const int N = a.Cout;
-    constexpr int CH = NI / 2;                       // 8-channel chunks per lane
-    const int nb = n0 + wn * (BN / 2) + (lane >> 4) * (4 * NI);
-    float s1[NI][4], s2[NI][4];
-#pragma unroll
-    for (int ch = 0; ch < CH; ++ch) {               // chunk-outer / pixel-inner keeps the per-channel constants short-lived
-        const int n = nb + 8 * ch;
-        float bias[8], es[8], et[8], emu[8], eis[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            s1[2 * ch + (j >> 2)][j & 3] = 0.f; s2[2 * ch + (j >> 2)][j & 3] = 0.f;
-            bias[j] = a.bias ? a.bias[n + j] : 0.f;
-            if (a.ep.mode == PA_OUT_BWD) {
-                es[j] = a.ep.scale[n + j]; et[j] = a.ep.shift[n + j]; emu[j] = a.ep.mean[n + j]; eis[j] = a.ep.invstd[n + j];
-            }
-        }
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-            const int m = m0 + wm * (BM / 2) + mi * 16 + (lane & 15);
-            if (m >= M) continue;
-            const size_t idx = (size_t)m * N + n;
-            float e1[8], e2[8];
-            pa_read8(a.add1, idx, n, e1);
-            pa_read8(a.add2, idx, n, e2);
-            bf16x8 o;
-            if (a.ep.mode == PA_OUT_BWD) {
-                bf16x8 xr = *reinterpret_cast<const bf16x8*>(a.ep.xref + idx);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int ni = 2 * ch + (j >> 2);
-                    float v = acc[ni][mi][j & 3] + bias[j] + e1[j] + e2[j];
-                    float x = (float)xr[j];
-                    float dz = (fmaf(es[j], x, et[j]) > 0.f) ? v : 0.f;
-                    o[j] = (bf16)dz;
-                    float dzr = (float)o[j];
-                    s1[ni][j & 3] += dzr;
-                    s2[ni][j & 3] += dzr * (x - emu[j]) * eis[j];
-                }
-            } else {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int ni = 2 * ch + (j >> 2);
-                    float v = acc[ni][mi][j & 3] + bias[j] + e1[j] + e2[j];
-                    o[j] = (bf16)v;
-                    float rv = (float)o[j];
-                    s1[ni][j & 3] += rv;
-                    s2[ni][j & 3] += rv * rv;
-                }
-            }
-            *reinterpret_cast<bf16x8*>(a.out + idx) = o;
-        }
-    }
-    if (a.ep.mode != PA_OUT_PLAIN) {
-        // per-workgroup partial row of the two per-channel reductions: no atomics (a float atomicAdd per
-        // channel per wave cost 6-10x the whole conv); the BatchNorm finalize kernel sums the rows.
-        float* red = reinterpret_cast<float*>(lds);          // [2 (wm)][BN][2]; the operand tiles are dead here
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float x1 = s1[ni][j], x2 = s2[ni][j];
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) { x1 += __shfl_xor(x1, o, 64); x2 += __shfl_xor(x2, o, 64); }
-                if ((lane & 15) == 0) {
-                    const int col = wn * (BN / 2) + (lane >> 4) * (4 * NI) + 4 * ni + j;
-                    red[(wm * BN + col) * 2] = x1;
-                    red[(wm * BN + col) * 2 + 1] = x2;
-                }
-            }
-        }
-        __syncthreads();
-        for (int c = tid; c < BN; c += 256) {
-            f32x2 v = {red[c * 2] + red[(BN + c) * 2], red[c * 2 + 1] + red[(BN + c) * 2 + 1]};
-            *reinterpret_cast<f32x2*>(a.ep.stats + ((size_t)blockIdx.x * N + n0 + c) * 2) = v;
-        }
-    }
+    // ---------------------------------------------------------------- epilogue (conv_epilogue.h)
+    pa_conv_epilogue<BN, NI, MI>(a, acc, n0, wm, wn,
+                                 [&](int mi) { const int m = m0 + wm * (BM / 2) + mi * 16 + (lane & 15); return m < M ? m : -1; },
+                                 reinterpret_cast<float*>(lds), (int)blockIdx.x);
 }
 
 template <int BM, int BN, int TAPS>
@@ -304,6 +229,12 @@ int pa_launch_conv(const PaConvArgs& a, hipStream_t st, int* stat_rows) {
         pa_set_error_msg("pa_launch_conv: channel counts must be multiples of 64 and taps 1 or 9");
         return 1;
     }
+    static int old3 = -1;
+    if (old3 < 0) old3 = getenv("PA_CONV3_OLD") ? 1 : 0;          // experiments: force the generic kernel
+    if (!old3 && pa_conv3x3_tile_supported(a)) return pa_launch_conv3x3_tile(a, st, stat_rows);
+    static int old1 = -1;
+    if (old1 < 0) old1 = getenv("PA_CONV1_OLD") ? 1 : 0;
+    if (!old1 && pa_conv1x1_tile_supported(a)) return pa_launch_conv1x1_tile(a, st, stat_rows);
     const int M = a.B * a.H * a.W;
     // small problems get the 64-row tile so that the grid still covers the 256 CUs
     const bool bigM = M >= 128 * 256;

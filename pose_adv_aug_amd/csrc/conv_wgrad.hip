@@ -225,14 +225,25 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(PaWgradArgs a) {
 
 static int round_up8(int v) { return (v + 7) & ~7; }
 
-static void tile_of(int Cin, int Cout, int& TN, int& TK) {
+static void tile_of(int Cin, int Cout, int taps, int& TN, int& TK) {
     TN = (Cout % 128 == 0) ? 128 : 64;
     TK = (Cin % 128 == 0) ? 128 : 64;
+    static int t1 = -1, t9 = -1;
+    if (t1 < 0) { const char* e = getenv("PA_WGRAD_TILE1"); t1 = e ? atoi(e) : 0; }
+    if (t9 < 0) { const char* e = getenv("PA_WGRAD_TILE9"); t9 = e ? atoi(e) : 0; }
+    const int f = taps == 1 ? t1 : t9;       // experiments: 1 = 64x64, 2 = 128x64, 3 = 64x128
+    if (f == 1) { TN = 64; TK = 64; }
+    if (f == 2) { TK = 64; }
+    if (f == 3) { TN = 64; }
 }
 
-int pa_wgrad_splits(int M, int Cin, int Cout, int taps) {
+int pa_wgrad_splits(int M, int H, int W, int Cin, int Cout, int taps) {
+    if (H > 0 && W > 0 && M % (H * W) == 0) {
+        const int ts = pa_wgrad_tile_splits(M / (H * W), H, W, Cin, Cout, taps);
+        if (ts > 0) return ts;
+    }
     int TN, TK;
-    tile_of(Cin, Cout, TN, TK);
+    tile_of(Cin, Cout, taps, TN, TK);
     const int tiles = (Cout / TN) * (taps * Cin / TK);
     const int ms = (TN + TK <= 128) ? 128 : 64;
     const int steps_total = (M + ms - 1) / ms;
@@ -281,8 +292,10 @@ int pa_launch_wgrad(const PaWgradArgs& a, hipStream_t st) {
         pa_set_error_msg("pa_launch_wgrad: channel counts must be multiples of 64, taps 1 or 9, splits >= 1");
         return 1;
     }
+    const int rc = pa_launch_wgrad_tile(a, st);
+    if (rc >= 0) return rc;
     int TN, TK;
-    tile_of(a.Cin, a.Cout, TN, TK);
+    tile_of(a.Cin, a.Cout, a.taps, TN, TK);
     dim3 grid(a.splits, a.taps * a.Cin / TK, a.Cout / TN);
     if (TN == 128 && TK == 128) launch_w_modes<128, 128>(a, grid, st);
     else if (TN == 128) launch_w_modes<128, 64>(a, grid, st);

@@ -1,0 +1,292 @@
+// Weight gradients of the 1x1 / 3x3 convolutions, TILE version (gfx950):
+//
+//   dw[n][tap][c] = sum_p dy[p][n] * x[p + tap][c]
+//
+// The reduction index is the pixel, the slow index of both NHWC operands.  conv_wgrad.hip transposes
+// 8x8 blocks in registers while staging (VALU bound) and re-loads/re-transforms both operands for each
+// of the 9 taps.  Here
+//   * both operand tiles are staged in their NATURAL [pixel][channel] layout (one coalesced 16-byte load
+//     and one ds_write_b128 per chunk, transform applied once) and the MFMA fragments -- 8 consecutive
+//     PIXELS of one channel per lane -- are read with ds_read_b64_tr_b16, the LDS transpose read of gfx950;
+//   * for the 3x3 layers a workgroup stages the 8x16-pixel dy tile and the 10x18 halo of x ONCE and
+//     accumulates all 9 taps from them (9 x fewer dy loads, 6.4 x fewer x loads and transforms);
+//   * a workgroup owns a (n-block, c-block) of the gradient for ALL taps in registers and walks over
+//     many pixel tiles before it writes its fp32 partial slab once (same slab layout / reducer as
+//     conv_wgrad.hip: part[split][n][tap*Cin + c]).
+// LDS images: [pixel][CH] bf16 rows; the 32-byte granule (16 channels = what 4 lanes of a transpose read
+// fetch) is XOR-swizzled with pixel bits (0,1,3) [CH = 128] or (1,3) [CH = 64], which makes the 8 pixel
+// rows touched by a 32-lane half of ds_read_b64_tr_b16 fall into 8 distinct bank groups for any tap shift.
+#include "common.h"
+#include "kernels.h"
+#include <stdlib.h>
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+template <int CH>
+__device__ __forceinline__ int wg_sw(int p) {
+    return CH == 128 ? ((p & 3) | ((p >> 1) & 4)) : (((p >> 1) & 1) | ((p >> 2) & 2));
+}
+
+// fragment: lane l receives 8 consecutive pixels (p0 .. p0+7, p0 = base + 8*(l>>4)) of channel 16*gran + (l&15)
+template <int CH, class PixFn>
+__device__ __forceinline__ bf16x8 wg_tr_frag(const bf16* tile, int gran, PixFn pix) {
+    const int l = threadIdx.x & 63;
+    s16x4 h[2];
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+        const int p = pix(8 * (l >> 4) + 4 * hh + ((l & 15) >> 2));
+        const bf16* ptr = tile + p * CH + ((gran ^ wg_sw<CH>(p)) << 4) + 4 * (l & 3);
+        h[hh] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ptr));
+    }
+    s16x8 v = __builtin_shufflevector(h[0], h[1], 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+// NF/CF: 16-channel fragments per wave along n / c; WNW waves along n (4/WNW along c)
+template <int TAPS, int NF, int CF, int WNW, int PMODE, int QMODE, bool DB>
+__global__ __launch_bounds__(256, 2) void wgrad_tile_kernel(PaWgradArgs a, int ntiles) {
+    constexpr int WCW = 4 / WNW;
+    constexpr int NB = 16 * NF * WNW, CB = 16 * CF * WCW;
+    constexpr int PW = 18, HP = TAPS == 9 ? 180 : 128;
+    constexpr int CPN = NB / 8, CPC = CB / 8;                   // 16-byte chunks per row
+    constexpr int PASS_N = 128 * CPN / 256;                     // dy chunks per thread
+    constexpr int PASS_C = (HP * CPC + 255) / 256;              // x chunks per thread
+    __shared__ __attribute__((aligned(16))) bf16 lds[128 * NB + HP * CB];
+    bf16* dyT = lds;
+    bf16* xT = lds + 128 * NB;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave % WNW, wc = wave / WNW;
+    const int split = blockIdx.x, S = gridDim.x;
+    const int n0 = blockIdx.y * NB, c0 = blockIdx.z * CB;
+    const int M = a.B * a.H * a.W;
+    const int tiles_x = TAPS == 9 ? a.W / 16 : 1, tiles_y = TAPS == 9 ? a.H / 8 : 1;
+    const int Kfull = TAPS * a.Cin;
+
+    // a thread always handles the same channel chunk; its transform constants are re-read per tile
+    // (L1 hits) so that they are not live across the MFMA section
+    const int nchunk = tid % CPN, cchunk = tid % CPC;
+    const bool want_db = DB && a.dbpart != nullptr && blockIdx.z == 0;
+    float colsum[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) colsum[j] = 0.f;
+
+    f32x4 acc[TAPS][CF][NF];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int cf = 0; cf < CF; ++cf)
+#pragma unroll
+            for (int f = 0; f < NF; ++f) acc[t][cf][f] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int tile = split; tile < ntiles; tile += S) {
+        int b = 0, y0 = 0, x0 = 0;
+        if (TAPS == 9) {
+            int t = tile;
+            x0 = (t % tiles_x) * 16; t /= tiles_x;
+            y0 = (t % tiles_y) * 8;
+            b = t / tiles_y;
+        }
+        if (tile != split) __syncthreads();          // the previous tile's fragments have been read
+        // ---- dy tile [128][NB]
+        {
+            bf16x8 rp[PASS_N], rq[PASS_N];
+            bool ok[PASS_N];
+            float pk0[8], pk1[8], pk2[8];
+            if (PMODE == PA_LD_LIN2) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    pk0[j] = a.dy.k0[n0 + nchunk * 8 + j]; pk1[j] = a.dy.k1[n0 + nchunk * 8 + j]; pk2[j] = a.dy.k2[n0 + nchunk * 8 + j];
+                }
+            }
+            // 3x3: 144 accumulator registers are live -> stage in batches of 2 loads (+2 for LIN2's second operand)
+            constexpr int UNP = TAPS == 9 ? 2 : PASS_N;
+#pragma unroll
+            for (int u0 = 0; u0 < PASS_N; u0 += UNP) {
+#pragma unroll
+                for (int v = 0; v < UNP; ++v) {
+                    const int u = u0 + v;
+                    const int r = u * (256 / CPN) + tid / CPN;
+                    int m;
+                    if (TAPS == 9) { m = (b * a.H + y0 + (r >> 4)) * a.W + x0 + (r & 15); ok[u] = true; }
+                    else { m = tile * 128 + r; ok[u] = m < M; }
+                    const size_t idx = ok[u] ? (size_t)m * a.Cout + n0 + nchunk * 8 : 0;      // clamped, unconditional
+                    rp[u] = *reinterpret_cast<const bf16x8*>(a.dy.p + idx);
+                    if (PMODE == PA_LD_LIN2) rq[u] = *reinterpret_cast<const bf16x8*>(a.dy.q + idx);
+                }
+#pragma unroll
+                for (int v = 0; v < UNP; ++v) {
+                    const int u = u0 + v;
+                    const int r = u * (256 / CPN) + tid / CPN;
+                    bf16x8 o;
+                    if (PMODE == PA_LD_LIN2) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) o[j] = (bf16)fmaf(pk0[j], (float)rp[u][j], fmaf(pk1[j], (float)rq[u][j], pk2[j]));
+                    } else {
+                        o = rp[u];
+                    }
+                    if (!ok[u]) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) o[j] = (bf16)0.f;
+                    }
+                    if (DB && want_db) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) colsum[j] += (float)o[j];
+                    }
+                    *reinterpret_cast<bf16x8*>(dyT + r * NB + (((nchunk >> 1) ^ wg_sw<NB>(r)) << 4) + (nchunk & 1) * 8) = o;
+                }
+            }
+        }
+        // ---- x tile / halo [HP][CB]
+        {
+            bf16x8 rx[PASS_C];
+            bool ok[PASS_C];
+            float qk0[8], qk1[8];
+            if (QMODE == PA_LD_BNRELU) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { qk0[j] = a.x.k0[c0 + cchunk * 8 + j]; qk1[j] = a.x.k1[c0 + cchunk * 8 + j]; }
+            }
+#pragma unroll
+            for (int u = 0; u < PASS_C; ++u) {
+                const int hp = u * (256 / CPC) + tid / CPC;
+                int m;
+                if (TAPS == 9) {
+                    const int hy = hp / PW, hx = hp - hy * PW;
+                    const int y = y0 + hy - 1, x = x0 + hx - 1;
+                    ok[u] = hp < HP && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
+                    m = (b * a.H + y) * a.W + x;
+                } else { m = tile * 128 + hp; ok[u] = m < M; }
+                const size_t idx = ok[u] ? (size_t)m * a.Cin + c0 + cchunk * 8 : 0;
+                rx[u] = *reinterpret_cast<const bf16x8*>(a.x.p + idx);
+            }
+#pragma unroll
+            for (int u = 0; u < PASS_C; ++u) {
+                const int hp = u * (256 / CPC) + tid / CPC;
+                if (hp < HP) {
+                    bf16x8 o;
+                    if (QMODE == PA_LD_BNRELU) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) o[j] = (bf16)fmaxf(fmaf(qk0[j], (float)rx[u][j], qk1[j]), 0.f);
+                    } else {
+                        o = rx[u];
+                    }
+                    if (!ok[u]) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) o[j] = (bf16)0.f;
+                    }
+                    *reinterpret_cast<bf16x8*>(xT + hp * CB + (((cchunk >> 1) ^ wg_sw<CB>(hp)) << 4) + (cchunk & 1) * 8) = o;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- MFMA: 4 steps of 32 pixels
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            bf16x8 fd[NF];
+#pragma unroll
+            for (int f = 0; f < NF; ++f) fd[f] = wg_tr_frag<NB>(dyT, wn * NF + f, [&](int kl) { return 32 * ks + kl; });
+#pragma unroll
+            for (int t = 0; t < TAPS; ++t) {
+                const int dy = TAPS == 9 ? t / 3 - 1 : 0, dx = TAPS == 9 ? t % 3 - 1 : 0;
+#pragma unroll
+                for (int cf = 0; cf < CF; ++cf) {
+                    bf16x8 fx = wg_tr_frag<CB>(xT, wc * CF + cf, [&](int kl) {
+                        return TAPS == 9 ? (2 * ks + (kl >> 4) + 1 + dy) * PW + (kl & 15) + 1 + dx : 32 * ks + kl;
+                    });
+#pragma unroll
+                    for (int f = 0; f < NF; ++f)
+                        acc[t][cf][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fx, fd[f], acc[t][cf][f], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // ---- partial slab part[split][n][tap*Cin + c]: D rows = c (4 consecutive per lane), columns = n
+    float* slab = a.part + (size_t)split * a.Cout * Kfull;
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+        const int n = n0 + (wn * NF + f) * 16 + (lane & 15);
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+            for (int cf = 0; cf < CF; ++cf) {
+                const int c = c0 + (wc * CF + cf) * 16 + (lane >> 4) * 4;
+                *reinterpret_cast<f32x4*>(slab + (size_t)n * Kfull + t * a.Cin + c) = acc[t][cf][f];
+            }
+    }
+    if (DB && want_db) {
+        // column sums of dy: threads with the same chunk (tid % CPN) hold partial sums over their rows
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(lds);          // [256][8]
+#pragma unroll
+        for (int j = 0; j < 8; ++j) red[tid * 8 + j] = colsum[j];
+        __syncthreads();
+        if (tid < NB) {
+            const int ch = tid >> 3, j = tid & 7;
+            float s = 0.f;
+            for (int r = ch; r < 256; r += CPN) s += red[r * 8 + j];
+            a.dbpart[(size_t)split * a.Cout + n0 + tid] = s;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+struct WgTileCfg { int nb, cb, ntiles, splits; };
+
+static bool wg_tile_cfg(int B, int H, int W, int Cin, int Cout, int taps, WgTileCfg& c) {
+    static int off = -1, target1 = 0, target9 = 0;
+    if (off < 0) {
+        off = getenv("PA_WGRAD_OLD") ? 1 : 0;
+        const char* e = getenv("PA_WGRAD_WGS1"); target1 = e ? atoi(e) : 512;
+        e = getenv("PA_WGRAD_WGS9"); target9 = e ? atoi(e) : 512;
+    }
+    if (off || H <= 0 || W <= 0) return false;
+    const int M = B * H * W;
+    if (taps == 9) {
+        if (Cin % 64 || Cout % 64 || H % 8 || W % 16) return false;
+        c.nb = 64; c.cb = 64; c.ntiles = B * (H / 8) * (W / 16);
+        if (c.ntiles < 48) return false;
+    } else if (taps == 1) {
+        if (Cin % 64 || Cout % 64) return false;
+        c.nb = Cout % 128 == 0 ? 128 : 64; c.cb = Cin % 128 == 0 ? 128 : 64; c.ntiles = (M + 127) / 128;
+        if (c.ntiles < 96) return false;
+    } else return false;
+    const int types = (Cout / c.nb) * (Cin / c.cb);
+    int s = (taps == 9 ? target9 : target1) / types;
+    if (s < 1) s = 1;
+    if (s > c.ntiles) s = c.ntiles;
+    const int per = (c.ntiles + s - 1) / s;          // tiles per workgroup
+    c.splits = (c.ntiles + per - 1) / per;           // balanced
+    return true;
+}
+
+int pa_wgrad_tile_splits(int B, int H, int W, int Cin, int Cout, int taps) {
+    WgTileCfg c;
+    return wg_tile_cfg(B, H, W, Cin, Cout, taps, c) ? c.splits : 0;
+}
+
+template <int TAPS, int NF, int CF, int WNW>
+static void launch_wt_modes(const PaWgradArgs& a, dim3 grid, int ntiles, hipStream_t st) {
+    const bool lin2 = a.dy.mode == PA_LD_LIN2, bnrelu = a.x.mode == PA_LD_BNRELU;
+    constexpr bool DB = TAPS == 1;          // bias gradients: only convs without a BatchNorm behind them (all 1x1 here)
+    if (lin2 && bnrelu) hipLaunchKernelGGL((wgrad_tile_kernel<TAPS, NF, CF, WNW, PA_LD_LIN2, PA_LD_BNRELU, DB>), grid, dim3(256), 0, st, a, ntiles);
+    else if (lin2) hipLaunchKernelGGL((wgrad_tile_kernel<TAPS, NF, CF, WNW, PA_LD_LIN2, PA_LD_PLAIN, DB>), grid, dim3(256), 0, st, a, ntiles);
+    else if (bnrelu) hipLaunchKernelGGL((wgrad_tile_kernel<TAPS, NF, CF, WNW, PA_LD_PLAIN, PA_LD_BNRELU, DB>), grid, dim3(256), 0, st, a, ntiles);
+    else hipLaunchKernelGGL((wgrad_tile_kernel<TAPS, NF, CF, WNW, PA_LD_PLAIN, PA_LD_PLAIN, DB>), grid, dim3(256), 0, st, a, ntiles);
+}
+
+// returns -1 when the shape is not handled here (caller falls back to conv_wgrad.hip)
+int pa_launch_wgrad_tile(const PaWgradArgs& a, hipStream_t st) {
+    WgTileCfg c;
+    if (!wg_tile_cfg(a.B, a.H, a.W, a.Cin, a.Cout, a.taps, c) || c.splits != a.splits) return -1;
+    if (a.taps == 9 && a.dbpart) return -1;
+    dim3 grid(c.splits, a.Cout / c.nb, a.Cin / c.cb);
+    if (a.taps == 9) launch_wt_modes<9, 4, 1, 1>(a, grid, c.ntiles, st);
+    else if (c.nb == 128 && c.cb == 128) launch_wt_modes<1, 4, 4, 2>(a, grid, c.ntiles, st);
+    else if (c.nb == 128) launch_wt_modes<1, 4, 2, 2>(a, grid, c.ntiles, st);
+    else if (c.cb == 128) launch_wt_modes<1, 2, 4, 2>(a, grid, c.ntiles, st);
+    else launch_wt_modes<1, 2, 2, 2>(a, grid, c.ntiles, st);
+    return (int)hipGetLastError();
+}

@@ -14,6 +14,12 @@ struct PaConvArgs {
 };
 // stat_rows (optional) receives the number of partial-statistics rows the launch writes (= grid.x)
 int pa_launch_conv(const PaConvArgs& a, hipStream_t st, int* stat_rows = nullptr);
+// halo-tile 3x3 kernel (conv3x3_tile.hip); pa_launch_conv dispatches to it when the shape is supported
+bool pa_conv3x3_tile_supported(const PaConvArgs& a);
+int pa_launch_conv3x3_tile(const PaConvArgs& a, hipStream_t st, int* stat_rows = nullptr);
+// row-tile 1x1 kernel (conv1x1_tile.hip), same dispatch rule
+bool pa_conv1x1_tile_supported(const PaConvArgs& a);
+int pa_launch_conv1x1_tile(const PaConvArgs& a, hipStream_t st, int* stat_rows = nullptr);
 // upper bound of stat rows any conv / elementwise launch writes for a tensor with M pixels
 inline int pa_max_stat_rows(int M) { int r = (M + 63) / 64; return r < 512 ? 512 : r; }
 
@@ -28,7 +34,11 @@ struct PaWgradArgs {
     int B, H, W, Cin, Cout, taps, splits;
 };
 int pa_launch_wgrad(const PaWgradArgs& a, hipStream_t st);
-int pa_wgrad_splits(int M, int Cin, int Cout, int taps);
+// H, W = 0: spatial shape unknown (generic kernel only)
+int pa_wgrad_splits(int M, int H, int W, int Cin, int Cout, int taps);
+// tile kernels (conv_wgrad_tile.hip): 0 / -1 = shape not handled there
+int pa_wgrad_tile_splits(int B, int H, int W, int Cin, int Cout, int taps);
+int pa_launch_wgrad_tile(const PaWgradArgs& a, hipStream_t st);
 
 // reduce partial slabs into the fp32 gradient in PyTorch layout  dst[n][c][tap]  (real_cin/real_cout
 // select the un-padded sub-block for the 16-channel head layers)

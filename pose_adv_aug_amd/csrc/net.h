@@ -152,7 +152,7 @@ struct Net {
     size_t add_buffer(const std::string& name, int C);
     void declare_conv(ConvLayer& c, const std::string& name, int cin, int cout, int k, bool bn_after);
     void declare_bn(BNLayer& b, const std::string& name, int C);
-    void layout_conv(ConvLayer& c, Arena& a, int M);
+    void layout_conv(ConvLayer& c, Arena& a, int M, int H = 0, int W = 0);
     void layout_bn(BNLayer& b, Arena& a, int M);
     void layout_shared(Arena& a);                  // call last in every layout pass
     Act new_act(Arena& a, int B, int H, int W, int C, BNLayer* bn, bool need_grad);

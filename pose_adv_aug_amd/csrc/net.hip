@@ -98,11 +98,16 @@ void Net::declare_pose() {
 
 // ------------------------------------------------------------------------------------------------
 // workspace layout
-void Net::layout_conv(ConvLayer& c, Arena& a, int M) {
+void Net::layout_conv(ConvLayer& c, Arena& a, int M, int H, int W) {
+    if (H <= 0 && B > 0) {                     // the net's own layers are square maps
+        const int hw = M / B;
+        int h = 1; while (h * h < hw) ++h;
+        if (h * h == hw && hw * B == M) H = W = h;
+    }
     const size_t wn = (size_t)c.pcout * (c.k == 7 ? 1 : c.taps()) * c.pcin;
     c.wf = a.get<bf16>(wn);
     c.wb = (c.k == 7) ? nullptr : a.get<bf16>(wn);
-    c.splits = pa_wgrad_splits(M, c.pcin, c.pcout, c.k == 7 ? 1 : c.taps());
+    c.splits = c.k == 7 ? pa_wgrad_splits(M, 0, 0, c.pcin, c.pcout, 1) : pa_wgrad_splits(M, H, W, c.pcin, c.pcout, c.taps());
     c.part_floats = (size_t)c.splits * wn;
     c.db_floats = c.has_bn_after ? 0 : (size_t)c.splits * c.pcout;
     if (immediate_reduce) {                   // shared slab: remember the largest request, bind after the layout pass
