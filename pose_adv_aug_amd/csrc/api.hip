@@ -152,7 +152,8 @@ int pa_conv2d(int mode, const float* a_in, const float* b_in, const float* w, co
     g_err[0] = 0;
     if (Cin % 64 || Cout % 64 || (k != 1 && k != 3)) { pa_set_error_msg("pa_conv2d: channels % 64 == 0, k in {1,3}"); return 1; }
     ConvOp op; Net& n = op.n; n.is_agent = true; n.B = B; n.st = ST(s);
-    n.declare_conv(op.c, "c", Cin, Cout, k, false);
+    // mode 2 without out2: no bias gradient wanted (the case of every conv in front of a BatchNorm)
+    n.declare_conv(op.c, "c", Cin, Cout, k, mode == 2 && out2 == nullptr);
     op.build(B, H, W, reinterpret_cast<char*>(ws));
     // parameter block: [weight | bias] as declared
     float* pbuf = nullptr; float* gbuf = nullptr;

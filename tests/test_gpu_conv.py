@@ -17,7 +17,7 @@ def rel_rms(a, b):
     return float((a - b).pow(2).mean().sqrt() / (b.pow(2).mean().sqrt() + 1e-30))
 
 
-def run_conv(mode, a, b, w, bias, B, Cin, Cout, H, W, k):
+def run_conv(mode, a, b, w, bias, B, Cin, Cout, H, W, k, want_db=True):
     from pose_adv_aug_amd._lib import lib, check, ptr, stream
     L = lib()
     ws = torch.zeros(L.pa_conv2d_workspace_bytes(B, Cin, Cout, H, W, k), dtype=torch.uint8, device='cuda')
@@ -26,7 +26,7 @@ def run_conv(mode, a, b, w, bias, B, Cin, Cout, H, W, k):
     elif mode == 1:
         out = torch.empty((B, Cin, H, W), device='cuda'); out2 = None
     else:
-        out = torch.empty((Cout, Cin, k, k), device='cuda'); out2 = torch.empty(Cout, device='cuda')
+        out = torch.empty((Cout, Cin, k, k), device='cuda'); out2 = torch.empty(Cout, device='cuda') if want_db else None
     # keep the device copies alive across the call (a temporary's block would be recycled by the allocator)
     ad = a.cuda().contiguous(); bd = b.cuda().contiguous() if b is not None else None
     wd = w.cuda().contiguous(); biasd = bias.cuda() if bias is not None else None
@@ -45,6 +45,13 @@ SHAPES = [
     (3, 64, 64, 6, 10, 3),       # ragged M, non-square
     (24, 128, 256, 64, 64, 1),   # full-size expand conv: M = 98304 -> 128x128 tiles
     (24, 128, 128, 64, 64, 3),   # full-size 3x3 (BASELINE config 2 shape)
+    # shapes that select the tile kernels (conv3x3_tile.hip: H % 8 == 0, W % 16 == 0; conv_wgrad_tile.hip: >= 48 / 96 tiles)
+    (6, 128, 128, 32, 32, 3),    # 48 halo tiles, 128 channels
+    (8, 64, 128, 32, 48, 3),     # non-square, Cin != Cout, 96 tiles
+    (3, 128, 64, 16, 32, 3),     # 12 tiles: tile forward/dgrad, generic wgrad
+    (3, 256, 128, 64, 64, 1),    # 96 row tiles of 128 pixels
+    (3, 64, 128, 65, 63, 1),     # ragged M = 12285 -> last row tile partly empty
+    (4, 64, 64, 64, 64, 1),      # 64-channel blocks on both sides
 ]
 
 
@@ -83,3 +90,6 @@ def test_conv_wgrad(B, Cin, Cout, H, W, k):
     F.conv2d(xr, wr, br, padding=k // 2).backward(dyr)
     assert rel_rms(dw, wr.grad) < 1e-4
     assert rel_rms(db, br.grad) < 1e-4
+    # without the bias gradient (every conv in front of a BatchNorm): the 3x3 tile kernel takes this path
+    dw2, _ = run_conv(2, dy, x, w, None, B, Cin, Cout, H, W, k, want_db=False)
+    assert rel_rms(dw2, wr.grad) < 1e-4
