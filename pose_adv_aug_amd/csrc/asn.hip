@@ -183,6 +183,7 @@ size_t Net::layout_asn(char* base) {
 // stem + the down path of hg[0]: everything the agent reads (reference :300-304 with is_half_hg)
 int Net::forward_half(const float* img_nchw, const bf16* img4_in, bool train) {
     train_bn = train;
+    TRY(ensure_streams());
     TRY(begin_step());
     if (!train) TRY(pa_launch_bn_eval(bneval_jobs, n_bneval, eps, st));
     const bf16* image = img4_in ? img4_in : img4;
@@ -193,7 +194,10 @@ int Net::forward_half(const float* img_nchw, const bf16* img4_in, bool train) {
     TRY(pa_launch_maxpool_fwd(op(res1.x3), pool0.raw, B, res / 2, res / 2, 128, st));
     TRY(res2.fwd(*this, pool0));
     TRY(res3.fwd(*this, res2.x3));
-    return hg[0].encode(*this, xin[0]);
+    TRY(hg[0].encode(*this, xin[0]));
+    if (multi_stream)                      // no decoder here: join the skip branches before anyone reads them
+        for (int k = 0; k < 4; ++k) TRY(wait_join(k));
+    return 0;
 }
 
 int Net::asn_forward(Net& pose, bool train, float* logits_s, float* logits_r) {

@@ -9,26 +9,41 @@
 // ------------------------------------------------------------------------------------------------
 // BatchNorm bookkeeping (reference semantics: torch.nn.BatchNorm2d, eps 1e-5, momentum 0.1,
 // biased variance for normalisation, unbiased for the running estimate).
-// Sum `rows` partial rows [rows][C][2] for the 32 channels of this workgroup: 1024 threads =
-// 32 channels x 32 row slices, float2 loads, LDS tree over the slices.  Result in LDS sums[32][2].
+// Sum `rows` partial rows [rows][C][2] for the FC channels of this workgroup: 1024 threads =
+// FC channels x (1024/FC) row slices, float2 loads, LDS tree over the slices.  Result in LDS sums[FC][2].
+// FC = 8: 16-32 workgroups per BatchNorm and <= 6 dependent loads per thread at 768 rows (the kernel is pure
+// latency: launch + one round of loads + tree; 32 channels per workgroup took 6 us).
+constexpr int FC = 8;
 __device__ __forceinline__ void reduce_partial_rows(const float* part, int rows, int C, int c0, float (*sums)[2]) {
-    __shared__ float red[32][33][2];
-    const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    constexpr int SL = 1024 / FC;
+    __shared__ float red[SL][FC + 1][2];
+    const int cl = threadIdx.x % FC, sl = threadIdx.x / FC;
     float a = 0.f, b = 0.f;
     if (c0 + cl < C) {
 #pragma unroll 8
-        for (int r = sl; r < rows; r += 32) {
+        for (int r = sl; r < rows; r += SL) {
             f32x2 v = *reinterpret_cast<const f32x2*>(part + ((size_t)r * C + c0 + cl) * 2);
             a += v[0]; b += v[1];
         }
     }
     red[sl][cl][0] = a; red[sl][cl][1] = b;
     __syncthreads();
-    if (sl == 0) {
+    // two-level tree over the SL slices: 16 groups of SL/16 slices, then the 16 group sums
+    const bool act = threadIdx.x < FC * 16;
+    const int tc = threadIdx.x % FC, tg = threadIdx.x / FC;
+    float x2 = 0.f, y2 = 0.f;
+    if (act) {
+#pragma unroll
+        for (int s = tg * (SL / 16); s < (tg + 1) * (SL / 16); ++s) { x2 += red[s][tc][0]; y2 += red[s][tc][1]; }
+    }
+    __syncthreads();
+    if (act) { red[tg][tc][0] = x2; red[tg][tc][1] = y2; }
+    __syncthreads();
+    if (threadIdx.x < FC) {
         float x = 0.f, y = 0.f;
-#pragma unroll 8
-        for (int s = 0; s < 32; ++s) { x += red[s][cl][0]; y += red[s][cl][1]; }
-        sums[cl][0] = x; sums[cl][1] = y;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) { x += red[s][threadIdx.x][0]; y += red[s][threadIdx.x][1]; }
+        sums[threadIdx.x][0] = x; sums[threadIdx.x][1] = y;
     }
     __syncthreads();
 }
@@ -37,10 +52,10 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* stats, i
                                                            float* rmean, float* rvar, float* scale, float* shift, float* mean,
                                                            float* invstd, int C, float count, float momentum, float eps,
                                                            int update_running) {
-    __shared__ float sums[32][2];
-    const int c0 = blockIdx.x * 32;
+    __shared__ float sums[FC][2];
+    const int c0 = blockIdx.x * FC;
     reduce_partial_rows(stats, rows, C, c0, sums);
-    if (threadIdx.x >= 32) return;
+    if (threadIdx.x >= FC) return;
     const int c = c0 + threadIdx.x;
     if (c >= C) return;
     float mu = sums[threadIdx.x][0] / count;
@@ -61,7 +76,7 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* stats, i
 int pa_launch_bn_finalize(const float* stats, int rows, const float* gamma, const float* beta, float* rmean, float* rvar,
                           float* scale, float* shift, float* mean, float* invstd, int C, float count,
                           float momentum, float eps, int update_running, hipStream_t st) {
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 31) / 32), dim3(1024), 0, st, stats, rows, gamma, beta, rmean, rvar, scale,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + FC - 1) / FC), dim3(1024), 0, st, stats, rows, gamma, beta, rmean, rvar, scale,
                        shift, mean, invstd, C, count, momentum, eps, update_running);
     return (int)hipGetLastError();
 }
@@ -85,10 +100,10 @@ int pa_launch_bn_eval(const PaBnEvalJob* jobs_dev, int njobs, float eps, hipStre
 __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* bstats, int rows, const float* scale, const float* mean,
                                                                const float* invstd, float* kA, float* kB, float* kC,
                                                                float* dgamma, float* dbeta, int C, float count) {
-    __shared__ float sums[32][2];
-    const int c0 = blockIdx.x * 32;
+    __shared__ float sums[FC][2];
+    const int c0 = blockIdx.x * FC;
     reduce_partial_rows(bstats, rows, C, c0, sums);
-    if (threadIdx.x >= 32) return;
+    if (threadIdx.x >= FC) return;
     const int c = c0 + threadIdx.x;
     if (c >= C) return;
     float S1 = sums[threadIdx.x][0], S2 = sums[threadIdx.x][1];
@@ -104,7 +119,7 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* bsta
 int pa_launch_bn_bwd_finalize(const float* bstats, int rows, const float* scale, const float* mean, const float* invstd,
                               float* kA, float* kB, float* kC, float* dgamma, float* dbeta, int C, float count,
                               hipStream_t st) {
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 31) / 32), dim3(1024), 0, st, bstats, rows, scale, mean, invstd, kA, kB,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + FC - 1) / FC), dim3(1024), 0, st, bstats, rows, scale, mean, invstd, kA, kB,
                        kC, dgamma, dbeta, C, count);
     return (int)hipGetLastError();
 }

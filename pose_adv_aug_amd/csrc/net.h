@@ -88,6 +88,8 @@ struct Residual {
     void layout(Net& n, Arena& a, int B, int H, int W, bool need_grad);
     int fwd(Net& n, const Act& in);
     int bwd(Net& n, const Act& in, const PaOperand& extra, bool in_needs_grad);
+    int bwd_a(Net& n, const Act& in);                                  // everything except the input gradient
+    int bwd_b(Net& n, const Act& in, const PaOperand& extra);           // input gradient (needs `extra`)
 };
 
 struct Hourglass {
@@ -128,6 +130,15 @@ struct Net {
     PaBnEvalJob* bneval_jobs = nullptr; int n_bneval = 0;
     // run state
     hipStream_t st = nullptr;
+    // side streams: the skip branch of hourglass level k runs on side[k] next to the low-resolution path
+    // (tiny, latency-bound kernels that leave most CUs idle); fork/join by events, joined before the call returns
+    hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork[4], ev_join[4];
+    bool streams_ready = false, multi_stream = true;
+    int ensure_streams();
+    int fork_to(int k);                        // side[k] waits for everything enqueued on st so far
+    int record_join(int k);                    // mark the end of the work enqueued on side[k]
+    int wait_join(int k);                      // st waits for that mark
     Prof prof;
     bool train_bn = true;
     int bn_update = 1;                         // 0: use batch statistics without touching the running estimates

@@ -387,8 +387,10 @@ int Residual::fwd(Net& n, const Act& in) {
     return 0;
 }
 
-// precondition: x3.grad holds the finished masked gradient and finish_grad(x3) has run
-int Residual::bwd(Net& n, const Act& in, const PaOperand& extra, bool in_needs_grad) {
+// precondition: x3.grad holds the finished masked gradient and finish_grad(x3) has run.
+// bwd = bwd_a (parameter gradients and the inner data gradients) + bwd_b (gradient of the block input, the only
+// part that needs `extra`, the gradient arriving at the input from its other consumers)
+int Residual::bwd_a(Net& n, const Act& in) {
     const int B = in.B, H = in.H, W = in.W;
     const PaOperand g3 = n.gradop(x3);
     TRY(n.conv_wgrad(c3, g3, n.op(x2), B, H, W));
@@ -401,7 +403,12 @@ int Residual::bwd(Net& n, const Act& in, const PaOperand& extra, bool in_needs_g
     const PaOperand g1 = n.gradop(x1);
     TRY(n.conv_wgrad(c1, g1, n.op(in), B, H, W));
     if (has_adapter) TRY(n.conv_wgrad(ad, g3, n.op(in), B, H, W));
-    if (!in_needs_grad) return 0;
+    return 0;
+}
+
+int Residual::bwd_b(Net& n, const Act& in, const PaOperand& extra) {
+    const int B = in.B, H = in.H, W = in.W;
+    const PaOperand g3 = n.gradop(x3), g1 = n.gradop(x1);
     if (has_adapter) {
         TRY(n.conv_dgrad(ad, g3, B, H, W, extra, pa_none(), ep_plain(), adgrad));
         TRY(n.conv_dgrad(c1, g1, B, H, W, pa_plain(adgrad), pa_none(), n.final_ep(in), in.grad));
@@ -411,12 +418,31 @@ int Residual::bwd(Net& n, const Act& in, const PaOperand& extra, bool in_needs_g
     return 0;
 }
 
+int Residual::bwd(Net& n, const Act& in, const PaOperand& extra, bool in_needs_grad) {
+    TRY(bwd_a(n, in));
+    return in_needs_grad ? bwd_b(n, in, extra) : 0;
+}
+
 // ------------------------------------------------------------------------------------------------
 // hourglass (reference :139-157 down path, :192-203 up path)
+// The skip branch of level k (a full-resolution residual block) does not depend on the low-resolution path
+// below it: it is enqueued on side stream k and joined where its result is consumed.
+struct StreamScope {
+    Net& n; hipStream_t saved;
+    StreamScope(Net& n_, hipStream_t s) : n(n_), saved(n_.st) { n.st = s; }
+    ~StreamScope() { n.st = saved; }
+};
+
 int Hourglass::encode(Net& n, const Act& in) {
     const Act* cur = &in;
     for (int k = 0; k < 4; ++k) {
-        TRY(skip[k].fwd(n, *cur));
+        if (n.multi_stream) {
+            TRY(n.fork_to(k));
+            { StreamScope sc(n, n.side[k]); TRY(skip[k].fwd(n, *cur)); }
+            TRY(n.record_join(k));
+        } else {
+            TRY(skip[k].fwd(n, *cur));
+        }
         TRY(pa_launch_maxpool_fwd(n.op(*cur), pooled[k].raw, cur->B, cur->H, cur->W, cur->C, n.st));
         TRY(down[k].fwd(n, pooled[k]));
         cur = &down[k].x3;
@@ -429,6 +455,7 @@ int Hourglass::decode(Net& n) {
     for (int k = 3; k >= 0; --k) {
         TRY(up[k].fwd(n, *low));
         const Act& m = merged[k];
+        if (n.multi_stream) TRY(n.wait_join(k));
         TRY(pa_launch_upadd_fwd(n.op(up[k].x3), n.op(skip[k].x3), m.raw, m.B, m.H, m.W, m.C, n.st));
         low = &merged[k];
     }
@@ -444,6 +471,12 @@ int Hourglass::bwd(Net& n, const Act& in, const PaOperand& extra0) {
                                 m.B, m.H, m.W, m.C, n.st));
         TRY(n.finish_grad(up[k].x3));
         TRY(n.finish_grad(skip[k].x3));
+        if (n.multi_stream) {          // parameter / inner gradients of the skip block next to the deeper levels
+            const Act& x = (k == 0) ? in : down[k - 1].x3;
+            TRY(n.fork_to(k));
+            { StreamScope sc(n, n.side[k]); TRY(skip[k].bwd_a(n, x)); }
+            TRY(n.record_join(k));
+        }
         const Act& upin = (k == 3) ? neck.x3 : merged[k + 1];
         TRY(up[k].bwd(n, upin, pa_none(), true));
     }
@@ -455,11 +488,31 @@ int Hourglass::bwd(Net& n, const Act& in, const PaOperand& extra0) {
         const Act& x = (k == 0) ? in : down[k - 1].x3;
         TRY(pa_launch_maxpool_bwd(pooled[k].grad, n.op(x), (k == 0) ? extra0 : pa_none(), ep_plain(), poolgrad[k],
                                   x.B, x.H, x.W, x.C, n.st));
-        TRY(skip[k].bwd(n, x, pa_plain(poolgrad[k]), true));
+        if (n.multi_stream) {
+            TRY(n.wait_join(k));
+            TRY(skip[k].bwd_b(n, x, pa_plain(poolgrad[k])));
+        } else {
+            TRY(skip[k].bwd(n, x, pa_plain(poolgrad[k]), true));
+        }
         TRY(n.finish_grad(x));
     }
     return 0;
 }
+
+int Net::ensure_streams() {
+    if (streams_ready) return 0;
+    if (getenv("PA_SINGLE_STREAM")) { multi_stream = false; streams_ready = true; return 0; }
+    for (int k = 0; k < 4; ++k) {
+        PA_CHECK(hipStreamCreateWithFlags(&side[k], hipStreamNonBlocking));
+        PA_CHECK(hipEventCreateWithFlags(&ev_fork[k], hipEventDisableTiming));
+        PA_CHECK(hipEventCreateWithFlags(&ev_join[k], hipEventDisableTiming));
+    }
+    streams_ready = true;
+    return 0;
+}
+int Net::fork_to(int k) { PA_CHECK(hipEventRecord(ev_fork[k], st)); PA_CHECK(hipStreamWaitEvent(side[k], ev_fork[k], 0)); return 0; }
+int Net::record_join(int k) { PA_CHECK(hipEventRecord(ev_join[k], side[k])); return 0; }
+int Net::wait_join(int k) { PA_CHECK(hipStreamWaitEvent(st, ev_join[k], 0)); return 0; }
 
 // ------------------------------------------------------------------------------------------------
 int Net::prepare_weights() { return pa_launch_weight_prep(prep_jobs, n_prep, prep_max, st); }
@@ -472,6 +525,7 @@ int Net::begin_step() {
 // reference :282-342 (stem :283-289, stacks :292-334) + loss of stack-hg.py:156-159
 int Net::forward_pose(const float* img_nchw, const bf16* img4_in, const double* pts, bool train, float* loss_out_dev) {
     train_bn = train;
+    TRY(ensure_streams());
     TRY(begin_step());
     if (!train) TRY(pa_launch_bn_eval(bneval_jobs, n_bneval, eps, st));
     const bf16* image = img4_in ? img4_in : img4;
@@ -502,6 +556,7 @@ int Net::forward_pose(const float* img_nchw, const bf16* img4_in, const double* 
 
 // hand-written backward of the whole pose net; gradients land in the flat `grads` array
 int Net::backward_pose() {
+    TRY(ensure_streams());
     const int Hh = res / 4;
     const float gscale = 1.f / ((float)B * 16.f * (float)Hh * (float)Hh);
     for (int i = stacks - 1; i >= 0; --i) {
