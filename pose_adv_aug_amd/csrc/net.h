@@ -135,6 +135,11 @@ struct Net {
     hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_fork[4], ev_join[4];
     bool streams_ready = false, multi_stream = true;
+    // weight-gradient launches only feed the slab reducer at the end of the backward pass: they run on their own
+    // stream behind an event recorded where their operands are final, off the dgrad / BatchNorm critical chain
+    hipStream_t wstream = nullptr;
+    hipEvent_t ev_w[16]; int ev_w_next = 0;
+    hipEvent_t ev_wdone;
     int ensure_streams();
     int fork_to(int k);                        // side[k] waits for everything enqueued on st so far
     int record_join(int k);                    // mark the end of the work enqueued on side[k]

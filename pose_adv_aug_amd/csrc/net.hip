@@ -357,9 +357,16 @@ int Net::conv_wgrad(ConvLayer& c, const PaOperand& dy, const PaOperand& x, int B
     a.B = B_; a.H = H; a.W = W; a.Cin = c.pcin; a.Cout = c.pcout; a.taps = c.k == 7 ? 1 : c.taps(); a.splits = c.splits;
     double wb, wf; conv_work(B_ * H * W, c.k == 7 ? 147 : c.Cin, c.Cout, c.k == 7 ? 1 : c.taps(), true, wb, wf);
     if (c.k == 7) wb = 2.0 * B_ * (4.0 * H * W * 4 + (double)H * W * 64) + 4.0 * 64 * 147;
-    ProfEntry* pe = prof.begin(c.k == 7 ? PA_PROF_STEM_WGRAD : (c.k == 3 ? PA_PROF_WGRAD3 : PA_PROF_WGRAD1), wb, wf, st);
-    int rc = (c.k == 7) ? pa_launch_stem_wgrad(a, st) : pa_launch_wgrad(a, st);
-    prof.end(pe, st);
+    hipStream_t ws = st;
+    if (multi_stream && wstream && !immediate_reduce) {
+        hipEvent_t ev = ev_w[ev_w_next]; ev_w_next = (ev_w_next + 1) & 15;
+        PA_CHECK(hipEventRecord(ev, st));
+        PA_CHECK(hipStreamWaitEvent(wstream, ev, 0));
+        ws = wstream;
+    }
+    ProfEntry* pe = prof.begin(c.k == 7 ? PA_PROF_STEM_WGRAD : (c.k == 3 ? PA_PROF_WGRAD3 : PA_PROF_WGRAD1), wb, wf, ws);
+    int rc = (c.k == 7) ? pa_launch_stem_wgrad(a, ws) : pa_launch_wgrad(a, ws);
+    prof.end(pe, ws);
     if (rc) return rc;
     if (immediate_reduce) {
         if (c.k == 7) {
@@ -507,6 +514,11 @@ int Net::ensure_streams() {
         PA_CHECK(hipEventCreateWithFlags(&ev_fork[k], hipEventDisableTiming));
         PA_CHECK(hipEventCreateWithFlags(&ev_join[k], hipEventDisableTiming));
     }
+    if (!getenv("PA_NO_WSTREAM")) {
+        PA_CHECK(hipStreamCreateWithFlags(&wstream, hipStreamNonBlocking));
+        for (int i = 0; i < 16; ++i) PA_CHECK(hipEventCreateWithFlags(&ev_w[i], hipEventDisableTiming));
+        PA_CHECK(hipEventCreateWithFlags(&ev_wdone, hipEventDisableTiming));
+    }
     streams_ready = true;
     return 0;
 }
@@ -599,6 +611,10 @@ int Net::backward_pose() {
 
 int Net::reduce_grads() {
     if (immediate_reduce) return 0;             // every layer was reduced right after its weight-gradient launch
+    if (multi_stream && wstream) {              // all weight-gradient slabs are complete
+        PA_CHECK(hipEventRecord(ev_wdone, wstream));
+        PA_CHECK(hipStreamWaitEvent(st, ev_wdone, 0));
+    }
     TRY(pa_launch_wgrad_reduce(red_jobs, n_red, red_max, st));
     if (!is_agent) {
         TRY(pa_launch_stem_wgrad_reduce(stem_conv.part, stem_conv.splits, grads + stem_conv.p_w, st));
