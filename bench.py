@@ -10,8 +10,9 @@
 
 Prints ONE JSON line on rank 0 (contract in the task description).  `roofline` comes from HIP events
 recorded around every launch of the MFMA kernels on the engine's own stream during a second pass of K
-steps right after the timed region (same inputs, same code path; the events are kept out of the timed
-region so that they do not perturb `value`).  `cpu_baseline` is the CPU oracle (PyTorch fp32
+steps right after the timed region (same inputs, same kernels; the events are kept out of the timed
+region so that they do not perturb `value`, and that pass runs with the engine's side streams off so that
+an event interval contains exactly one kernel).  `cpu_baseline` is the CPU oracle (PyTorch fp32
 restatement of stack-hg.py:153-180) timed on this box's host cores on a bounded sample."""
 import argparse
 import ctypes as C
@@ -122,10 +123,14 @@ def main():
     roofline = None
     if not args.no_roofline:
         h = net._net(B)
+        # per-kernel durations are taken with the engine's side streams off: with them on, launches of independent
+        # branches overlap and a launch's event interval contains other kernels' work
+        _lib.check(_lib.lib().pa_net_set_multi_stream(h, 0))
         _lib.check(_lib.lib().pa_net_profile_begin(h))
         run(args.steps)
         rep = (C.c_double * 32)()
         _lib.check(_lib.lib().pa_net_profile_report(h, rep))
+        _lib.check(_lib.lib().pa_net_set_multi_stream(h, 1))
         rows = []
         for i, name in enumerate(PROF_NAMES):
             ms, cnt, by, fl = rep[4 * i], rep[4 * i + 1], rep[4 * i + 2], rep[4 * i + 3]

@@ -184,6 +184,11 @@ int pa_hg_pckh(pa_net* net, int stack, const float* center, const float* scale, 
 int pa_net_profile_begin(pa_net* net);
 int pa_net_profile_report(pa_net* net, double* out_host);
 
+/* The engine enqueues independent branches (hourglass skip blocks, weight gradients) on internal side
+ * streams that fork from / join into the caller's stream by events.  on = 0 serialises everything on
+ * the caller's stream (clean per-kernel timings: bench.py's roofline pass); on = 1 restores the default. */
+int pa_net_set_multi_stream(pa_net* net, int on);
+
 /* Test hook: copy an internal activation (pending BatchNorm+ReLU applied) or, with grad != 0, its raw
  * gradient buffer out as NCHW fp32; shape4 receives {B, C, H, W} (out may be NULL to query the shape).
  * Names: "stem", "res1".."res3", "pool0", "hg<i>.skip<k>|pool<k>|down<k>|up<k>|merge<k>|neck" (k=1..4),

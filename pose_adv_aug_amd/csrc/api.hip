@@ -400,6 +400,12 @@ int pa_net_profile_report(pa_net* net, double* out) {
     return r;
 }
 
+int pa_net_set_multi_stream(pa_net* net, int on) {
+    if (net->n.ensure_streams()) return 1;
+    net->n.multi_stream = on != 0 && net->n.side[0] != nullptr;
+    return 0;
+}
+
 // debug / test hook: copy an internal activation (BatchNorm+ReLU applied) or its gradient buffer out as
 // NCHW fp32.  which: "stem", "res1", "pool0", "res2", "res3", "hg<i>.skip<k>", "hg<i>.pool<k>",
 // "hg<i>.down<k>", "hg<i>.neck", "hg<i>.up<k>", "hg<i>.merge<k>", "post<i>", "lin<i>", "xin<i>" (k = 1..4)

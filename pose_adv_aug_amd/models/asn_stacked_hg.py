@@ -258,7 +258,12 @@ class HourglassNet(_HipModule):
         Hh = self.res // 4
         dev = self.flat_params.device
         scratch = torch.empty(B * 16 * Hh * Hh + 4 * B * 16 + B + 16, dtype=torch.float32, device=dev)
-        ix = torch.as_tensor([int(i) for i in idxs], dtype=torch.int32, device=dev)
+        # cached: a host->device copy here would make the host wait for the whole step (no run-ahead)
+        key = tuple(int(i) for i in idxs)
+        cache = self.__dict__.setdefault('_idx_cache', {})
+        ix = cache.get(key)
+        if ix is None:
+            ix = cache[key] = torch.as_tensor(key, dtype=torch.int32, device=dev)
         acc = torch.zeros(len(idxs) + 1, dtype=torch.float32, device=dev)
         check(lib().pa_hg_accuracy(h, stack, ptr(ix), len(idxs), ptr(acc), ptr(scratch)), 'pa_hg_accuracy')
         return acc

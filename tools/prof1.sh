@@ -11,7 +11,8 @@ import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: -float(r['TotalDurationNs']))
 tot = sum(float(r['TotalDurationNs']) for r in rows)
-print('# rocprofv3 --kernel-trace --stats -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline   (13 steps incl. warm-up)')
+import os
+print('# %srocprofv3 --kernel-trace --stats -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline   (13 steps incl. warm-up)' % ('PA_SINGLE_STREAM=1 ' if os.environ.get('PA_SINGLE_STREAM') else ''))
 print('# total kernel time %.3f ms over 13 steps = %.3f ms/step' % (tot/1e6, tot/1e6/13))
 print('%7s %7s %10s %10s  %s' % ('pct', 'calls', 'avg_us', 'total_ms', 'kernel'))
 for r in rows[:60]:
