@@ -71,6 +71,13 @@ int pa_transform_pts(const float* pts, const double* params, const double* t, in
 int pa_affine_warp_bilinear(const uint8_t* src, int Hs, int Ws, const double* tinv, const double* params,
                             int B, int res, void* out4, float* outf, void* stream);
 
+/* Validation with flip test-time augmentation (stack-hg.py:222-230).
+ * pa_flip_lr_nhwc4: mirror the bf16 NHWC4 network input along W (img.numpy()[:, :, :, ::-1], :223).
+ * pa_flip_tta_merge: merged = (out + shuffle_channels_for_horizontal_flipping(flip_channels(out_flipped))) / 2
+ * (pylib/HumanAug.py:198-210, :179-196, stack-hg.py:228-230) over NCHW fp32 heat maps [B][16][H][W]. */
+int pa_flip_lr_nhwc4(const void* src, void* dst, int B, int H, int W, void* stream);
+int pa_flip_tta_merge(const float* out, const float* out_flipped, float* merged, int B, int J, int H, int W, void* stream);
+
 /* augmentation laws: mode 0 = data/mpii_for_mpii.py:119-135 (regular), 1 = agent bins
  * (data/joint_train_s_r_agent.py:15-16,33-36,134-139), 2 = agent scale only, 3 = agent rotation only.
  * meta [B][4] = {objpos_x, objpos_y, scale, frame_width}; params [B][8] as above. */

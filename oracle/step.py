@@ -50,3 +50,23 @@ def agent_kl_loss(scale_logits, rot_logits, grnd_scale, grnd_rot):
     ls = F.kl_div(torch.log(ps + 1e-7), grnd_scale, reduction='mean') * grnd_scale.size(1)
     lr = F.kl_div(torch.log(pr + 1e-7), grnd_rot, reduction='mean') * grnd_rot.size(1)
     return ls + lr
+
+
+def validate_tta(out_last, out_last_flipped):
+    """stack-hg.py:227-229: flip the second forward's last heat map back, swap the left/right joints, average."""
+    return (out_last + pylib.flip_heatmaps(out_last_flipped)) / 2
+
+
+def validate_batch(net, img, heat, center, scale, rot, grnd_pts, normalizer, pck_idx=(0, 1, 2, 3, 4, 5, 10, 11, 14, 15)):
+    """stack-hg.py:206-258 for one batch (net in eval mode): loss of the plain forward, flip test-time
+    augmentation, PCKh in heat-map space and at the original resolution, final predictions (original image px)."""
+    with torch.no_grad():
+        out1 = net(img)                                                       # :215
+        loss = pylib.stack_mse(out1, heat)                                    # :216-219
+        out2 = net(torch.from_numpy(img.numpy()[:, :, :, ::-1].copy()))       # :222-226
+        output = validate_tta(out1[-1], out2[-1])
+    res = [output.shape[2], output.shape[3]]
+    pckh = pylib.accuracy(output, heat, list(pck_idx))                        # :235
+    pckh_o = pylib.accuracy_origin_res(output, center, scale, res, grnd_pts, normalizer, rot)   # :237-238
+    preds = pylib.final_preds(output, center, scale, res, rot)                # :253
+    return loss, pckh[0], pckh_o[0], preds, output

@@ -51,6 +51,13 @@ int pa_affine_warp_bilinear(const uint8_t* src, int Hs, int Ws, const double* ti
                             void* out4, float* outf, void* s) {
     TRY(pa_launch_warp(src, Hs, Ws, tinv, params, B, res, reinterpret_cast<bf16*>(out4), outf, ST(s))); return 0;
 }
+int pa_flip_lr_nhwc4(const void* src, void* dst, int B, int H, int W, void* s) {
+    TRY(pa_launch_flip_lr_nhwc4(reinterpret_cast<const bf16*>(src), reinterpret_cast<bf16*>(dst), B, H, W, ST(s))); return 0;
+}
+int pa_flip_tta_merge(const float* out, const float* out_flipped, float* merged, int B, int J, int H, int W, void* s) {
+    if (J != 16) { pa_set_error_msg("pa_flip_tta_merge: the left/right joint table is MPII's (16 joints)"); return 1; }
+    TRY(pa_launch_flip_tta_merge(out, out_flipped, merged, B, H, W, ST(s))); return 0;
+}
 int pa_sample_aug(const float* meta, const int32_t* scale_idx, const int32_t* rot_idx, int mode, uint64_t seed, uint64_t step,
                   int B, double* params, void* s) {
     TRY(pa_launch_sample_aug(meta, scale_idx, rot_idx, mode, seed, step, B, params, ST(s))); return 0;

@@ -23,3 +23,5 @@ int pa_launch_sample_aug(const float* meta, const int* scale_idx, const int* rot
                          unsigned long long step, int B, double* params, hipStream_t st);
 int pa_launch_sample_categorical(const float* logits, int B, int K, unsigned long long seed, unsigned long long step, unsigned slot,
                                  float* probs, int* idx, hipStream_t st);
+int pa_launch_flip_lr_nhwc4(const bf16* src, bf16* dst, int B, int H, int W, hipStream_t st);
+int pa_launch_flip_tta_merge(const float* a, const float* b, float* out, int B, int H, int W, hipStream_t st);

@@ -557,3 +557,50 @@ int pa_launch_sample_categorical(const float* logits, int B, int K, unsigned lon
     hipLaunchKernelGGL(sample_categorical_kernel, dim3((B + 63) / 64), dim3(64), 0, st, logits, B, K, seed, step, slot, probs, idx);
     return (int)hipGetLastError();
 }
+
+// ------------------------------------------------------------------------------------------------
+// validation with flip test-time augmentation (reference stack-hg.py:222-230)
+// mirror the 4-channel-padded NHWC bf16 network input along W (img.numpy()[:, :, :, ::-1])
+__global__ void flip_lr_nhwc4_kernel(const bf16x4* src, bf16x4* dst, int rows, int W) {
+    const size_t total = (size_t)rows * W;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = i / W;
+        const int x = (int)(i - r * W);
+        dst[i] = src[r * W + (W - 1 - x)];
+    }
+}
+
+int pa_launch_flip_lr_nhwc4(const bf16* src, bf16* dst, int B, int H, int W, hipStream_t st) {
+    const size_t total = (size_t)B * H * W;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(flip_lr_nhwc4_kernel, dim3(blocks), dim3(256), 0, st, reinterpret_cast<const bf16x4*>(src),
+                       reinterpret_cast<bf16x4*>(dst), B * H, W);
+    return (int)hipGetLastError();
+}
+
+// out = (a + shuffle_channels(flip_channels(b))) / 2 over NCHW fp32 heat maps: HumanAug.flip_channels
+// (pylib/HumanAug.py:198-210) mirrors W, shuffle_channels_for_horizontal_flipping (:179-196) swaps the MPII
+// left/right joints [1,4] [0,5] [12,13] [11,14] [10,15] [2,3]
+__constant__ int pa_flip_perm[16] = {5, 4, 3, 2, 1, 0, 6, 7, 8, 9, 15, 14, 13, 12, 11, 10};
+
+__global__ void flip_tta_merge_kernel(const float* a, const float* b, float* out, int B, int H, int W) {
+    const size_t total = (size_t)B * 16 * H * W;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % W);
+        size_t r = i / W;
+        const int y = (int)(r % H); r /= H;
+        const int j = (int)(r % 16);
+        const size_t n = r / 16;
+        const float fb = b[((n * 16 + pa_flip_perm[j]) * H + y) * W + (W - 1 - x)];
+        out[i] = (a[i] + fb) / 2.f;
+    }
+}
+
+int pa_launch_flip_tta_merge(const float* a, const float* b, float* out, int B, int H, int W, hipStream_t st) {
+    const size_t total = (size_t)B * 16 * H * W;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(flip_tta_merge_kernel, dim3(blocks), dim3(256), 0, st, a, b, out, B, H, W);
+    return (int)hipGetLastError();
+}

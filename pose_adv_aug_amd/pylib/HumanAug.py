@@ -110,6 +110,24 @@ def flip_channels(maps):
     return maps.flip(-1).float()
 
 
+def flip_lr_img4(img4):
+    """device: mirror the bf16 NHWC4 network input along W (stack-hg.py:223 `img.numpy()[:, :, :, ::-1]`)."""
+    B, H, W, _ = img4.shape
+    out = torch.empty_like(img4)
+    check(lib().pa_flip_lr_nhwc4(ptr(img4), ptr(out), B, H, W, stream()), 'pa_flip_lr_nhwc4')
+    return out
+
+
+def flip_tta_merge(output, output_flipped):
+    """device, one kernel: (output + shuffle_channels_for_horizontal_flipping(flip_channels(output_flipped))) / 2
+    (stack-hg.py:228-230) for NCHW fp32 MPII heat maps."""
+    a = to_dev(output, torch.float32); b = to_dev(output_flipped, torch.float32)
+    B, J, H, W = a.shape
+    out = torch.empty_like(a)
+    check(lib().pa_flip_tta_merge(ptr(a), ptr(b), ptr(out), B, J, H, W, stream()), 'pa_flip_tta_merge')
+    return out
+
+
 def shuffle_channels_for_horizontal_flipping(maps):
     """pylib/HumanAug.py:179-196 (in place)."""
     dim = 1 if maps.dim() == 4 else 0

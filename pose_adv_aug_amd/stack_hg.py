@@ -67,6 +67,46 @@ def train(batches, net, optimizer, augmenter, epoch, opt, log=print):
     return losses.avg, pckhs_o.avg
 
 
+def validate_step(net, augmenter, batch):
+    """stack-hg.py:206-258 for one batch, on the device: forward on the un-augmented crop, loss against the
+    Gaussian target, second forward on the W-mirrored input, flip back + left/right channel swap + average
+    (flip test-time augmentation), PCKh in heat-map space and at the original resolution, final predictions.
+    Returns (loss, pckh, pckh_origin_res, preds [B][16][2], merged heat maps)."""
+    from .pylib import Evaluation, HumanAug, HumanPts
+    data = augmenter.standard(batch)
+    out1 = net.forward(img4=data['img4'], pts=data['pts'])                    # stack-hg.py:215-219 (loss inside)
+    loss = net._last_losses.sum()
+    out2 = net.forward(img4=HumanAug.flip_lr_img4(data['img4']))              # :222-226
+    output = HumanAug.flip_tta_merge(out1[-1], out2[-1])                      # :227-229
+    target = HumanPts.pts2heatmap_batch(data['pts'], output.shape[2], output.shape[3])
+    pckh = Evaluation.accuracy(output, target, PCK_IDX)                       # :235
+    res = [output.shape[2], output.shape[3]]
+    pckh_o = Evaluation.accuracy_origin_res(output, data['c'], data['s'], res, data['grnd_pts'], data['normalizer'], data['r'])
+    preds = Evaluation.final_preds(output, data['c'], data['s'], res, data['r'])     # :253
+    return loss, pckh[0], pckh_o[0], preds, output
+
+
+def validate(batches, net, augmenter, epoch, opt, num_classes=16, log=print):
+    """stack-hg.py:191-260: returns (losses.avg, pckhs_origin_res.avg, predictions [N][num_classes][2])."""
+    losses, pckhs, pckhs_o = AverageMeter(), AverageMeter(), AverageMeter()
+    n_total = sum(b.B for b in batches)
+    predictions = torch.zeros(n_total, num_classes, 2)
+    net.eval()
+    n = len(batches)
+    off = 0
+    for i, batch in enumerate(batches):
+        loss, pckh, pckh_o, preds, _ = validate_step(net, augmenter, batch)
+        losses.update(float(loss)); pckhs.update(float(pckh)); pckhs_o.update(float(pckh_o))
+        index = getattr(batch, 'index', None)
+        index = list(range(off, off + batch.B)) if index is None else [int(v) for v in index]
+        predictions[index] = preds.cpu()                                      # :254-255
+        off += batch.B
+        if i % opt.print_freq == 0 or i == n - 1:
+            d = OrderedDict([('loss', losses.avg), ('pckh', pckhs.avg), ('pckh_origin_res', pckhs_o.avg)])
+            log('val epoch:%d, iters:%d/%d ' % (epoch, i, n) + ' '.join('%s: %.4f' % kv for kv in d.items()))
+    return losses.avg, pckhs_o.avg, predictions
+
+
 def main(argv=None):
     from .options.train_options import TrainOptions
     from .utils.checkpoint import Checkpoint
@@ -86,14 +126,16 @@ def main(argv=None):
     augmenter = Augmenter(seed=1234 + rank)
     # synthetic MPII-shape people (the dataset JSON / images are not part of the checkout)
     batches = [DeviceBatch.synthetic(opt.bs, seed=rank * 1000 + k) for k in range(4)]
+    val_batches = [DeviceBatch.synthetic(opt.bs, seed=500000 + k) for k in range(2)]
     start = history.epoch[-1]['epoch'] + 1 if history.epoch else 0
     for epoch in range(start, opt.nEpochs):
         adjust_lr(opt, optimizer, epoch)
         tl, tp = train(batches, net, optimizer, augmenter, epoch, opt)
+        vl, vp, predictions = validate(val_batches, net, augmenter, epoch, opt)               # stack-hg.py:98-99
         history.update(OrderedDict([('epoch', epoch)]), OrderedDict([('lr', optimizer.param_groups[0]['lr'])]),
-                       OrderedDict([('train_loss', tl), ('val_loss', tl)]), OrderedDict([('train_pckh', tp), ('val_pckh', tp)]))
+                       OrderedDict([('train_loss', tl), ('val_loss', vl)]), OrderedDict([('train_pckh', tp), ('val_pckh', vp)]))
         if rank == 0:
-            ckpt.save_checkpoint(net, optimizer, history, torch.zeros(1, 16, 2))
+            ckpt.save_checkpoint(net, optimizer, history, predictions)                        # :108 (+ -preds.mat)
 
 
 if __name__ == '__main__':
