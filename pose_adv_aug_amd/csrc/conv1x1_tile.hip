@@ -14,12 +14,13 @@
 #include "common.h"
 #include "kernels.h"
 #include "conv_epilogue.h"
+#include <stdlib.h>
 
 #define PA_GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 #define PA_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 
 template <int CIN, int BM, int BN, int LDMODE>
-__global__ __launch_bounds__(256, 2) void conv1x1_tile_kernel(PaConvArgs a, int nb_per_wg) {
+__global__ __launch_bounds__(256, (CIN == 128 && BM == 64) ? 3 : 2) void conv1x1_tile_kernel(PaConvArgs a, int nb_per_wg) {
     constexpr int CPP = CIN / 8;                     // 16-byte chunks per pixel row
     constexpr int NI = BN / 32, MI = BM / 32;
     constexpr int KT = CIN / 64;
@@ -157,7 +158,13 @@ static void launch_row_ld(const PaConvArgs& a, dim3 grid, int nbw, hipStream_t s
     }
 }
 
-static int row_bm(int Cin) { return Cin == 256 ? 64 : 128; }
+// 64-row tiles also for 128 input channels: at B = 24, 64x64 maps the 768 tiles of 128 rows fill 256 CUs x 2
+// workgroups 1.5 times (the last round runs half empty); 1536 tiles of 64 rows at 3 workgroups/CU are 2 full rounds
+static int row_bm(int Cin) {
+    static int big = -1;
+    if (big < 0) big = getenv("PA_CONV1_BM128") ? 1 : 0;
+    return (Cin == 256 || (Cin == 128 && !big)) ? 64 : 128;
+}
 
 bool pa_conv1x1_tile_supported(const PaConvArgs& a) {
     if (a.taps != 1 || (a.Cin != 64 && a.Cin != 128 && a.Cin != 256) || a.Cout % 64 != 0) return false;
@@ -177,6 +184,7 @@ int pa_launch_conv1x1_tile(const PaConvArgs& a, hipStream_t st, int* stat_rows) 
     const int nbw = tiles >= 512 ? nb : 1;          // enough row tiles: loop over the channel blocks inside (input read once)
     dim3 grid(tiles, nb / nbw);
     if (a.Cin == 256) { if (bigN) launch_row_ld<256, 64, 128>(a, grid, nbw, st); else launch_row_ld<256, 64, 64>(a, grid, nbw, st); }
+    else if (a.Cin == 128 && bm == 64) { if (bigN) launch_row_ld<128, 64, 128>(a, grid, nbw, st); else launch_row_ld<128, 64, 64>(a, grid, nbw, st); }
     else if (a.Cin == 128) { if (bigN) launch_row_ld<128, 128, 128>(a, grid, nbw, st); else launch_row_ld<128, 128, 64>(a, grid, nbw, st); }
     else { if (bigN) launch_row_ld<64, 128, 128>(a, grid, nbw, st); else launch_row_ld<64, 128, 64>(a, grid, nbw, st); }
     return (int)hipGetLastError();

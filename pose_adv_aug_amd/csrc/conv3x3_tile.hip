@@ -19,9 +19,18 @@
 #include "common.h"
 #include "kernels.h"
 #include "conv_epilogue.h"
+#include <stdlib.h>
 
 #define PA_GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 #define PA_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+// 16-byte slot swizzle of halo pixel p.  128 channels (16 slots = one 256-byte bank row per pixel): bits (0,1,2,0)
+// of p -- found by exhaustive search over linear maps: with ds_read_b128's lane groups {0-3,12-15,20-27},... a
+// fragment read touches pixels b+{0..3,12..15} at chunk c and b+{4..11} at chunk c^1, and this map keeps the 16
+// slots distinct for EVERY base b, i.e. for every tap shift (p & 15 conflicts 2-way for odd shifts: 10 % of the
+// LDS cycles, SQ_LDS_BANK_CONFLICT).  64 channels (two pixels per bank row): (p >> 1) & 7.
+template <int CPP>
+__device__ __forceinline__ int halo_sw(int p) { return CPP == 16 ? ((p & 7) | ((p & 1) << 3)) : ((p >> 1) & 7); }
 
 template <int CIN, int BN, int LDMODE>
 __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(PaConvArgs a) {
@@ -113,8 +122,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(PaConvArgs a) {
 #pragma unroll
                         for (int j = 0; j < 8; ++j) o[j] = (bf16)0.f;
                     }
-                    const int sw = CPP == 16 ? (hp[u] & 15) : ((hp[u] >> 1) & 7);
-                    *reinterpret_cast<bf16x8*>(halo + hp[u] * CIN + ((chunk ^ sw) << 3)) = o;
+                    *reinterpret_cast<bf16x8*>(halo + hp[u] * CIN + ((chunk ^ halo_sw<CPP>(hp[u])) << 3)) = o;
                 }
             }
         }
@@ -130,13 +138,26 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(PaConvArgs a) {
     __syncthreads();
 
     const int frow = lane & 15, fchk = lane >> 4;
-    int pbase[MI];
+    int pbase[MI], boff[NI];
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) pbase[mi] = (wm * 4 + mi + 1) * PW + frow + 1;
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+        const int row = wn * (BN / 2) + ni * 16 + frow;
+        boff[ni] = row * 64 + ((fchk ^ (row & 7)) << 3);
+    }
 
     for (int tap = 0; tap < 9; ++tap) {
         const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
         const int toff = dy * PW + dx;
+        // element offset of k-chunk `fchk` of the tap-shifted pixel; the other chunks of the pixel are reached by
+        // XOR-ing the chunk bits (the swizzle is an XOR on the same bits), so one address per (tap, fragment)
+        int aoff[MI];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const int p = pbase[mi] + toff;
+            aoff[mi] = p * CIN + ((fchk ^ halo_sw<CPP>(p)) << 3);
+        }
 #pragma unroll
         for (int kh = 0; kh < KT; ++kh) {
             const int it = tap * KT + kh;
@@ -145,18 +166,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(PaConvArgs a) {
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
                 bf16x8 fa[MI], fw[NI];
-                const int chunk = kh * 8 + kk * 4 + fchk;
 #pragma unroll
-                for (int mi = 0; mi < MI; ++mi) {
-                    const int p = pbase[mi] + toff;
-                    const int sw = CPP == 16 ? (p & 15) : ((p >> 1) & 7);
-                    fa[mi] = *reinterpret_cast<const bf16x8*>(halo + p * CIN + ((chunk ^ sw) << 3));
-                }
+                for (int mi = 0; mi < MI; ++mi)
+                    fa[mi] = *reinterpret_cast<const bf16x8*>(halo + (aoff[mi] ^ ((kh * 8 + kk * 4) << 3)));
 #pragma unroll
-                for (int ni = 0; ni < NI; ++ni) {
-                    const int row = wn * (BN / 2) + ni * 16 + frow;
-                    fw[ni] = *reinterpret_cast<const bf16x8*>(Bs + row * 64 + (((fchk + 4 * kk) ^ (row & 7)) << 3));
-                }
+                for (int ni = 0; ni < NI; ++ni)
+                    fw[ni] = *reinterpret_cast<const bf16x8*>(Bs + (boff[ni] ^ ((kk * 4) << 3)));
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
@@ -191,7 +206,9 @@ int pa_launch_conv3x3_tile(const PaConvArgs& a, hipStream_t st, int* stat_rows) 
     const int tiles = a.B * (a.H / 8) * (a.W / 16);
     if (stat_rows) *stat_rows = tiles;
     if (a.ep.rows_out) *a.ep.rows_out = tiles;
-    const bool bigN = a.Cout % 128 == 0;
+    static int n64 = -1;
+    if (n64 < 0) n64 = getenv("PA_CONV3_BN64") ? 1 : 0;          // experiment: 64-channel halves
+    const bool bigN = a.Cout % 128 == 0 && !n64;
     dim3 grid(tiles, a.Cout / (bigN ? 128 : 64));
     if (a.Cin == 128) { if (bigN) launch_tile_ld<128, 128>(a, grid, st); else launch_tile_ld<128, 64>(a, grid, st); }
     else { if (bigN) launch_tile_ld<64, 128>(a, grid, st); else launch_tile_ld<64, 64>(a, grid, st); }

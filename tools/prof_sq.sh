@@ -18,6 +18,7 @@ for mode, var in ((0, 7), (1, 7), (2, 9)):
     check(L.pa_conv2d_time(mode, var, 24, 256, 128, 64, 64, 1, 5, ptr(ws), C.byref(ms), stream()))
     print(mode, var, ms.value * 1e3, 'us')
 PY
+rm -rf gpurun_out/sq_*
 for SET in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR"; do
   tag=$(echo $SET | cut -c1-12 | tr ' ' '_')
   rocprofv3 --pmc $SET --kernel-trace --output-format csv -d gpurun_out/sq_$tag -o c -- python /tmp/one.py > gpurun_out/sq_$tag.log 2>&1
@@ -28,7 +29,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = col
 for f in glob.glob('gpurun_out/sq_*/*counter_collection.csv'):
     for r in csv.DictReader(open(f)):
         k = r['Kernel_Name'][:64]
-        if 'conv_' not in k: continue
+        if 'conv' not in k and 'wgrad' not in k: continue
         agg[k][r['Counter_Name']] += float(r['Counter_Value'])
 for k, d in agg.items():
     n = 8.0
