@@ -48,11 +48,14 @@ template <int TAPS, int NF, int CF, int WNW, int PMODE, int QMODE, bool DB>
 __global__ __launch_bounds__(256, 2) void wgrad_tile_kernel(PaWgradArgs a, int ntiles) {
     constexpr int WCW = 4 / WNW;
     constexpr int NB = 16 * NF * WNW, CB = 16 * CF * WCW;
-    constexpr int PW = 18, HP = TAPS == 9 ? 180 : 128;
+    // 3x3: 10 x 18 halo pixels, stored with a row pitch of 32 pixels: the swizzle bits (<= bit 3) and the pixel-in-row
+    // part of a fragment address then do not depend on the halo ROW, so the 72 (k-step, tap, half) addresses of a lane
+    // are 6 registers + compile-time offsets (with pitch 18 they were recomputed or spilled: 36 spill slots)
+    constexpr int PW = 18, PWL = 32, HP = TAPS == 9 ? 180 : 128, HPL = TAPS == 9 ? 10 * PWL : 128;
     constexpr int CPN = NB / 8, CPC = CB / 8;                   // 16-byte chunks per row
     constexpr int PASS_N = 128 * CPN / 256;                     // dy chunks per thread
     constexpr int PASS_C = (HP * CPC + 255) / 256;              // x chunks per thread
-    __shared__ __attribute__((aligned(16))) bf16 lds[128 * NB + HP * CB];
+    __shared__ __attribute__((aligned(16))) bf16 lds[128 * NB + HPL * CB];
     bf16* dyT = lds;
     bf16* xT = lds + 128 * NB;
 
@@ -163,8 +166,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile_kernel(PaWgradArgs a, int n
             }
 #pragma unroll
             for (int u = 0; u < PASS_C; ++u) {
-                const int hp = u * (256 / CPC) + tid / CPC;
-                if (hp < HP) {
+                const int hi = u * (256 / CPC) + tid / CPC;
+                const int hp = TAPS == 9 ? (hi / PW) * PWL + hi % PW : hi;          // pixel index in the LDS image
+                if (hi < HP) {
                     bf16x8 o;
                     if (QMODE == PA_LD_BNRELU) {
 #pragma unroll
@@ -182,22 +186,52 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile_kernel(PaWgradArgs a, int n
         }
         __syncthreads();
         // ---- MFMA: 4 steps of 32 pixels
+        if (TAPS == 9) {
+            // per-lane element offsets for k-step 0 / halo row 0; everything else is a compile-time offset
+            int doff[NF][2], xoff[3][2];
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            bf16x8 fd[NF];
+            for (int hh = 0; hh < 2; ++hh) {
+                const int kl = 8 * (lane >> 4) + 4 * hh + ((lane & 15) >> 2);
 #pragma unroll
-            for (int f = 0; f < NF; ++f) fd[f] = wg_tr_frag<NB>(dyT, wn * NF + f, [&](int kl) { return 32 * ks + kl; });
+                for (int f = 0; f < NF; ++f) doff[f][hh] = kl * NB + (((wn * NF + f) ^ wg_sw<NB>(kl)) << 4) + 4 * (lane & 3);
 #pragma unroll
-            for (int t = 0; t < TAPS; ++t) {
-                const int dy = TAPS == 9 ? t / 3 - 1 : 0, dx = TAPS == 9 ? t % 3 - 1 : 0;
+                for (int d = 0; d < 3; ++d) {
+                    const int col = (kl & 15) + d;                                   // + 1 + dx, dx = d - 1
+                    xoff[d][hh] = ((kl >> 4) * PWL + col) * CB + ((wc ^ wg_sw<CB>(col)) << 4) + 4 * (lane & 3);
+                }
+            }
+            auto tr8 = [&](const bf16* base, int o0, int o1) {
+                s16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + o0));
+                s16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + o1));
+                s16x8 v = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+                return __builtin_bit_cast(bf16x8, v);
+            };
 #pragma unroll
-                for (int cf = 0; cf < CF; ++cf) {
-                    bf16x8 fx = wg_tr_frag<CB>(xT, wc * CF + cf, [&](int kl) {
-                        return TAPS == 9 ? (2 * ks + (kl >> 4) + 1 + dy) * PW + (kl & 15) + 1 + dx : 32 * ks + kl;
-                    });
+            for (int ks = 0; ks < 4; ++ks) {
+                bf16x8 fd[NF];
+#pragma unroll
+                for (int f = 0; f < NF; ++f) fd[f] = tr8(dyT + ks * 32 * NB, doff[f][0], doff[f][1]);
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const int row = 2 * ks + 1 + (t / 3 - 1);                        // halo row of the first 16 pixels
+                    bf16x8 fx = tr8(xT + row * PWL * CB, xoff[t % 3][0], xoff[t % 3][1]);
 #pragma unroll
                     for (int f = 0; f < NF; ++f)
-                        acc[t][cf][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fx, fd[f], acc[t][cf][f], 0, 0, 0);
+                        acc[t][0][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fx, fd[f], acc[t][0][f], 0, 0, 0);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                bf16x8 fd[NF];
+#pragma unroll
+                for (int f = 0; f < NF; ++f) fd[f] = wg_tr_frag<NB>(dyT, wn * NF + f, [&](int kl) { return 32 * ks + kl; });
+#pragma unroll
+                for (int cf = 0; cf < CF; ++cf) {
+                    bf16x8 fx = wg_tr_frag<CB>(xT, wc * CF + cf, [&](int kl) { return 32 * ks + kl; });
+#pragma unroll
+                    for (int f = 0; f < NF; ++f)
+                        acc[0][cf][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fx, fd[f], acc[0][cf][f], 0, 0, 0);
                 }
             }
         }
