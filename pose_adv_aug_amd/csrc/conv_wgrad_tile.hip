@@ -274,7 +274,7 @@ static bool wg_tile_cfg(int B, int H, int W, int Cin, int Cout, int taps, WgTile
     if (off < 0) {
         off = getenv("PA_WGRAD_OLD") ? 1 : 0;
         const char* e = getenv("PA_WGRAD_WGS1"); target1 = e ? atoi(e) : 256;
-        e = getenv("PA_WGRAD_WGS9"); target9 = e ? atoi(e) : 512;
+        e = getenv("PA_WGRAD_WGS9"); target9 = e ? atoi(e) : 256;
     }
     if (off || H <= 0 || W <= 0) return false;
     const int M = B * H * W;
