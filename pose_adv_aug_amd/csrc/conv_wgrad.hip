@@ -340,20 +340,24 @@ int pa_launch_wgrad_reduce(const PaWgradReduceJob* jobs_dev, int njobs, int max_
     return (int)hipGetLastError();
 }
 
-__global__ void stem_wgrad_reduce_kernel(const float* part, int splits, float* dst) {
-    const int total = 64 * 3 * 49;
-    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
-        int n = e / 147, r = e - n * 147;
-        int c = r / 49, t = r - c * 49;
-        int ky = t / 7, kx = t - ky * 7;
-        const float* src = part + (size_t)n * 256 + ky * 32 + kx * 4 + c;
-        float s = 0.f;
-        for (int sp = 0; sp < splits; ++sp) s += src[(size_t)sp * 64 * 256];
-        dst[e] = s;
+// one workgroup per output channel n: 1024 threads = 256 patch elements k (coalesced 1 KB rows) x 4 slices of the
+// split range, LDS tree over the slices, scatter into dst[n][c][ky][kx]
+__global__ __launch_bounds__(1024) void stem_wgrad_reduce_kernel(const float* part, int splits, float* dst) {
+    __shared__ float red[4][256];
+    const int n = blockIdx.x, k = threadIdx.x & 255, sl = threadIdx.x >> 8;
+    const float* src = part + (size_t)n * 256 + k;
+    float s = 0.f;
+#pragma unroll 8
+    for (int sp = sl; sp < splits; sp += 4) s += src[(size_t)sp * 64 * 256];
+    red[sl][k] = s;
+    __syncthreads();
+    if (sl == 0) {
+        const int ky = k >> 5, kx = (k & 31) >> 2, c = k & 3;
+        if (ky < 7 && kx < 7 && c < 3) dst[((size_t)(n * 3 + c) * 7 + ky) * 7 + kx] = red[0][k] + red[1][k] + red[2][k] + red[3][k];
     }
 }
 
 int pa_launch_stem_wgrad_reduce(const float* part, int splits, float* dst, hipStream_t st) {
-    hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3(37), dim3(256), 0, st, part, splits, dst);
+    hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3(64), dim3(1024), 0, st, part, splits, dst);
     return (int)hipGetLastError();
 }
