@@ -7,10 +7,10 @@
 //     forward: reference models/asn_stacked_hg.py:36-41) or BatchNorm backward (PA_LD_LIN2, dgrad) is
 //     applied during this single pass, zero padding is written as zeros, 1.4x read amplification
 //     instead of 9x;
-//   * streams the weight tile [BN][64] of every (tap, 64-channel slice) with global_load_lds
-//     (16 B per lane, no VGPR staging, no ds_write), double buffered: slice t+1 is in flight while slice
-//     t feeds the MFMAs; the LDS image is [row][64] with the 16-byte slot XOR-swizzled by (row & 7),
-//     realised on the per-lane SOURCE address (the LDS side of global_load_lds is lane-linear);
+//   * streams the weight slice [BN][32] of every (tap, 32-channel slice) with global_load_lds (16 B per
+//     lane, no VGPR staging, no ds_write) through a ring of 4 LDS buffers: slices t+1, t+2 are in flight
+//     while slice t feeds the MFMAs (counted s_waitcnt vmcnt + raw s_barrier); the 16-byte slot swizzle
+//     is realised on the per-lane SOURCE address (the LDS side of global_load_lds is lane-linear);
 //   * reads the activation fragment of tap (dy,dx) straight from the halo at pixel offset
 //     (dy*18 + dx): no per-tap address or bounds arithmetic besides one add and the swizzle.
 // Halo image: [180 pixels][CIN] bf16, 16-byte slot XOR-swizzled by the pixel index so that the 16
@@ -32,16 +32,20 @@
 template <int CPP>
 __device__ __forceinline__ int halo_sw(int p) { return CPP == 16 ? ((p & 7) | ((p & 1) << 3)) : ((p >> 1) & 7); }
 
-template <int CIN, int BN, int LDMODE>
-__global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(PaConvArgs a) {
-    constexpr int TH = 8, TW = 16, PW = TW + 2, HP = (TH + 2) * PW;       // 180 halo pixels
+// TW x TH = spatial block of one image; a workgroup always owns 128 output pixels = IMG blocks.  16 x 8: one block of
+// a big map.  8 x 8 / 4 x 4: the low-resolution levels, where the block IS the image and a workgroup takes 2 / 8
+// images (the generic kernel needs 20 us for these 384..1536-pixel problems: 18-36 serial K-steps with two barriers).
+template <int CIN, int BN, int LDMODE, int TW = 16, int TH = 8>
+__global__ __launch_bounds__(256, (TW == 16 ? 2 : 1)) void conv3x3_tile_kernel(PaConvArgs a) {
+    constexpr int IMG = 128 / (TW * TH), PW = TW + 2, PHh = TH + 2, HP = IMG * PHh * PW;   // 180 / 200 / 288 halo pixels
     constexpr int CPP = CIN / 8;                                         // 16-byte chunks per pixel
     constexpr int NI = BN / 32, MI = 4;
-    constexpr int KT = CIN / 64;                                         // 64-channel slices per tap
+    constexpr int NSL = CIN / 32;                                        // 32-channel weight slices per tap
+    constexpr int NIT = 9 * NSL, NBUF = 4, NIW = BN / 64;                // ring of 4 slices [BN][32]; glds per wave per slice
     constexpr int PSTEP = 256 / CPP;                                     // halo pixels staged per pass
     constexpr int NPASS = (HP + PSTEP - 1) / PSTEP;
     // ONE shared object (a second one makes hipcc drain vmcnt(0) before every ds_read of the pipeline)
-    __shared__ __attribute__((aligned(16))) bf16 lds[HP * CIN + 2 * BN * 64];
+    __shared__ __attribute__((aligned(16))) bf16 lds[HP * CIN + NBUF * BN * 32];
     bf16* halo = lds;
     bf16* wbuf = lds + HP * CIN;
 
@@ -52,27 +56,28 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(PaConvArgs a) {
     int t = blockIdx.x;
     const int tx = t % tiles_x; t /= tiles_x;
     const int ty = t % tiles_y;
-    const int b = t / tiles_y;
+    const int b = (t / tiles_y) * IMG;                 // first image of this workgroup
     const int y0 = ty * TH, x0 = tx * TW;
     const int n0 = blockIdx.y * BN;
     const int K = 9 * CIN;
 
-    // ---- weight slices: wave w streams LDS rows [w*BN/4, (w+1)*BN/4) in NI instructions of 8 rows x 8 slots
-    const bf16* wsrc[NI];
+    // ---- weight slices [BN][32] (64-byte rows): wave w streams LDS rows [w*BN/4, (w+1)*BN/4), one instruction =
+    // 16 rows x 4 slots.  Slot swizzle wsw(row) = (-(row >> 2)) & 3: conflict-free for ds_read_b128's lane groups
+    // (rows 0-3/12-15 at chunk c with rows 4-11 at chunk c^1).  Slice `it` covers k = 32*it .. 32*it+31.
+    const bf16* wsrc[NIW];
 #pragma unroll
-    for (int i = 0; i < NI; ++i) {
-        const int lr = wave * (BN / 4) + i * 8 + (lane >> 3);
-        const int slot = lane & 7;
-        wsrc[i] = a.w + (size_t)(n0 + pa_weight_row_of_lds_row<BN, NI>(lr)) * K + ((slot ^ (lr & 7)) << 3);
+    for (int i = 0; i < NIW; ++i) {
+        const int lr = wave * (BN / 4) + i * 16 + (lane >> 2);
+        const int slot = lane & 3;
+        wsrc[i] = a.w + (size_t)(n0 + pa_weight_row_of_lds_row<BN, NI>(lr)) * K + ((slot ^ ((-(lr >> 2)) & 3)) << 3);
     }
-    auto issue_w = [&](int it, int buf) {
-        const int koff = (it / KT) * CIN + (it % KT) * 64;
+    auto issue_w = [&](int it) {
+        bf16* dst = wbuf + (it % NBUF) * (BN * 32) + wave * (BN / 4) * 32;
 #pragma unroll
-        for (int i = 0; i < NI; ++i)
-            __builtin_amdgcn_global_load_lds(PA_GLOBAL_PTR(wsrc[i] + koff),
-                                             PA_LDS_PTR(wbuf + buf * (BN * 64) + (wave * (BN / 4) + i * 8) * 64), 16, 0, 0);
+        for (int i = 0; i < NIW; ++i)
+            __builtin_amdgcn_global_load_lds(PA_GLOBAL_PTR(wsrc[i] + it * 32), PA_LDS_PTR(dst + i * 16 * 32), 16, 0, 0);
     };
-    issue_w(0, 0);
+    issue_w(0); issue_w(1); issue_w(2);
 
     // ---- halo staging (single pass over the input, transform applied here)
     {
@@ -96,11 +101,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(PaConvArgs a) {
 #pragma unroll
             for (int u = 0; u < UN; ++u) {
                 hp[u] = (p0 + u) * PSTEP + tid / CPP;
-                const int hy = hp[u] / PW, hx = hp[u] - hy * PW;
+                const int im = IMG == 1 ? 0 : hp[u] / (PHh * PW);
+                const int hr = hp[u] - im * (PHh * PW);
+                const int hy = hr / PW, hx = hr - hy * PW;
                 const int y = y0 + hy - 1, x = x0 + hx - 1;
-                ok[u] = hp[u] < HP && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
+                ok[u] = hp[u] < HP && b + im < a.B && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
                 // unconditional (clamped) loads: a branch around a load makes hipcc wait vmcnt(0) per element
-                const size_t idx = ok[u] ? (img + (size_t)y * a.W + x) * CIN + c : 0;
+                const size_t idx = ok[u] ? (img + ((size_t)im * a.H + y) * a.W + x) * CIN + c : 0;
                 ra[u] = *reinterpret_cast<const bf16x8*>(a.in.p + idx);
                 if (LDMODE == PA_LD_LIN2) rq[u] = *reinterpret_cast<const bf16x8*>(a.in.q + idx);
             }
@@ -140,13 +147,21 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(PaConvArgs a) {
     const int frow = lane & 15, fchk = lane >> 4;
     int pbase[MI], boff[NI];
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi) pbase[mi] = (wm * 4 + mi + 1) * PW + frow + 1;
+    for (int mi = 0; mi < MI; ++mi) {
+        const int l = (wm * 4 + mi) * 16 + frow;                         // pixel 0..127 of the workgroup
+        const int im = l / (TW * TH), r = l - im * (TW * TH);
+        pbase[mi] = im * (PHh * PW) + (r / TW + 1) * PW + r % TW + 1;
+    }
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
         const int row = wn * (BN / 2) + ni * 16 + frow;
-        boff[ni] = row * 64 + ((fchk ^ (row & 7)) << 3);
+        boff[ni] = row * 32 + ((fchk ^ ((-(row >> 2)) & 3)) << 3);
     }
 
+    // K loop: slice `it` is consumed while slices it+1, it+2 are in flight and it+3 is issued right after the barrier
+    // into the buffer that was read in iteration it-1.  Counted vmcnt + raw s_barrier: __syncthreads() would drain
+    // the LDS-DMA queue (vmcnt(0)) and expose one L2 round trip per slice, which is what bounded the first version
+    // of this kernel (0.7 us per 64-channel slice = 30 % MFMA utilisation).
     for (int tap = 0; tap < 9; ++tap) {
         const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
         const int toff = dy * PW + dx;
@@ -159,58 +174,84 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(PaConvArgs a) {
             aoff[mi] = p * CIN + ((fchk ^ halo_sw<CPP>(p)) << 3);
         }
 #pragma unroll
-        for (int kh = 0; kh < KT; ++kh) {
-            const int it = tap * KT + kh;
-            if (it + 1 < 9 * KT) issue_w(it + 1, (it + 1) & 1);
-            const bf16* Bs = wbuf + (it & 1) * (BN * 64);
+        for (int sub = 0; sub < NSL; ++sub) {
+            const int it = tap * NSL + sub;
+            const int rem = NIT - 1 - it;                       // slices issued after this one (at most 2 outstanding)
+            if (NIW == 2) {
+                if (rem >= 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else if (rem == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            } else {
+                if (rem >= 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                else if (rem == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+            if (it + 3 < NIT) issue_w(it + 3);
+            const bf16* Bs = wbuf + (it % NBUF) * (BN * 32);
+            bf16x8 fa[MI], fw[NI];
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                bf16x8 fa[MI], fw[NI];
+            for (int mi = 0; mi < MI; ++mi)
+                fa[mi] = *reinterpret_cast<const bf16x8*>(halo + (aoff[mi] ^ ((sub * 4) << 3)));
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+                fw[ni] = *reinterpret_cast<const bf16x8*>(Bs + boff[ni]);
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi)
-                    fa[mi] = *reinterpret_cast<const bf16x8*>(halo + (aoff[mi] ^ ((kh * 8 + kk * 4) << 3)));
-#pragma unroll
-                for (int ni = 0; ni < NI; ++ni)
-                    fw[ni] = *reinterpret_cast<const bf16x8*>(Bs + (boff[ni] ^ ((kk * 4) << 3)));
-#pragma unroll
-                for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-                    for (int mi = 0; mi < MI; ++mi)
-                        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[ni], fa[mi], acc[ni][mi], 0, 0, 0);
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[ni], fa[mi], acc[ni][mi], 0, 0, 0);
         }
     }
+    __syncthreads();            // every wave is done with the halo and the ring before the epilogue reuses the LDS
 
     pa_conv_epilogue<BN, NI, MI>(a, acc, n0, wm, wn,
-                                 [&](int mi) { return (b * a.H + y0 + wm * 4 + mi) * a.W + x0 + (lane & 15); },
+                                 [&](int mi) {
+                                     const int l = (wm * 4 + mi) * 16 + (lane & 15);
+                                     const int im = l / (TW * TH), r = l - im * (TW * TH);
+                                     return b + im < a.B ? ((b + im) * a.H + y0 + r / TW) * a.W + x0 + r % TW : -1;
+                                 },
                                  reinterpret_cast<float*>(lds), (int)blockIdx.x);
 }
 
-template <int CIN, int BN>
+template <int CIN, int BN, int TW, int TH>
 static void launch_tile_ld(const PaConvArgs& a, dim3 grid, hipStream_t st) {
     switch (a.in.mode) {
-        case PA_LD_PLAIN: hipLaunchKernelGGL((conv3x3_tile_kernel<CIN, BN, PA_LD_PLAIN>), grid, dim3(256), 0, st, a); break;
-        case PA_LD_BNRELU: hipLaunchKernelGGL((conv3x3_tile_kernel<CIN, BN, PA_LD_BNRELU>), grid, dim3(256), 0, st, a); break;
-        default: hipLaunchKernelGGL((conv3x3_tile_kernel<CIN, BN, PA_LD_LIN2>), grid, dim3(256), 0, st, a); break;
+        case PA_LD_PLAIN: hipLaunchKernelGGL((conv3x3_tile_kernel<CIN, BN, PA_LD_PLAIN, TW, TH>), grid, dim3(256), 0, st, a); break;
+        case PA_LD_BNRELU: hipLaunchKernelGGL((conv3x3_tile_kernel<CIN, BN, PA_LD_BNRELU, TW, TH>), grid, dim3(256), 0, st, a); break;
+        default: hipLaunchKernelGGL((conv3x3_tile_kernel<CIN, BN, PA_LD_LIN2, TW, TH>), grid, dim3(256), 0, st, a); break;
     }
 }
 
+template <int TW, int TH>
+static void launch_tile_shape(const PaConvArgs& a, dim3 grid, bool bigN, hipStream_t st) {
+    if (a.Cin == 128) { if (bigN) launch_tile_ld<128, 128, TW, TH>(a, grid, st); else launch_tile_ld<128, 64, TW, TH>(a, grid, st); }
+    else { if (bigN) launch_tile_ld<64, 128, TW, TH>(a, grid, st); else launch_tile_ld<64, 64, TW, TH>(a, grid, st); }
+}
+
+static bool small_map(const PaConvArgs& a) { return (a.H == 8 && a.W == 8) || (a.H == 4 && a.W == 4); }
+
 bool pa_conv3x3_tile_supported(const PaConvArgs& a) {
-    return a.taps == 9 && (a.Cin == 64 || a.Cin == 128) && a.Cout % 64 == 0 && a.H % 8 == 0 && a.W % 16 == 0;
+    static int nosmall = -1;
+    if (nosmall < 0) nosmall = getenv("PA_CONV3_NOSMALL") ? 1 : 0;
+    if (a.taps != 9 || (a.Cin != 64 && a.Cin != 128) || a.Cout % 64 != 0) return false;
+    return (a.H % 8 == 0 && a.W % 16 == 0) || (!nosmall && small_map(a));
 }
 
 int pa_launch_conv3x3_tile(const PaConvArgs& a, hipStream_t st, int* stat_rows) {
     if (!pa_conv3x3_tile_supported(a)) { pa_set_error_msg("pa_launch_conv3x3_tile: unsupported shape"); return 1; }
-    const int tiles = a.B * (a.H / 8) * (a.W / 16);
+    const bool small = !(a.H % 8 == 0 && a.W % 16 == 0);
+    const int img = small ? 128 / (a.H * a.W) : 1;
+    const int tiles = small ? (a.B + img - 1) / img : a.B * (a.H / 8) * (a.W / 16);
     if (stat_rows) *stat_rows = tiles;
     if (a.ep.rows_out) *a.ep.rows_out = tiles;
     static int n64 = -1;
     if (n64 < 0) n64 = getenv("PA_CONV3_BN64") ? 1 : 0;          // experiment: 64-channel halves
-    const bool bigN = a.Cout % 128 == 0 && !n64;
+    // the low-resolution levels have 3..12 pixel tiles: 64-channel halves double the number of workgroups
+    const bool bigN = a.Cout % 128 == 0 && !n64 && !small;
     dim3 grid(tiles, a.Cout / (bigN ? 128 : 64));
-    if (a.Cin == 128) { if (bigN) launch_tile_ld<128, 128>(a, grid, st); else launch_tile_ld<128, 64>(a, grid, st); }
-    else { if (bigN) launch_tile_ld<64, 128>(a, grid, st); else launch_tile_ld<64, 64>(a, grid, st); }
+    if (!small) launch_tile_shape<16, 8>(a, grid, bigN, st);
+    else if (a.H == 8) launch_tile_shape<8, 8>(a, grid, bigN, st);
+    else launch_tile_shape<4, 4>(a, grid, bigN, st);
     return (int)hipGetLastError();
 }

@@ -52,6 +52,10 @@ SHAPES = [
     (3, 256, 128, 64, 64, 1),    # 96 row tiles of 128 pixels
     (3, 64, 128, 65, 63, 1),     # ragged M = 12285 -> last row tile partly empty
     (4, 64, 64, 64, 64, 1),      # 64-channel blocks on both sides
+    # low-resolution levels: one workgroup = 2 images of 8x8 / 8 images of 4x4 (ragged image counts)
+    (3, 128, 128, 8, 8, 3),
+    (5, 64, 128, 4, 4, 3),
+    (24, 128, 128, 4, 4, 3),
 ]
 
 
