@@ -9,7 +9,7 @@ def cls(name):
         ld, taps, stem = int(m.group(3)), int(m.group(4)), m.group(5) == 'true'
         if stem: return 'stem_fwd_7x7'
         return ('conv_dgrad_' if ld == 2 else 'conv_fwd_') + ('3x3' if taps == 9 else '1x1')
-    m = re.match(r'void conv3x3_tile_kernel<(\d+), (\d+), (\d+)>', name)
+    m = re.match(r'void conv3x3_tile_kernel<(\d+), (\d+), (\d+)[,>]', name)
     if m: return 'conv_dgrad_3x3' if int(m.group(3)) == 2 else 'conv_fwd_3x3'
     m = re.match(r'void conv1x1_tile_kernel<(\d+), (\d+), (\d+), (\d+)>', name)
     if m: return 'conv_dgrad_1x1' if int(m.group(4)) == 2 else 'conv_fwd_1x1'
