@@ -73,6 +73,7 @@ def main():
     ap.add_argument('--bs', type=int, default=24, help='per-GPU batch (BASELINE config: 24)')
     ap.add_argument('--stacks', type=int, default=2)
     ap.add_argument('--chan', type=int, default=256)
+    ap.add_argument('--res', type=int, default=256, help='network input resolution (SURVEY.md C5: --stacks 8 --res 384 --bs 16)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     args = ap.parse_args()
@@ -88,12 +89,12 @@ def main():
     if world != args.gpus:
         raise SystemExit('bench.py --gpus %d needs WORLD_SIZE=%d (launch N > 1 with torch.distributed.run)' % (args.gpus, args.gpus))
     dev = torch.device('cuda', torch.cuda.current_device())
-    B, res = args.bs, 256
+    B, res = args.bs, args.res
     net = create_hg(args.stacks, 1, 16, args.chan, res=res, default_batch=B)
     net.reset_parameters(seed=0)
     broadcast_parameters(net)
     opt = RMSprop(net, lr=2.5e-4, alpha=0.99, eps=1e-8)
-    aug = Augmenter(seed=100 + rank)
+    aug = Augmenter(seed=100 + rank, inp_res=res, out_res=res // 4)
     batches = [DeviceBatch.synthetic(B, seed=rank * 100 + k) for k in range(2)]       # resident in HBM
     net.train()
 
@@ -162,21 +163,22 @@ def main():
                     'classes': {r['kernel']: {'ms_per_step': round(r['ms_total'] / args.steps, 3),
                                               'tflops': round(r['flops'] / (r['ms_total'] * 1e-3) / 1e12, 1),
                                               'gbps': round(r['bytes'] / (r['ms_total'] * 1e-3) / 1e9, 1)} for r in rows},
-                    'whole_step': {'hbm_frac': round(value / world * 380.5e6 / HBM_PEAK, 4),
-                                   'mfma_frac': round(value / world * 50.0e9 / MFMA_PEAK, 4)}}
+                    'whole_step': ({'hbm_frac': round(value / world * 380.5e6 / HBM_PEAK, 4),
+                                    'mfma_frac': round(value / world * 50.0e9 / MFMA_PEAK, 4)}
+                                   if (args.stacks, args.chan, res) == (2, 256, 256) else None)}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args.stacks, args.chan, B, res)
 
     if rank == 0:
-        line = {'metric': 'images/sec, 2-stack HG 256x256 bs=24 per GPU, full training step', 'value': round(value, 2),
+        line = {'metric': 'images/sec, %d-stack HG %dx%d bs=%d per GPU, full training step' % (args.stacks, res, res, B), 'value': round(value, 2),
                 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
                 'ms_per_step': round(1e3 * dt / args.steps, 3), 'higher_is_better': True, 'scaling': 'weak',
                 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
-                'config': {'workload': 'BASELINE configs[1]: %d-stack hourglass chan %d, bs=%d/GPU, 256x256 MPII-shape synthetic frames '
+                'config': {'workload': '%s%d-stack hourglass chan %d, bs=%d/GPU, %dx%d MPII-shape synthetic frames '
                                        '(720x1280 uint8 resident in HBM), on-device HumanAug warp, heat-map MSE, RMSprop, PCKh'
-                                       % (args.stacks, args.chan, B),
+                                       % ('BASELINE configs[1]: ' if (args.stacks, args.chan, res, B) == (2, 256, 256, 24) else '', args.stacks, args.chan, B, res, res),
                            'global_batch': world * B, 'parallelism': 'dp%d' % world,
                            'loss': float(loss), 'pckh': float(pckh), 'pckh_origin_res': float(pckh_o)},
                 'roofline': roofline, 'cpu_baseline': cpu}

@@ -196,3 +196,28 @@ def test_full_size_config_runs_and_is_finite():
     assert np.isfinite(float(loss)) and abs(float(loss) - recomputed) / recomputed < 1e-4
     assert bool(torch.isfinite(net.flat_grads).all())
     assert net.num_params() == 6570784
+
+
+def test_eight_stack_384_config_matches_oracle_loss():
+    """SURVEY.md config C5 shape (8-stack, 384x384 -> 96x96 maps; here B=2): map sizes 96, 48, 24, 12, 6 exercise the
+    halo-tile kernels (96, 48) AND the generic ones (24, 12, 6: not multiples of 8x16).  Loss vs the fp32 oracle,
+    loss consistency with the returned heat maps, finite gradients, parameter count of the reference module tree."""
+    torch.set_num_threads(8)
+    B, res, chan = 2, 384, 256
+    ref, net = _hg_pair(8, chan, B, res, seed=5)
+    img = t(inputs.images(31, B, res))
+    pts = inputs.heat_pts(32, B, res=res // 4)
+    heat = t(inputs.heatmaps_from_pts(pts, res=res // 4))
+    ref.train(); net.train()
+    with torch.no_grad():
+        out_ref = ref(img)
+    loss_ref = float(opl.stack_mse(out_ref, heat))
+    loss, outs = net.loss_and_backward(img.cuda(), t(pts).cuda(), want_outputs=True)
+    assert len(outs) == 8 and tuple(outs[-1].shape) == (B, 16, 96, 96)
+    assert abs(float(loss) - loss_ref) / loss_ref < 2e-2, (float(loss), loss_ref)
+    recomputed = sum(float(((o.cpu() - heat) ** 2).mean()) for o in outs)
+    assert abs(float(loss) - recomputed) / recomputed < 1e-4
+    assert bool(torch.isfinite(net.flat_grads).all()) and float(net.flat_grads.abs().max()) > 0
+    assert net.num_params() == sum(p.numel() for p in ref.parameters())
+    # first stack's heat map: 3 blocks + one hourglass deep, still well conditioned
+    assert rel_rms(outs[0].cpu(), out_ref[0]) < 0.15
