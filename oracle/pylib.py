@@ -276,6 +276,72 @@ def approx_pckh(pred, target, idxs, res):
     return avg / (len(idxs) - bad)
 
 
+def _acc_dists(pred, target, normalize):
+    """The distance matrix every HumanAcc function builds first (e.g. pylib/HumanAcc.py:12-20): [n_joints][n_samples],
+    ||target - pred|| / normalize where both target coordinates are > 0, else -1.  normalize: scalar or [n_samples]."""
+    assert pred.size() == target.size()
+    target = target.float(); pred = pred.float()
+    d = (target - pred).pow(2).sum(-1).sqrt().t()                      # [J][B]
+    nm = torch.as_tensor(normalize, dtype=torch.float32).reshape(1, -1)
+    d = d / nm
+    valid = ((target[..., 0] > 0) & (target[..., 1] > 0)).t()
+    return torch.where(valid, d, torch.full_like(d, -1.0))
+
+
+def _joint_acc(row, thr=0.5):
+    """per-joint accuracy of one distance row, -1 when the row has no valid entry (pylib/HumanAcc.py:26-37)."""
+    valid = row.ne(-1)
+    if int(valid.sum()) == 0:
+        return -1.0
+    return float((row.le(thr) & valid).sum()) / float(valid.sum())
+
+
+def approx_pckh_per(pred, target, idxs, res):
+    """pylib/HumanAcc.py:46-84 -> (average over the joints with a valid sample, per-joint accuracies, -1 = none valid)."""
+    dists = _acc_dists(pred, target, res // 10)
+    pck = torch.tensor([_joint_acc(dists[int(i)]) for i in idxs], dtype=torch.float32)
+    good = pck.ge(0)
+    return float(pck[good].sum() / good.sum()), pck
+
+
+def pckh_report(pred, target, normalizer):
+    """pylib/HumanAcc.py:86-137 (PCKh prints, returns nothing): (per-joint PCKh [n], 7 body-part means in the printed
+    order Head, Knee, Ankle, Shoulder, Elbow, Wrist, Hip, average over the joints with a valid sample)."""
+    dists = _acc_dists(pred, target, torch.as_tensor(normalizer, dtype=torch.float32).reshape(-1))
+    pck = torch.tensor([_joint_acc(dists[i]) for i in range(dists.size(0))], dtype=torch.float32)
+    parts = [[8, 9], [1, 4], [0, 5], [12, 13], [11, 14], [10, 15], [2, 3]]
+    part_means = torch.tensor([(float(pck[a]) + float(pck[b])) / 2 for a, b in parts])
+    good = pck.ge(0)
+    return pck, part_means, float(pck[good].sum() / good.sum())
+
+
+def approx_pckh_samples(pred, target, res):
+    """pylib/HumanAcc.py:139-177: number of correctly predicted joints per sample."""
+    dists = _acc_dists(pred, target, res // 10)
+    return (dists.le(0.5) & dists.ne(-1)).sum(0).float()
+
+
+def correct_predicted_joints(pred, target, res):
+    """pylib/HumanAcc.py:179-218: uint8 mask [n_samples][n_joints]."""
+    dists = _acc_dists(pred, target, res // 10)
+    return (dists.le(0.5) & dists.ne(-1)).t().to(torch.uint8)
+
+
+def correct_predicted_joints_original_resolution(pred, target, normalizer):
+    """pylib/HumanAcc.py:220-259: same with a caller-given scalar normaliser."""
+    dists = _acc_dists(pred, target, float(normalizer))
+    return (dists.le(0.5) & dists.ne(-1)).t().to(torch.uint8)
+
+
+def predicted_joints_dist_to_grnd(pred, target, res):
+    """pylib/HumanAcc.py:261-308: mean normalised distance over the valid joints of each sample (0 if none)."""
+    dists = _acc_dists(pred, target, res // 10)
+    valid = dists.ne(-1)
+    n = valid.sum(0)
+    tot = torch.where(valid, dists, torch.zeros_like(dists)).sum(0)
+    return torch.where(n > 0, tot / n.clamp(min=1), torch.zeros_like(tot))
+
+
 # --------------------------------------------------------------- Criterion
 def weighted_l2(pred, gt, weight):
     """pylib/Criterion.py:12-18."""

@@ -124,6 +124,18 @@ def gen_pylib(R):
     pp = out['ev_get_preds']
     gp = Evaluation.get_preds(t(tgt)).numpy()
     out['acc_approx_pckh'] = np.array(HumanAcc.approx_PCKh(t(pp), t(gp), idx, 64), dtype=np.float64)
+    # the rest of the HumanAcc family (pylib/HumanAcc.py:46-308)
+    import contextlib, io
+    avg, per = HumanAcc.approx_PCKh_per(t(pp), t(gp), idx, 64)
+    out['acc_per_avg'] = np.array(float(avg)); out['acc_per'] = per.numpy()
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        HumanAcc.PCKh(t(pp), t(gp), t(norm).float() / 20)
+    out['acc_pckh_print'] = np.array([float(l.split(':')[1]) for l in buf.getvalue().strip().splitlines()])
+    out['acc_samples'] = HumanAcc.approx_PCKh_samples(t(pp), t(gp), 64).numpy()
+    out['acc_correct'] = HumanAcc.correct_predicted_joints(t(pp), t(gp), 64).numpy()
+    out['acc_correct_orig'] = HumanAcc.correct_predicted_joints_original_resolution(t(pp), t(gp), 2.5).numpy()
+    out['acc_dist_to_grnd'] = HumanAcc.predicted_joints_dist_to_grnd(t(pp), t(gp), 64).numpy()
     out['flip_maps'] = HumanAug.shuffle_channels_for_horizontal_flipping(HumanAug.flip_channels(t(pred[:1].copy()))).numpy()
     # --- loss (a6)
     w = inputs.rng(14).random(pred.shape, dtype=np.float32) + 0.5

@@ -88,6 +88,21 @@ def test_evaluation_and_humanacc(P):
     assert abs(pk - float(g['acc_approx_pckh'])) < 1e-4
     fl = P.HumanAug.shuffle_channels_for_horizontal_flipping(P.HumanAug.flip_channels(t(pred[:1].copy())))
     assert np.array_equal(fl.numpy(), g['flip_maps'])
+    # the rest of the HumanAcc family (pylib/HumanAcc.py:46-308) against the reference's goldens
+    A = P.HumanAcc
+    pp_, gp_ = E.get_preds(t(pred)), E.get_preds(t(tgt))
+    avg, per = A.approx_PCKh_per(pp_, gp_, idx, 64)
+    assert abs(avg - float(g['acc_per_avg'])) < 1e-4 and np.allclose(per.cpu().numpy(), g['acc_per'], atol=1e-4)
+    import contextlib, io
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        assert A.PCKh(pp_, gp_, t(norm).float() / 20) is None
+    printed = np.array([float(l.split(':')[1]) for l in buf.getvalue().strip().splitlines()])
+    assert np.allclose(printed, g['acc_pckh_print'], atol=1.01e-4)
+    assert np.array_equal(A.approx_PCKh_samples(pp_, gp_, 64).cpu().numpy(), g['acc_samples'])
+    assert np.array_equal(A.correct_predicted_joints(pp_, gp_, 64).cpu().numpy(), g['acc_correct'])
+    assert np.array_equal(A.correct_predicted_joints_original_resolution(pp_, gp_, 2.5).cpu().numpy(), g['acc_correct_orig'])
+    assert np.allclose(A.predicted_joints_dist_to_grnd(pp_, gp_, 64).cpu().numpy(), g['acc_dist_to_grnd'], atol=1e-6)
     # calc_dists matrix vs the oracle
     from oracle import pylib as opl
     d = E.calc_dists(E.get_preds(t(pred)), E.get_preds(t(tgt)), torch.ones(n) * 6.4).cpu()

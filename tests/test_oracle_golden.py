@@ -85,6 +85,16 @@ def test_evaluation_and_humanacc():
     pk = opl.approx_pckh(opl.get_preds(t(pred)), opl.get_preds(t(tgt)), idx, 64)
     assert abs(pk - float(g['acc_approx_pckh'])) < 1e-7
     assert np.array_equal(opl.flip_heatmaps(t(pred[:1].copy())).numpy(), g['flip_maps'])
+    # the rest of the HumanAcc family (pylib/HumanAcc.py:46-308)
+    pp_, gp_ = opl.get_preds(t(pred)), opl.get_preds(t(tgt))
+    avg, per = opl.approx_pckh_per(pp_, gp_, idx, 64)
+    assert abs(avg - float(g['acc_per_avg'])) < 1e-6 and np.allclose(per.numpy(), g['acc_per'], atol=1e-7)
+    _, parts, avg_all = opl.pckh_report(pp_, gp_, t(norm).float() / 20)
+    assert np.allclose(np.append(parts.numpy(), avg_all), g['acc_pckh_print'], atol=5.1e-5)       # printed with %.4f
+    assert np.array_equal(opl.approx_pckh_samples(pp_, gp_, 64).numpy(), g['acc_samples'])
+    assert np.array_equal(opl.correct_predicted_joints(pp_, gp_, 64).numpy(), g['acc_correct'])
+    assert np.array_equal(opl.correct_predicted_joints_original_resolution(pp_, gp_, 2.5).numpy(), g['acc_correct_orig'])
+    assert np.allclose(opl.predicted_joints_dist_to_grnd(pp_, gp_, 64).numpy(), g['acc_dist_to_grnd'], atol=1e-6)
 
 
 def test_losses_and_reward_shaping():
