@@ -97,6 +97,23 @@ __device__ __forceinline__ void pa_read8(const PaOperand& op, size_t idx, int c,
     else pa_load8<PA_LD_LIN2>(op, idx, c, v);
 }
 
+// the transform of pa_read8 applied to values that were loaded earlier (raw p / q chunks of channel c..c+7)
+__device__ __forceinline__ void pa_apply8(const PaOperand& op, const bf16x8& p, const bf16x8& q, int c, float (&v)[8]) {
+    if (op.mode == PA_LD_NONE) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = 0.f;
+    } else if (op.mode == PA_LD_PLAIN) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (float)p[j];
+    } else if (op.mode == PA_LD_BNRELU) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = fmaxf(fmaf(op.k0[c + j], (float)p[j], op.k1[c + j]), 0.f);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = fmaf(op.k0[c + j], (float)p[j], fmaf(op.k1[c + j], (float)q[j], op.k2[c + j]));
+    }
+}
+
 // runtime-mode 4-wide operand read used by epilogues (8-byte accesses)
 __device__ __forceinline__ void pa_read4(const PaOperand& op, size_t idx, int c, float (&v)[4]) {
     if (op.mode == PA_LD_NONE) { v[0] = v[1] = v[2] = v[3] = 0.f; return; }

@@ -142,10 +142,12 @@ __global__ __launch_bounds__(256, (CIN == 128 && BM == 64) ? 3 : 2) void conv1x1
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
         }
-        pa_conv_epilogue<BN, NI, MI>(a, acc, (nb0 + nbi) * BN, wm, wn,
-                                     [&](int mi) { const int m = m0 + wm * (BM / 2) + mi * 16 + (lane & 15); return m < M ? m : -1; },
-                                     red, (int)blockIdx.x);
-        __syncthreads();            // `red` is reused by the next channel block
+        // the ring half that the last K step read is free now (the other one holds the next block's first slice)
+        float* T = reinterpret_cast<float*>(wbuf + ((nbi * KT + KT - 1) & 1) * (BN * 64));
+        pa_conv_epilogue_auto<BN, NI, MI>(a, acc, (nb0 + nbi) * BN, wm, wn,
+                                         [&](int wr, int mi, int p) { const int m = m0 + wr * (BM / 2) + mi * 16 + p; return m < M ? m : -1; },
+                                         T, (int)blockIdx.x);
+        __syncthreads();            // T is handed back to the weight ring
     }
 }
 

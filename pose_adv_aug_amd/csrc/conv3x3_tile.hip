@@ -205,13 +205,13 @@ __global__ __launch_bounds__(256, (TW == 16 ? 2 : 1)) void conv3x3_tile_kernel(P
     }
     __syncthreads();            // every wave is done with the halo and the ring before the epilogue reuses the LDS
 
-    pa_conv_epilogue<BN, NI, MI>(a, acc, n0, wm, wn,
-                                 [&](int mi) {
-                                     const int l = (wm * 4 + mi) * 16 + (lane & 15);
-                                     const int im = l / (TW * TH), r = l - im * (TW * TH);
-                                     return b + im < a.B ? ((b + im) * a.H + y0 + r / TW) * a.W + x0 + r % TW : -1;
-                                 },
-                                 reinterpret_cast<float*>(lds), (int)blockIdx.x);
+    pa_conv_epilogue_auto<BN, NI, MI>(a, acc, n0, wm, wn,
+                                     [&](int wr, int mi, int p) {
+                                         const int l = (wr * 4 + mi) * 16 + p;
+                                         const int im = l / (TW * TH), r = l - im * (TW * TH);
+                                         return b + im < a.B ? ((b + im) * a.H + y0 + r / TW) * a.W + x0 + r % TW : -1;
+                                     },
+                                     reinterpret_cast<float*>(lds), (int)blockIdx.x);
 }
 
 template <int CIN, int BN, int TW, int TH>

@@ -99,3 +99,98 @@ __device__ __forceinline__ void pa_conv_epilogue(const PaConvArgs& a, f32x4 (&ac
         }
     }
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// LDS-TRANSPOSED epilogue.  The direct epilogue above stores, per instruction, 16-byte pieces that lie 32 bytes apart
+// in 16 different pixel rows: measured on the 3x3 tile kernel (tools/bench_conv3.py ablation) the plain store of a
+// 25 MB output costs 11.6 us = 2.2 TB/s, a third of the kernel.  Here the accumulators go through a 16 KB fp32 LDS
+// tile, 32 pixel rows at a time, and are read back so that 16 (BN = 128) consecutive lanes cover one whole 256-byte
+// pixel row: every global access of the epilogue (addends, reference tensor, output) is a fully coalesced 16 B/lane
+// stream, and a thread owns the SAME 8 channels for all its pixels (bias / BatchNorm constants loaded once,
+// per-channel reductions in registers).  Arithmetic and rounding points are those of pa_conv_epilogue.
+//   T   : >= 32 * BN floats of LDS that are dead after the K loop (16-byte slots XOR-swizzled by the row)
+//   pix : (wm, mi, p) -> flattened NHWC pixel index of pixel p (0..15) of fragment row-block mi of wave row wm, or -1
+// Measured (tools/bench_conv1.py, bench.py): forward epilogues (plain / statistics, with residual addends) gain 10-30 %
+// on the 1x1 kernels; the BatchNorm-backward epilogue (reference tensor + mask + two reductions) is SLOWER this way
+// (one memory round trip per 32-row pass is exposed to all 256 threads by the pass barrier; prefetching the next
+// sweep's operands costs more registers than it hides).  pa_conv_epilogue_auto therefore keeps the direct epilogue
+// for PA_OUT_BWD.
+template <int BN, int NI, int MI, class PixFn>
+__device__ __forceinline__ void pa_conv_epilogue_lds(const PaConvArgs& a, f32x4 (&acc)[NI][MI], int n0, int wm, int wn,
+                                                     PixFn pix, float* T, int stat_row) {
+    constexpr int CPR = BN / 8;                      // 8-channel chunks per pixel row
+    constexpr int RPS = 256 / CPR;                   // pixel rows per sweep of the 256 threads
+    constexpr int SW = 32 / RPS;                     // sweeps per 32-row pass
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int N = a.Cout;
+    const int chunk = tid % CPR, rsub = tid / CPR;
+    const int n = n0 + chunk * 8;
+    float bias[8], s1[8], s2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; bias[j] = a.bias ? a.bias[n + j] : 0.f; }
+    // writer side: lane (q = lane >> 4, p = lane & 15) of wave (wm, wn) holds channels wn*BN/2 + q*4*NI + 4*ni + reg of pixel p
+    const int wrow = wm * 16 + (lane & 15);
+    const int wslot0 = (wn * (BN / 2) + (lane >> 4) * (4 * NI)) / 4;          // first 16-byte slot (4 floats) of the lane's channels
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        if (mi) __syncthreads();                     // the previous pass has been read
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+            *reinterpret_cast<f32x4*>(T + wrow * BN + (((wslot0 + ni) ^ (wrow & 7)) << 2)) = acc[ni][mi];
+        __syncthreads();
+#pragma unroll
+        for (int sw = 0; sw < SW; ++sw) {
+            const int r = sw * RPS + rsub;           // 0..31: wave row r >> 4, pixel r & 15
+            const int m = pix(r >> 4, mi, r & 15);
+            if (m < 0) continue;
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(T + r * BN + (((2 * chunk) ^ (r & 7)) << 2));
+            const f32x4 v1 = *reinterpret_cast<const f32x4*>(T + r * BN + (((2 * chunk + 1) ^ (r & 7)) << 2));
+            const size_t idx = (size_t)m * N + n;
+            float e1[8], e2[8];
+            pa_read8(a.add1, idx, n, e1);
+            pa_read8(a.add2, idx, n, e2);
+            bf16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float v = (j < 4 ? v0[j & 3] : v1[j & 3]) + bias[j] + e1[j] + e2[j];
+                o[j] = (bf16)v;
+                float rv = (float)o[j];
+                s1[j] += rv;
+                s2[j] += rv * rv;
+            }
+            *reinterpret_cast<bf16x8*>(a.out + idx) = o;
+        }
+    }
+    if (a.ep.mode != PA_OUT_PLAIN) {
+        // threads with the same chunk: lanes l, l + CPR, ... of a wave, then the 4 waves through LDS
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+#pragma unroll
+            for (int o = CPR; o < 64; o <<= 1) { s1[j] += __shfl_xor(s1[j], o, 64); s2[j] += __shfl_xor(s2[j], o, 64); }
+        }
+        __syncthreads();                             // T is dead
+        const int wave = tid >> 6;
+        if (lane < CPR) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { T[(wave * BN + chunk * 8 + j) * 2] = s1[j]; T[(wave * BN + chunk * 8 + j) * 2 + 1] = s2[j]; }
+        }
+        __syncthreads();
+        for (int c = tid; c < BN; c += 256) {
+            f32x2 v = {T[c * 2] + T[(BN + c) * 2] + T[(2 * BN + c) * 2] + T[(3 * BN + c) * 2],
+                       T[c * 2 + 1] + T[(BN + c) * 2 + 1] + T[(2 * BN + c) * 2 + 1] + T[(3 * BN + c) * 2 + 1]};
+            *reinterpret_cast<f32x2*>(a.ep.stats + ((size_t)stat_row * N + n0 + c) * 2) = v;
+        }
+    }
+}
+
+// forward epilogues through LDS (coalesced rows), backward epilogue direct; pix(wm, mi, p) as above
+template <int BN, int NI, int MI, class PixFn>
+__device__ __forceinline__ void pa_conv_epilogue_auto(const PaConvArgs& a, f32x4 (&acc)[NI][MI], int n0, int wm, int wn,
+                                                      PixFn pix, float* T, int stat_row) {
+    if (a.ep.mode == PA_OUT_BWD) {
+        const int p = threadIdx.x & 15;
+        pa_conv_epilogue<BN, NI, MI>(a, acc, n0, wm, wn, [&](int mi) { return pix(wm, mi, p); }, T, stat_row);
+    } else {
+        pa_conv_epilogue_lds<BN, NI, MI>(a, acc, n0, wm, wn, pix, T, stat_row);
+    }
+}

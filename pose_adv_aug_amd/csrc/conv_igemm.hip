@@ -190,9 +190,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(PaConvArgs a) {
     }
 
     // ---------------------------------------------------------------- epilogue (conv_epilogue.h)
-    pa_conv_epilogue<BN, NI, MI>(a, acc, n0, wm, wn,
-                                 [&](int mi) { const int m = m0 + wm * (BM / 2) + mi * 16 + (lane & 15); return m < M ? m : -1; },
-                                 reinterpret_cast<float*>(lds), (int)blockIdx.x);
+    pa_conv_epilogue_auto<BN, NI, MI>(a, acc, n0, wm, wn,
+                                     [&](int wr, int mi, int p) { const int m = m0 + wr * (BM / 2) + mi * 16 + p; return m < M ? m : -1; },
+                                     reinterpret_cast<float*>(lds), (int)blockIdx.x);
 }
 
 template <int BM, int BN, int TAPS>
