@@ -35,13 +35,18 @@ __device__ __forceinline__ int halo_sw(int p) { return CPP == 16 ? ((p & 7) | ((
 // TW x TH = spatial block of one image; a workgroup always owns 128 output pixels = IMG blocks.  16 x 8: one block of
 // a big map.  8 x 8 / 4 x 4: the low-resolution levels, where the block IS the image and a workgroup takes 2 / 8
 // images (the generic kernel needs 20 us for these 384..1536-pixel problems: 18-36 serial K-steps with two barriers).
+// 16 x 4 (BM = 64 pixels): smaller halo and a ring of 3 slices = 52 KB of LDS -> THREE workgroups per CU, and 1536
+// instead of 768 workgroups for a 24 x 64 x 64 map (2 full rounds): staging, K loop and epilogue of different
+// workgroups overlap instead of running in lockstep.
 template <int CIN, int BN, int LDMODE, int TW = 16, int TH = 8>
-__global__ __launch_bounds__(256, (TW == 16 ? 2 : 1)) void conv3x3_tile_kernel(PaConvArgs a) {
-    constexpr int IMG = 128 / (TW * TH), PW = TW + 2, PHh = TH + 2, HP = IMG * PHh * PW;   // 180 / 200 / 288 halo pixels
+__global__ __launch_bounds__(256, (TW == 16 ? (TH == 4 ? 3 : 2) : 1)) void conv3x3_tile_kernel(PaConvArgs a) {
+    constexpr int BM = (TW == 16 && TH == 4) ? 64 : 128;
+    constexpr int IMG = BM / (TW * TH), PW = TW + 2, PHh = TH + 2, HP = IMG * PHh * PW;   // 180 / 108 / 200 / 288 halo pixels
     constexpr int CPP = CIN / 8;                                         // 16-byte chunks per pixel
-    constexpr int NI = BN / 32, MI = 4;
+    constexpr int NI = BN / 32, MI = BM / 32;
     constexpr int NSL = CIN / 32;                                        // 32-channel weight slices per tap
-    constexpr int NIT = 9 * NSL, NBUF = 4, NIW = BN / 64;                // ring of 4 slices [BN][32]; glds per wave per slice
+    constexpr int NIT = 9 * NSL, NBUF = BM == 64 ? 3 : 4, NIW = BN / 64;  // ring of NBUF slices [BN][32]; glds per wave per slice
+    constexpr int AHEAD = NBUF - 2;                                      // slices still in flight while one is consumed
     constexpr int PSTEP = 256 / CPP;                                     // halo pixels staged per pass
     constexpr int NPASS = (HP + PSTEP - 1) / PSTEP;
     // ONE shared object (a second one makes hipcc drain vmcnt(0) before every ds_read of the pipeline)
@@ -77,7 +82,8 @@ __global__ __launch_bounds__(256, (TW == 16 ? 2 : 1)) void conv3x3_tile_kernel(P
         for (int i = 0; i < NIW; ++i)
             __builtin_amdgcn_global_load_lds(PA_GLOBAL_PTR(wsrc[i] + it * 32), PA_LDS_PTR(dst + i * 16 * 32), 16, 0, 0);
     };
-    issue_w(0); issue_w(1); issue_w(2);
+    issue_w(0); issue_w(1);
+    if (NBUF == 4) issue_w(2);
 
     // ---- halo staging (single pass over the input, transform applied here)
     {
@@ -148,7 +154,7 @@ __global__ __launch_bounds__(256, (TW == 16 ? 2 : 1)) void conv3x3_tile_kernel(P
     int pbase[MI], boff[NI];
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
-        const int l = (wm * 4 + mi) * 16 + frow;                         // pixel 0..127 of the workgroup
+        const int l = (wm * MI + mi) * 16 + frow;                        // pixel 0..BM-1 of the workgroup
         const int im = l / (TW * TH), r = l - im * (TW * TH);
         pbase[mi] = im * (PHh * PW) + (r / TW + 1) * PW + r % TW + 1;
     }
@@ -177,17 +183,13 @@ __global__ __launch_bounds__(256, (TW == 16 ? 2 : 1)) void conv3x3_tile_kernel(P
         for (int sub = 0; sub < NSL; ++sub) {
             const int it = tap * NSL + sub;
             const int rem = NIT - 1 - it;                       // slices issued after this one (at most 2 outstanding)
-            if (NIW == 2) {
-                if (rem >= 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                else if (rem == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            } else {
-                if (rem >= 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-                else if (rem == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            __builtin_amdgcn_s_barrier();
-            if (it + 3 < NIT) issue_w(it + 3);
+            const int fly = rem < AHEAD ? rem : AHEAD;          // slices issued after this one that may stay in flight
+            if (fly * NIW == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else if (fly * NIW == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else if (fly * NIW == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (it + NBUF - 1 < NIT) issue_w(it + NBUF - 1);
             const bf16* Bs = wbuf + (it % NBUF) * (BN * 32);
             bf16x8 fa[MI], fw[NI];
 #pragma unroll
@@ -207,7 +209,7 @@ __global__ __launch_bounds__(256, (TW == 16 ? 2 : 1)) void conv3x3_tile_kernel(P
 
     pa_conv_epilogue_auto<BN, NI, MI>(a, acc, n0, wm, wn,
                                      [&](int wr, int mi, int p) {
-                                         const int l = (wr * 4 + mi) * 16 + p;
+                                         const int l = (wr * MI + mi) * 16 + p;
                                          const int im = l / (TW * TH), r = l - im * (TW * TH);
                                          return b + im < a.B ? ((b + im) * a.H + y0 + r / TW) * a.W + x0 + r % TW : -1;
                                      },
@@ -242,7 +244,13 @@ int pa_launch_conv3x3_tile(const PaConvArgs& a, hipStream_t st, int* stat_rows) 
     if (!pa_conv3x3_tile_supported(a)) { pa_set_error_msg("pa_launch_conv3x3_tile: unsupported shape"); return 1; }
     const bool small = !(a.H % 8 == 0 && a.W % 16 == 0);
     const int img = small ? 128 / (a.H * a.W) : 1;
-    const int tiles = small ? (a.B + img - 1) / img : a.B * (a.H / 8) * (a.W / 16);
+    // 16 x 4 pixel tiles (3 workgroups per CU) where 16 x 8 tiles would leave CUs idle: measured 64x64 maps (768 tiles)
+    // 39.8 vs 42.8 us in favour of 16 x 8, 32x32 maps (192 tiles) 17.6 vs 14.6 us in favour of 16 x 4
+    static int bm64 = -1;
+    if (bm64 < 0) { const char* e = getenv("PA_CONV3_BM64"); bm64 = e ? atoi(e) : -2; }
+    const int tiles128 = small ? 0 : a.B * (a.H / 8) * (a.W / 16);
+    const bool half = !small && a.Cin == 128 && (bm64 == -2 ? tiles128 < 512 : bm64 != 0);
+    const int tiles = small ? (a.B + img - 1) / img : a.B * (a.H / (half ? 4 : 8)) * (a.W / 16);
     if (stat_rows) *stat_rows = tiles;
     if (a.ep.rows_out) *a.ep.rows_out = tiles;
     static int n64 = -1;
@@ -250,7 +258,8 @@ int pa_launch_conv3x3_tile(const PaConvArgs& a, hipStream_t st, int* stat_rows) 
     // the low-resolution levels have 3..12 pixel tiles: 64-channel halves double the number of workgroups
     const bool bigN = a.Cout % 128 == 0 && !n64 && !small;
     dim3 grid(tiles, a.Cout / (bigN ? 128 : 64));
-    if (!small) launch_tile_shape<16, 8>(a, grid, bigN, st);
+    if (half) launch_tile_shape<16, 4>(a, grid, bigN, st);
+    else if (!small) launch_tile_shape<16, 8>(a, grid, bigN, st);
     else if (a.H == 8) launch_tile_shape<8, 8>(a, grid, bigN, st);
     else launch_tile_shape<4, 4>(a, grid, bigN, st);
     return (int)hipGetLastError();
