@@ -244,8 +244,60 @@ __global__ void argmax_kernel(const float* maps, long sb, long sj, long sp, int 
     }
 }
 
+// The engine's own heat maps are [B][H*W][16] (joint-minor): the generic kernel reads them with a 64-byte stride per lane
+// (26 us for 6 MB).  Here one workgroup takes one sample, a thread reads whole pixels (four 16-byte loads = 16 joints)
+// and keeps the 16 running maxima; shuffle + LDS reduction with the same first-maximum tie rule.
+__global__ __launch_bounds__(1024) void argmax_nhwc16_kernel(const float* maps, int H, int W, float* preds, float* maxval) {
+    __shared__ float sv[16][16];
+    __shared__ int si[16][16];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int HW = H * W;
+    const f32x4* base = reinterpret_cast<const f32x4*>(maps + (size_t)b * HW * 16);
+    float best[16]; int bi[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { best[j] = -INFINITY; bi[j] = 0x7fffffff; }
+    for (int p = tid; p < HW; p += 1024) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 v = base[(size_t)p * 4 + q];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int j = q * 4 + r;
+                if (v[r] > best[j]) { best[j] = v[r]; bi[j] = p; }       // p increases: the first maximum is kept
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            float ov = __shfl_xor(best[j], o, 64);
+            int oi = __shfl_xor(bi[j], o, 64);
+            if (ov > best[j] || (ov == best[j] && oi < bi[j])) { best[j] = ov; bi[j] = oi; }
+        }
+        if (lane == 0) { sv[wave][j] = best[j]; si[wave][j] = bi[j]; }
+    }
+    __syncthreads();
+    if (tid < 16) {
+        float bv = sv[0][tid]; int bx = si[0][tid];
+#pragma unroll
+        for (int w = 1; w < 16; ++w) {
+            if (sv[w][tid] > bv || (sv[w][tid] == bv && si[w][tid] < bx)) { bv = sv[w][tid]; bx = si[w][tid]; }
+        }
+        float x = (float)(bx % W + 1), y = floorf((float)bx / (float)H) + 1.f;   // the reference divides by size(2)
+        if (!(bv > 0.f)) { x = 0.f; y = 0.f; }
+        preds[((size_t)b * 16 + tid) * 2] = x;
+        preds[((size_t)b * 16 + tid) * 2 + 1] = y;
+        if (maxval) maxval[(size_t)b * 16 + tid] = bv;
+    }
+}
+
 int pa_launch_argmax(const float* maps, long sb, long sj, long sp, int B, int J, int H, int W, float* preds, float* maxval,
                      hipStream_t st) {
+    if (J == 16 && sj == 1 && sp == 16 && sb == (long)H * W * 16 && (reinterpret_cast<uintptr_t>(maps) & 15) == 0) {
+        hipLaunchKernelGGL(argmax_nhwc16_kernel, dim3(B), dim3(1024), 0, st, maps, H, W, preds, maxval);
+        return (int)hipGetLastError();
+    }
     int waves = B * J;
     hipLaunchKernelGGL(argmax_kernel, dim3((waves + 3) / 4), dim3(256), 0, st, maps, sb, sj, sp, B, J, H, W, preds, maxval);
     return (int)hipGetLastError();
