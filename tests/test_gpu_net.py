@@ -221,3 +221,32 @@ def test_eight_stack_384_config_matches_oracle_loss():
     assert net.num_params() == sum(p.numel() for p in ref.parameters())
     # first stack's heat map: 3 blocks + one hourglass deep, still well conditioned
     assert rel_rms(outs[0].cpu(), out_ref[0]) < 0.15
+
+
+def test_training_is_bitwise_reproducible_across_runs_and_stream_modes():
+    """Race screen for the whole step.  Every reduction of the engine is order-deterministic (per-workgroup partial
+    rows, slab reduction, shuffle trees -- no float atomics on anything that feeds the gradients), so N training steps
+    from the same state must give BITWISE identical parameters and running statistics from run to run, and with the
+    engine's side streams (hourglass skip branches, weight-gradient stream) on or off.  A missing event / barrier shows
+    up here as a mismatch."""
+    from pose_adv_aug_amd import _lib
+    from pose_adv_aug_amd.stack_hg import train_step
+    from pose_adv_aug_amd.data import Augmenter, DeviceBatch
+    from pose_adv_aug_amd.models.asn_stacked_hg import create_hg
+    from pose_adv_aug_amd.utils.optim import RMSprop
+    B, steps = 24, 4
+
+    def run(multi):
+        net = create_hg(2, 1, 16, 256, res=256, default_batch=B); net.reset_parameters(seed=0)
+        opt = RMSprop(net, lr=2.5e-4, alpha=0.99, eps=1e-8); aug = Augmenter(seed=1)
+        batches = [DeviceBatch.synthetic(B, seed=k) for k in range(2)]
+        net.train()
+        _lib.check(_lib.lib().pa_net_set_multi_stream(net._net(B), 1 if multi else 0))
+        for i in range(steps):
+            train_step(net, opt, aug, batches[i % 2])
+        torch.cuda.synchronize()
+        return net.flat_params.clone(), net.flat_buffers.clone()
+    a, b, c = run(True), run(True), run(False)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]), 'run-to-run mismatch (race?)'
+    assert torch.equal(a[0], c[0]) and torch.equal(a[1], c[1]), 'side streams change the result (missing dependency?)'
+    assert bool(torch.isfinite(a[0]).all())
