@@ -172,6 +172,9 @@ const float* pa_asn_probs(const pa_net* asn);
  * utils/util.py:147) + backward into the agent's flat gradient; no gradient reaches the pose net.
  * target_* [B][K] fp32 device; loss: device fp32 scalar or NULL. */
 int pa_asn_backward(pa_net* asn, pa_net* pose, const float* target_scale, const float* target_rot, float* loss);
+/* eps of log(softmax + eps) in that loss: 1e-7 (default, joint-train-pose-s-r-agent.py:399-404) or 0 for the agent
+ * pre-training, which uses LogSoftmax (pretrain-s-r-agent.py:177-190). */
+int pa_asn_set_log_eps(pa_net* asn, float eps);
 
 /* Evaluation.accuracy (pylib/Evaluation.py:54-75) of stack i's heat maps against the Gaussian target
  * of the joints given to the last forward: acc [nidx+1]. */

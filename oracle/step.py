@@ -70,3 +70,20 @@ def validate_batch(net, img, heat, center, scale, rot, grnd_pts, normalizer, pck
     pckh_o = pylib.accuracy_origin_res(output, center, scale, res, grnd_pts, normalizer, rot)   # :237-238
     preds = pylib.final_preds(output, center, scale, res, rot)                # :253
     return loss, pckh[0], pckh_o[0], preds, output
+
+
+def lost_pckh_distribution(pckhs):
+    """collect-scale-ditri.py:215-238 for the per-person PCKh of the K deterministic crops of ONE person (tensor [K]):
+    lost = 1 - pckh, normalised; uniform when all K crops are perfect; negative entries are an error there (exit())."""
+    lost = 1 - pckhs
+    if float(lost.sum()) == 0:
+        return torch.ones(lost.size(0)) / lost.size(0)
+    assert not bool((lost < 0).any())
+    return lost / lost.sum()
+
+
+def pretrain_kl_loss(scale_logits, rot_logits, scale_distri, rot_distri):
+    """pretrain-s-r-agent.py:175-190: F.kl_div(LogSoftmax(pred), target) * K per head (element-mean reduction), summed."""
+    ls = F.kl_div(F.log_softmax(scale_logits, 1), scale_distri, reduction='mean') * scale_distri.size(1)
+    lr = F.kl_div(F.log_softmax(rot_logits, 1), rot_distri, reduction='mean') * rot_distri.size(1)
+    return ls + lr

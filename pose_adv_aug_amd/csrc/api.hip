@@ -311,6 +311,7 @@ int pa_asn_backward(pa_net* asn, pa_net* pose, const float* target_scale, const 
 }
 
 const float* pa_asn_probs(const pa_net* asn) { return asn->n.asn_probs; }
+int pa_asn_set_log_eps(pa_net* asn, float eps) { asn->n.asn_log_eps = eps; return 0; }
 
 void pa_net_destroy(pa_net* net) { delete net; }
 

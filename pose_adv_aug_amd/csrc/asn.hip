@@ -88,10 +88,11 @@ __global__ void asn_head_fwd_kernel(PaOperand x, int HW, int C, const float* ws,
 }
 
 // KL loss (joint-train-pose-s-r-agent.py:399-407): sum over the two heads of
-//   K * mean_{b,k} t * (log t - log(p + 1e-7)),  p = softmax(logits)
+//   K * mean_{b,k} t * (log t - log(p + eps)),  p = softmax(logits); eps = 1e-7 in the joint loop, 0 in the agent
+//   pre-training (pretrain-s-r-agent.py:177-190 uses LogSoftmax)
 // d/dlogits, d/dfeat (spread back over the HW pixels as the gradient of the average pool), loss value.
 __global__ void asn_head_bwd_kernel(const float* probs, const float* target_s, const float* target_r, const float* ws, const float* wr,
-                                    int Ks, int Kr, int HW, int C, int B, float* dlogits, bf16* dact, float* loss) {
+                                    int Ks, int Kr, int HW, int C, int B, float* dlogits, bf16* dact, float* loss, float leps) {
     extern __shared__ float sm[];          // [Ks+Kr] dlogits
     const int b = blockIdx.x, K = Ks + Kr;
     if (threadIdx.x < 2) {
@@ -100,11 +101,11 @@ __global__ void asn_head_bwd_kernel(const float* probs, const float* target_s, c
         const float* p = probs + (size_t)b * K + k0;
         float l = 0.f, gp = 0.f;
         for (int k = 0; k < kn; ++k) {
-            if (t[k] > 0.f) l += t[k] * (logf(t[k]) - logf(p[k] + 1e-7f));
-            gp += (-t[k] / ((float)B * (p[k] + 1e-7f))) * p[k];
+            if (t[k] > 0.f) l += t[k] * (logf(t[k]) - logf(p[k] + leps));
+            gp += (-t[k] / ((float)B * (p[k] + leps))) * p[k];
         }
         for (int k = 0; k < kn; ++k) {
-            const float g = -t[k] / ((float)B * (p[k] + 1e-7f));
+            const float g = -t[k] / ((float)B * (p[k] + leps));
             const float dz = p[k] * (g - gp);
             sm[k0 + k] = dz;
             dlogits[(size_t)b * K + k0 + k] = dz;
@@ -237,7 +238,7 @@ int Net::asn_backward(Net& pose, const float* target_s, const float* target_r, f
     const int HW = top.H * top.W, K = scale_num + rot_num;
     bf16* dact = asn_pa[3].grad;                   // scratch of the right size [B][4][4][C]; rewritten later in this pass
     hipLaunchKernelGGL(asn_head_bwd_kernel, dim3(B), dim3(256), K * sizeof(float), st, asn_probs, target_s, target_r,
-                       params + p_fcs_w, params + p_fcr_w, scale_num, rot_num, HW, chan, B, asn_dlogits, dact, loss_dev);
+                       params + p_fcs_w, params + p_fcr_w, scale_num, rot_num, HW, chan, B, asn_dlogits, dact, loss_dev, asn_log_eps);
     TRY((int)hipGetLastError());
     hipLaunchKernelGGL(asn_fc_wgrad_kernel, dim3(8), dim3(256), 0, st, asn_dlogits, asn_feat, B, scale_num, rot_num, chan,
                        grads + p_fcs_w, grads + p_fcs_b, grads + p_fcr_w, grads + p_fcr_b);

@@ -207,6 +207,7 @@ struct Net {
     void declare_asn();
     size_t layout_asn(char* base);
     int asn_forward(Net& pose, bool train, float* logits_s, float* logits_r);
+    float asn_log_eps = 1e-7f;                 // log(softmax + eps) of the agent's KL loss
     int asn_backward(Net& pose, const float* target_s, const float* target_r, float* loss_out);
 };
 

@@ -75,6 +75,17 @@ class Augmenter(object):
         self.step += 1
         return self._finish(batch, want_nchw)
 
+    def fixed(self, batch, scale_exp=0.0, rot=0.0, want_nchw=False):
+        """deterministic crop at scale * 2**scale_exp and rotation `rot` degrees, no flip / colour jitter: the 7 + 7 crops
+        per person of the distribution collection (data/collect_scale_distri.py:149-157, data/collect_rotation_distri.py)."""
+        p = batch.params
+        p.zero_()
+        p[:, 0:3] = batch.meta[:, 0:3].double()
+        p[:, 2] *= 2.0 ** float(scale_exp)
+        p[:, 3] = float(rot)
+        p[:, 5:8] = 1.0
+        return self._finish(batch, want_nchw)
+
     def standard(self, batch, want_nchw=False):
         """un-augmented crop (inp_std, data/joint_train_s_r_agent.py:160): scale as annotated, no rotation / flip / jitter."""
         p = batch.params

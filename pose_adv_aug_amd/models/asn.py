@@ -45,11 +45,24 @@ class ASN(_HipModule):
         self._last_B, self._last_pose = B, pose
         return ls, lr
 
-    def loss_and_backward(self, grnd_scale_distri, grnd_rotation_distri):
-        """KL(log(softmax + 1e-7) || target) * K for both heads (joint-train-pose-s-r-agent.py:399-407) and its
-        gradient w.r.t. the agent's parameters (flat_grads).  Returns the loss as a 0-d GPU tensor."""
+    @staticmethod
+    def kl_loss(scale_logits, rot_logits, grnd_scale_distri, grnd_rotation_distri, log_eps=1e-7):
+        """the same loss value without a backward pass (validation, pretrain-s-r-agent.py:228-238): [B][7] device tensors."""
+        total = 0.0
+        for logits, t in ((scale_logits, grnd_scale_distri), (rot_logits, grnd_rotation_distri)):
+            t = t.to(logits.device, torch.float32)
+            logp = torch.log(torch.softmax(logits, 1) + log_eps) if log_eps > 0 else torch.log_softmax(logits, 1)
+            kl = torch.where(t > 0, t * (torch.log(t.clamp(min=1e-30)) - logp), torch.zeros_like(t))
+            total = total + kl.mean() * t.shape[1]
+        return total
+
+    def loss_and_backward(self, grnd_scale_distri, grnd_rotation_distri, log_eps=1e-7):
+        """KL(log(softmax + log_eps) || target) * K for both heads and its gradient w.r.t. the agent's parameters
+        (flat_grads).  log_eps = 1e-7: joint-train-pose-s-r-agent.py:399-407; log_eps = 0: the LogSoftmax form of the
+        agent pre-training (pretrain-s-r-agent.py:177-190).  Returns the loss as a 0-d GPU tensor."""
         B, pose = self._last_B, self._last_pose
         dev = self.flat_params.device
+        check(lib().pa_asn_set_log_eps(self._net(B), float(log_eps)), 'pa_asn_set_log_eps')
         ts = grnd_scale_distri.to(dev, torch.float32).contiguous()
         tr = grnd_rotation_distri.to(dev, torch.float32).contiguous()
         loss = torch.zeros(1, dtype=torch.float32, device=dev)

@@ -1,0 +1,143 @@
+"""Stage 2 of the reference on the HIP engine: collect the per-person scale / rotation "hardness" distributions
+(collect-scale-ditri.py, collect-rotation-ditri.py) and pre-train the ASN agent against them (pretrain-s-r-agent.py).
+
+For every person the trained pose net (eval mode) sees 7 deterministic crops -- scale * 2**mean_k (or rotation mean_k) --
+and `1 - per_person_pckh` of the 7 crops, normalised, is the target distribution of that person
+(collect-scale-ditri.py:215-240; uniform if all 7 are perfect).  The text format is the reference's: one row of 7
+`%.2f` numbers per image.  Pre-training minimises K * KL(LogSoftmax(agent(half-hourglass features)) || target) for both
+heads with RMSprop (pretrain-s-r-agent.py:148-205).  Everything numeric runs on the device."""
+import os
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from .data import Augmenter, DeviceBatch
+from .utils.util import AverageMeter
+
+SCALE_MEANS = np.arange(-0.6, 0.61, 0.2)        # data/collect_scale_distri.py (scale_means): s * 2**mean
+ROT_MEANS = np.arange(-60, 61, 20)              # data/collect_rotation_distri.py (rotation_means): degrees
+
+
+def lost_pckh_to_distribution(lost):
+    """collect-scale-ditri.py:224-238 for a [K][B] device tensor of 1 - PCKh: columns normalised to sum 1, uniform where a
+    column is all zero.  Negative entries are an error in the reference (exit())."""
+    if bool((lost < 0).any()):
+        raise ValueError('some of tmp_pckh is negative. error...')
+    tot = lost.sum(0, keepdim=True)
+    uni = torch.full_like(lost, 1.0 / lost.shape[0])
+    return torch.where(tot > 0, lost / tot.clamp(min=1e-30), uni).t().contiguous()          # [B][K]
+
+
+def collect_data(batches, hg, augmenter, kind, save_path=None):
+    """collect_data of collect-scale-ditri.py:123-255 (kind='scale') / collect-rotation-ditri.py (kind='rotation').
+    Returns the list of per-image distributions (CPU tensors of 7) and appends them to `save_path` as '%.2f' rows."""
+    assert kind in ('scale', 'rotation')
+    means = SCALE_MEANS if kind == 'scale' else ROT_MEANS
+    hg.eval()
+    grnd_distri_list = []
+    for i, batch in enumerate(batches):
+        lost = []
+        for m in means:
+            d = augmenter.fixed(batch, scale_exp=float(m), rot=0.0) if kind == 'scale' else augmenter.fixed(batch, 0.0, float(m))
+            hg.forward(img4=d['img4'], pts=d['pts'])
+            _, person = hg.pckh_origin_res(d['c'], d['s'], d['r'], d['grnd_pts'], d['normalizer'], per_person=True)
+            lost.append(1.0 - person)
+        distri = lost_pckh_to_distribution(torch.stack(lost, 0)).cpu()
+        for row in distri:
+            grnd_distri_list.append(row.clone())
+        if save_path is not None:
+            with open(save_path, 'a+') as log_file:
+                np.savetxt(log_file, distri.numpy(), fmt='%.2f')
+    return grnd_distri_list
+
+
+def read_grnd_distri_from_txt(load_path):
+    """pretrain-s-r-agent.py:262-275 / collect-scale-ditri.py:257-278."""
+    grnd_distri_list = []
+    with open(load_path, 'r') as fd:
+        for line in fd:
+            tmp_vec = torch.tensor([float(x) for x in line.split()], dtype=torch.float32)
+            assert abs(1 - float(tmp_vec.sum())) < 0.1
+            grnd_distri_list.append(tmp_vec)
+    return grnd_distri_list
+
+
+def _targets(distri_list, first, B, dev):
+    """data/pretrain_s_r_agent.py:127-128: rows renormalised (the text file rounds to 2 decimals)."""
+    t = torch.stack(distri_list[first:first + B], 0)
+    return (t / t.sum(1, keepdim=True)).to(dev)
+
+
+def _run(batches, scale_distri, rotation_distri, hg, agent, optimizer, augmenter, epoch, opt, log):
+    losses = AverageMeter()
+    hg.eval()
+    first, n = 0, len(batches)
+    for i, batch in enumerate(batches):
+        dev = batch.params.device
+        ts, tr = _targets(scale_distri, first, batch.B, dev), _targets(rotation_distri, first, batch.B, dev)
+        first += batch.B
+        std = augmenter.standard(batch)
+        ls, lr = hg(asn=agent, img4=std['img4'], is_half_hg=True, is_aug=True)         # pretrain-s-r-agent.py:172-173
+        if optimizer is not None:
+            loss = agent.loss_and_backward(ts, tr, log_eps=0.0)                         # :177-190 (LogSoftmax form)
+            optimizer.step()                                                            # :192-194
+        else:
+            loss = agent.kl_loss(ls, lr, ts, tr, log_eps=0.0)
+        losses.update(float(loss))
+        if i % opt.print_freq == 0 or i == n - 1:
+            log('%s epoch:%d, iters:%d/%d loss: %.4f' % ('sr-pretrain' if optimizer is not None else 'sr-val', epoch, i, n, losses.avg))
+    return losses.avg
+
+
+def train(batches, scale_distri, rotation_distri, hg, agent, optimizer, augmenter, epoch, opt, log=print):
+    """pretrain-s-r-agent.py:148-205."""
+    agent.train()
+    return _run(batches, scale_distri, rotation_distri, hg, agent, optimizer, augmenter, epoch, opt, log)
+
+
+def validate(batches, scale_distri, rotation_distri, hg, agent, augmenter, epoch, opt, log=print):
+    """pretrain-s-r-agent.py:207-259."""
+    agent.eval()
+    return _run(batches, scale_distri, rotation_distri, hg, agent, None, augmenter, epoch, opt, log)
+
+
+def main(argv=None):
+    """collect (if the text files are missing) + pre-train, on synthetic MPII-shape people."""
+    from .options.train_options import TrainOptions
+    from .utils.checkpoint import Checkpoint
+    from .utils.optim import RMSprop
+    from .utils.util import PoseTrainHistory
+    from .models.asn_stacked_hg import create_hg, create_asn
+    opt = TrainOptions().parse(argv)
+    sr_dir = os.path.join(opt.exp_dir, opt.exp_id, 'sr-pretrain')
+    os.makedirs(sr_dir, exist_ok=True)
+    hg = create_hg(num_stacks=2, num_modules=1, num_classes=16, chan=256, default_batch=opt.bs)
+    if opt.load_prefix_pose != '':
+        ck = Checkpoint(); ck.load_prefix = os.path.join(opt.exp_dir, opt.exp_id, opt.load_prefix_pose)[0:-1]
+        ck.load_checkpoint(hg)
+    agent = create_asn(chan_in=256, chan_out=256, scale_num=len(SCALE_MEANS), rotation_num=len(ROT_MEANS), is_aug=True,
+                       default_batch=opt.bs)
+    optimizer = RMSprop(agent, lr=opt.lr, alpha=0.99, eps=1e-8)
+    aug = Augmenter(seed=4321)
+    sets = {'train': [DeviceBatch.synthetic(opt.bs, seed=k) for k in range(4)],
+            'val': [DeviceBatch.synthetic(opt.bs, seed=700000 + k) for k in range(2)]}
+    distri = {}
+    for split, batches in sets.items():
+        for kind, fname in (('scale', '%s_scales.txt' % split), ('rotation', '%s_rotations.txt' % split)):
+            path = os.path.join(sr_dir, fname)
+            if not os.path.isfile(path):
+                collect_data(batches, hg, aug, kind, path)
+            distri[(split, kind)] = read_grnd_distri_from_txt(path)
+    history, ckpt = PoseTrainHistory(), Checkpoint()
+    ckpt.save_prefix = sr_dir + '/'
+    for epoch in range(opt.nEpochs):
+        tl = train(sets['train'], distri[('train', 'scale')], distri[('train', 'rotation')], hg, agent, optimizer, aug, epoch, opt)
+        vl = validate(sets['val'], distri[('val', 'scale')], distri[('val', 'rotation')], hg, agent, aug, epoch, opt)
+        history.update(OrderedDict([('epoch', epoch)]), OrderedDict([('lr', optimizer.param_groups[0]['lr'])]),
+                       OrderedDict([('train_loss', tl), ('val_loss', vl)]), OrderedDict([('train_pckh', 0.0), ('val_pckh', 0.0)]))
+        ckpt.save_checkpoint(agent, optimizer, history, is_asn=True)
+
+
+if __name__ == '__main__':
+    main()
