@@ -70,6 +70,14 @@ int pa_transform_pts(const float* pts, const double* params, const double* t, in
  * (network input layout, 4th channel 0) and/or outf: fp32 [B][3][res][res]; either may be NULL. */
 int pa_affine_warp_bilinear(const uint8_t* src, int Hs, int Ws, const double* tinv, const double* params,
                             int B, int res, void* out4, float* outf, void* stream);
+/* The same two calls for a batch of frames of DIFFERENT sizes stored top-left aligned in a padded [B][Hs][Ws][3] buffer
+ * (real MPII images: data/mpii_for_mpii.py:97-135 loads one JPEG per person).  sizes: int32 [B][2] = width, height of
+ * each sample's own frame: the zero padding outside it, the mirror of a flipped frame (x <- w_b - 1 - x) and the
+ * mirror of its joints (x <- w_b - x, pylib/HumanAug.py:236-257) use the sample's own width. */
+int pa_affine_warp_bilinear_sized(const uint8_t* src, int Hs, int Ws, const int32_t* sizes, const double* tinv,
+                                  const double* params, int B, int res, void* out4, float* outf, void* stream);
+int pa_transform_pts_sized(const float* pts, const double* params, const double* t, int B, int J, const int32_t* sizes,
+                           double* out, float* pts_img, void* stream);
 
 /* Validation with flip test-time augmentation (stack-hg.py:222-230).
  * pa_flip_lr_nhwc4: mirror the bf16 NHWC4 network input along W (img.numpy()[:, :, :, ::-1], :223).

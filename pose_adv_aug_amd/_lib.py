@@ -42,6 +42,8 @@ _PROTOS = {
     'pa_affine_params': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
     'pa_transform_pts': (_i, [_vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp]),
     'pa_affine_warp_bilinear': (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _vp]),
+    'pa_affine_warp_bilinear_sized': (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
+    'pa_transform_pts_sized': (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
     'pa_flip_lr_nhwc4': (_i, [_vp, _vp, _i, _i, _i, _vp]),
     'pa_flip_tta_merge': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'pa_sample_aug': (_i, [_vp, _vp, _vp, _i, _u64, _u64, _i, _vp, _vp]),

@@ -45,11 +45,21 @@ int pa_affine_params(const double* params, int B, int res_in, int res_out, doubl
 }
 int pa_transform_pts(const float* pts, const double* params, const double* t, int B, int J, float width, double* out,
                      float* pts_img, void* s) {
-    TRY(pa_launch_transform_pts(pts, params, t, B, J, width, out, pts_img, ST(s))); return 0;
+    TRY(pa_launch_transform_pts(pts, params, t, B, J, width, nullptr, out, pts_img, ST(s))); return 0;
+}
+int pa_transform_pts_sized(const float* pts, const double* params, const double* t, int B, int J, const int32_t* sizes, double* out,
+                           float* pts_img, void* s) {
+    if (!sizes) { pa_set_error_msg("pa_transform_pts_sized: sizes is NULL"); return 1; }
+    TRY(pa_launch_transform_pts(pts, params, t, B, J, 0.f, sizes, out, pts_img, ST(s))); return 0;
 }
 int pa_affine_warp_bilinear(const uint8_t* src, int Hs, int Ws, const double* tinv, const double* params, int B, int res,
                             void* out4, float* outf, void* s) {
-    TRY(pa_launch_warp(src, Hs, Ws, tinv, params, B, res, reinterpret_cast<bf16*>(out4), outf, ST(s))); return 0;
+    TRY(pa_launch_warp(src, Hs, Ws, nullptr, tinv, params, B, res, reinterpret_cast<bf16*>(out4), outf, ST(s))); return 0;
+}
+int pa_affine_warp_bilinear_sized(const uint8_t* src, int Hs, int Ws, const int32_t* sizes, const double* tinv, const double* params,
+                                  int B, int res, void* out4, float* outf, void* s) {
+    if (!sizes) { pa_set_error_msg("pa_affine_warp_bilinear_sized: sizes is NULL"); return 1; }
+    TRY(pa_launch_warp(src, Hs, Ws, sizes, tinv, params, B, res, reinterpret_cast<bf16*>(out4), outf, ST(s))); return 0;
 }
 int pa_flip_lr_nhwc4(const void* src, void* dst, int B, int H, int W, void* s) {
     TRY(pa_launch_flip_lr_nhwc4(reinterpret_cast<const bf16*>(src), reinterpret_cast<bf16*>(dst), B, H, W, ST(s))); return 0;

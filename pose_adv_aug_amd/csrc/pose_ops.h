@@ -15,9 +15,9 @@ int pa_launch_final_preds(const float* maps, long sb, long sj, long sp, const fl
 int pa_launch_pck(const float* pred, const float* gt, const float* norm, float boundary, const int* idxs, int nidx, float thr,
                   const float* vis, int B, int J, float* acc, float* person, float* dists_out, hipStream_t st);
 int pa_launch_affine_params(const double* params, int B, int res_in, int res_out, double* t_out, double* tinv_in, hipStream_t st);
-int pa_launch_transform_pts(const float* pts, const double* params, const double* t, int B, int J, float width, double* out,
-                            float* pts_img, hipStream_t st);
-int pa_launch_warp(const unsigned char* src, int Hs, int Ws, const double* tinv, const double* params, int B, int res,
+int pa_launch_transform_pts(const float* pts, const double* params, const double* t, int B, int J, float width, const int* sizes,
+                            double* out, float* pts_img, hipStream_t st);
+int pa_launch_warp(const unsigned char* src, int Hs, int Ws, const int* sizes, const double* tinv, const double* params, int B, int res,
                    bf16* out4, float* outf, hipStream_t st);
 int pa_launch_sample_aug(const float* meta, const int* scale_idx, const int* rot_idx, int mode, unsigned long long seed,
                          unsigned long long step, int B, double* params, hipStream_t st);

@@ -445,8 +445,9 @@ int pa_launch_affine_params(const double* params, int B, int res_in, int res_out
 
 // joints -> heat-map coordinates (reference pylib/HumanAug.py:45-54 + data/mpii_for_mpii.py:126-147):
 // optional mirror (x <- width - x, left/right joints swapped), transform, invalid (x<=0||y<=0) -> 0
-__global__ void transform_pts_kernel(const float* pts, const double* params, const double* t, int B, int J, float width, double* out,
-                                     float* pts_img) {
+// sizes (optional): int [B][2] = width, height of each sample's own frame (frames of a batch are padded to a common size)
+__global__ void transform_pts_kernel(const float* pts, const double* params, const double* t, int B, int J, float width,
+                                     const int* sizes, double* out, float* pts_img) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B * J) return;
     const int b = i / J, j = i - b * J;
@@ -457,6 +458,7 @@ __global__ void transform_pts_kernel(const float* pts, const double* params, con
         src = (j < 6) ? 5 - j : (j >= 10 ? 25 - j : j);
     }
     const float x = pts[((size_t)b * J + src) * 2], y = pts[((size_t)b * J + src) * 2 + 1];
+    if (sizes) width = (float)sizes[2 * b];
     const float fxf = flip ? width - x : x;          // the reference mirrors every joint, valid or not
     double ox = 0.0, oy = 0.0;
     if (!(fxf <= 0.f || y <= 0.f)) {
@@ -469,9 +471,9 @@ __global__ void transform_pts_kernel(const float* pts, const double* params, con
     if (pts_img) { pts_img[(size_t)i * 2] = fxf; pts_img[(size_t)i * 2 + 1] = y; }
 }
 
-int pa_launch_transform_pts(const float* pts, const double* params, const double* t, int B, int J, float width, double* out,
-                            float* pts_img, hipStream_t st) {
-    hipLaunchKernelGGL(transform_pts_kernel, dim3((B * J + 63) / 64), dim3(64), 0, st, pts, params, t, B, J, width, out, pts_img);
+int pa_launch_transform_pts(const float* pts, const double* params, const double* t, int B, int J, float width, const int* sizes,
+                            double* out, float* pts_img, hipStream_t st) {
+    hipLaunchKernelGGL(transform_pts_kernel, dim3((B * J + 63) / 64), dim3(64), 0, st, pts, params, t, B, J, width, sizes, out, pts_img);
     return (int)hipGetLastError();
 }
 
@@ -479,8 +481,9 @@ int pa_launch_transform_pts(const float* pts, const double* params, const double
 // reference pylib/HumanAug.py:117-176): out[b][v][u][c] = clamp(gain_c * bilinear(src_b, Tinv_b (u,v))),
 // zero outside the frame, optional mirror of the source frame, output NHWC with 4 channels (4th = 0).
 // src: uint8 [B][Hs][Ws][3].  out4: bf16 [B][res][res][4]; outf (optional): fp32 NCHW [B][3][res][res].
-__global__ void warp_kernel(const unsigned char* src, int Hs, int Ws, const double* tinv, const double* params, int B, int res,
-                            bf16* out4, float* outf) {
+// sizes (optional): int [B][2] = width, height of each sample's own frame inside the padded [Hs][Ws] buffer
+__global__ void warp_kernel(const unsigned char* src, int Hs, int Ws, const int* sizes, const double* tinv, const double* params, int B,
+                            int res, bf16* out4, float* outf) {
     const size_t total = (size_t)B * res * res;
     for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
         const int u = (int)(t % res);
@@ -489,6 +492,7 @@ __global__ void warp_kernel(const unsigned char* src, int Hs, int Ws, const doub
         const double* ti = tinv + (size_t)b * 6;
         const double* p = params + (size_t)b * 8;
         const bool flip = p[4] != 0.0;
+        const int wb = sizes ? sizes[2 * b] : Ws, hb = sizes ? sizes[2 * b + 1] : Hs;
         const double sx = ti[0] * u + ti[1] * v + ti[2], sy = ti[3] * u + ti[4] * v + ti[5];
         const double fx0 = floor(sx), fy0 = floor(sy);
         const int x0 = (int)fx0, y0 = (int)fy0;
@@ -498,8 +502,8 @@ __global__ void warp_kernel(const unsigned char* src, int Hs, int Ws, const doub
         for (int k = 0; k < 4; ++k) {
             const int xx = x0 + (k & 1), yy = y0 + (k >> 1);
             const double w = ((k & 1) ? ax : 1.0 - ax) * ((k >> 1) ? ay : 1.0 - ay);
-            if ((unsigned)xx < (unsigned)Ws && (unsigned)yy < (unsigned)Hs) {
-                const int xs = flip ? Ws - 1 - xx : xx;
+            if ((unsigned)xx < (unsigned)wb && (unsigned)yy < (unsigned)hb) {
+                const int xs = flip ? wb - 1 - xx : xx;
                 const unsigned char* px = src + (((size_t)b * Hs + yy) * Ws + xs) * 3;
                 acc[0] += w * ((double)px[0] / 255.0);
                 acc[1] += w * ((double)px[1] / 255.0);
@@ -522,12 +526,12 @@ __global__ void warp_kernel(const unsigned char* src, int Hs, int Ws, const doub
     }
 }
 
-int pa_launch_warp(const unsigned char* src, int Hs, int Ws, const double* tinv, const double* params, int B, int res,
+int pa_launch_warp(const unsigned char* src, int Hs, int Ws, const int* sizes, const double* tinv, const double* params, int B, int res,
                    bf16* out4, float* outf, hipStream_t st) {
     size_t total = (size_t)B * res * res;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(warp_kernel, dim3(blocks), dim3(256), 0, st, src, Hs, Ws, tinv, params, B, res, out4, outf);
+    hipLaunchKernelGGL(warp_kernel, dim3(blocks), dim3(256), 0, st, src, Hs, Ws, sizes, tinv, params, B, res, out4, outf);
     return (int)hipGetLastError();
 }
 

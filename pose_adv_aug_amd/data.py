@@ -16,7 +16,9 @@ from .pylib import HumanAug
 
 
 class DeviceBatch(object):
-    def __init__(self, frames, objpos, scale, joints, normalizer):
+    def __init__(self, frames, objpos, scale, joints, normalizer, sizes=None, index=None):
+        """sizes: optional [B][2] (width, height) of each person's own image when the frames are padded to a common size
+        (real MPII images); index: optional dataset indices of the samples (validation predictions are stored by index)."""
         require_gpu()
         dev = torch.device('cuda', torch.cuda.current_device())
         self.frames = frames.to(dev).contiguous()
@@ -26,6 +28,12 @@ class DeviceBatch(object):
         meta[:, 0:2] = torch.as_tensor(objpos, dtype=torch.float32)
         meta[:, 2] = torch.as_tensor(scale, dtype=torch.float32).reshape(-1)
         meta[:, 3] = float(Ws)
+        self.sizes = None
+        if sizes is not None:
+            sz = torch.as_tensor(sizes, dtype=torch.int32).reshape(B, 2)
+            meta[:, 3] = sz[:, 0].float()          # the flip of the centre mirrors about the sample's own width
+            self.sizes = sz.to(dev).contiguous()
+        self.index = None if index is None else [int(i) for i in index]
         self.meta = meta.to(dev)
         self.joints = torch.as_tensor(joints, dtype=torch.float32).to(dev).contiguous()
         self.normalizer = torch.as_tensor(normalizer, dtype=torch.float32).to(dev).contiguous()
@@ -56,8 +64,8 @@ class Augmenter(object):
 
     def _finish(self, batch, want_nchw=False):
         t_out, tinv = HumanAug.affine_params(batch.params, self.inp_res, self.out_res)
-        img4, imgf = HumanAug.warp_batch(batch.frames, tinv, batch.params, res=self.inp_res, want_nchw=want_nchw)
-        pts_heat, pts_img = HumanAug.transform_pts_batch(batch.joints, batch.params, t_out, batch.Ws)
+        img4, imgf = HumanAug.warp_batch(batch.frames, tinv, batch.params, res=self.inp_res, want_nchw=want_nchw, sizes=batch.sizes)
+        pts_heat, pts_img = HumanAug.transform_pts_batch(batch.joints, batch.params, t_out, batch.Ws, sizes=batch.sizes)
         return {'img4': img4, 'img': imgf, 'pts': pts_heat, 'grnd_pts': pts_img,
                 'c': batch.params[:, 0:2].float().contiguous(), 's': batch.params[:, 2].float().contiguous(),
                 'r': batch.params[:, 3].float().contiguous(), 'normalizer': batch.normalizer}

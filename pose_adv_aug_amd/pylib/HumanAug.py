@@ -52,7 +52,7 @@ def TransformPts(pts, center, scale, rot, res, size, invert=0):
     return np.dot(t, p)[0:2, :].T
 
 
-def transform_pts_batch(pts, params, t, width):
+def transform_pts_batch(pts, params, t, width, sizes=None):
     """device: joints [B][J][2] fp32 image px -> (heat-map coords [B][J][2] float64 with invalid joints
     zeroed, mirrored/swapped image-space joints [B][J][2] fp32).  pylib/HumanAug.py:45-54,236-257 and
     data/mpii_for_mpii.py:138-146."""
@@ -60,20 +60,28 @@ def transform_pts_batch(pts, params, t, width):
     B, J = p.shape[0], p.shape[1]
     out = torch.empty((B, J, 2), dtype=torch.float64, device=dev())
     img = torch.empty((B, J, 2), dtype=torch.float32, device=dev())
-    check(lib().pa_transform_pts(ptr(p), ptr(params), ptr(t), B, J, float(width), ptr(out), ptr(img), stream()),
-          'pa_transform_pts')
+    if sizes is not None:          # frames of different sizes: every sample mirrors about its own width
+        check(lib().pa_transform_pts_sized(ptr(p), ptr(params), ptr(t), B, J, ptr(sizes), ptr(out), ptr(img), stream()),
+              'pa_transform_pts_sized')
+    else:
+        check(lib().pa_transform_pts(ptr(p), ptr(params), ptr(t), B, J, float(width), ptr(out), ptr(img), stream()),
+              'pa_transform_pts')
     return out, img
 
 
-def warp_batch(frames, tinv, params, res=256, want_nchw=False, want_nhwc4=True):
+def warp_batch(frames, tinv, params, res=256, want_nchw=False, want_nhwc4=True, sizes=None):
     """device: uint8 frames [B][Hs][Ws][3] -> network input (bf16 NHWC4 as a uint16-viewed tensor) and/or
     fp32 NCHW.  Replaces crop (pylib/HumanAug.py:117-176) + flip + colour gain (data/mpii_for_mpii.py:126-135)."""
     f = frames if (isinstance(frames, torch.Tensor) and frames.is_cuda) else to_dev(frames, torch.uint8)
     B, Hs, Ws, _ = f.shape
     out4 = torch.empty((B, res, res, 4), dtype=torch.bfloat16, device=dev()) if want_nhwc4 else None
     outf = torch.empty((B, 3, res, res), dtype=torch.float32, device=dev()) if want_nchw else None
-    check(lib().pa_affine_warp_bilinear(ptr(f), Hs, Ws, ptr(tinv), ptr(params), B, res, ptr(out4), ptr(outf), stream()),
-          'pa_affine_warp_bilinear')
+    if sizes is not None:
+        check(lib().pa_affine_warp_bilinear_sized(ptr(f), Hs, Ws, ptr(sizes), ptr(tinv), ptr(params), B, res, ptr(out4), ptr(outf),
+                                                  stream()), 'pa_affine_warp_bilinear_sized')
+    else:
+        check(lib().pa_affine_warp_bilinear(ptr(f), Hs, Ws, ptr(tinv), ptr(params), B, res, ptr(out4), ptr(outf), stream()),
+              'pa_affine_warp_bilinear')
     return out4, outf
 
 
