@@ -63,7 +63,7 @@ def train(batches, net, optimizer, augmenter, epoch, opt, log=print):
         if i % opt.print_freq == 0 or i == n - 1:          # the only host sync: every print_freq steps
             losses.update(float(loss)); pckhs.update(float(pckh)); pckhs_o.update(float(pckh_o))
             d = OrderedDict([('loss', losses.avg), ('pckh', pckhs.avg), ('pckh_origin_res', pckhs_o.avg)])
-            log('epoch:%d, iters:%d/%d ' % (epoch, i, n) + ' '.join('%s: %.4f' % kv for kv in d.items()))
+            log('epoch:%d, iters:%d/%d ' % (epoch, i, n) + ''.join('%s: %.4f ' % kv for kv in d.items()))      # utils/visualizer.py:70-72
     return losses.avg, pckhs_o.avg
 
 
@@ -103,7 +103,7 @@ def validate(batches, net, augmenter, epoch, opt, num_classes=16, log=print):
         off += batch.B
         if i % opt.print_freq == 0 or i == n - 1:
             d = OrderedDict([('loss', losses.avg), ('pckh', pckhs.avg), ('pckh_origin_res', pckhs_o.avg)])
-            log('val epoch:%d, iters:%d/%d ' % (epoch, i, n) + ' '.join('%s: %.4f' % kv for kv in d.items()))
+            log('epoch:%d, iters:%d/%d ' % (epoch, i, n) + ''.join('%s: %.4f ' % kv for kv in d.items()))
     return losses.avg, pckhs_o.avg, predictions
 
 

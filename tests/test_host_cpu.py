@@ -144,3 +144,26 @@ def test_checkpoint_names_and_round_trip(tmp_path):
     assert ck2.load_checkpoint(net2, opt, h2)
     assert torch.equal(net2.w['conv1.weight'], net.w['conv1.weight']) and h2.epoch[-1]['epoch'] == 10
     assert not Checkpoint().load_checkpoint(net2)                                   # missing file: message, no exception
+
+
+def test_text_log_formats(tmp_path, capsys):
+    """utils/visualizer.py:66-87 (print_log / write_log) and utils/logger.py:24-74 (Logger) byte for byte."""
+    from collections import OrderedDict
+    from pose_adv_aug_amd.utils.visualizer import Visualizer
+    from pose_adv_aug_amd.utils.logger import Logger
+    v = Visualizer(log_path=str(tmp_path / 'exp' / 'log.txt'))
+    d = OrderedDict([('loss', 0.01234567), ('pckh', 0.5), ('pckh_origin_res', 1.0)])
+    m0 = v.print_log(3, 0, 2, value1=d)
+    m1 = v.print_log(3, 1, 2, value1=d, value2=OrderedDict([('t', 1.23456)]))
+    assert m0 == 'epoch:3, iters:0/2 loss: 0.0123 pckh: 0.5000 pckh_origin_res: 1.0000 '
+    assert m1 == m0.replace('iters:0/2', 'iters:1/2') + '\nt:1.235 \n##########################################'
+    assert capsys.readouterr().out == m0 + '\n' + m1 + '\n'
+    assert (tmp_path / 'exp' / 'log.txt').read_text() == m0 + '\n' + m1 + '\n'
+    path = str(tmp_path / 'training-summary.txt')
+    lg = Logger(path, title='training-summary')
+    lg.set_names(['Epoch', 'LR', 'Train Loss', 'Val Loss'])
+    lg.append([0, 2.5e-4, 0.5, 0.25]); lg.append([1, 2.5e-4, 0.125, 0.1]); lg.close()
+    assert open(path).read() == 'Epoch\tLR\tTrain Loss\tVal Loss\t\n0.000000\t0.000250\t0.500000\t0.250000\t\n1.000000\t0.000250\t0.125000\t0.100000\t\n'
+    lg2 = Logger(path, resume=True)
+    assert lg2.names == ['Epoch', 'LR', 'Train Loss', 'Val Loss'] and lg2.numbers['Train Loss'] == ['0.500000', '0.125000']
+    lg2.close()
