@@ -8,9 +8,11 @@
 //     / BatchNorm backward is applied in this pass), then loops over the output-channel blocks itself,
 //     so the input is not re-read per 128 output channels;
 //   * the weight slices [BN][64] are streamed with global_load_lds, double buffered (conv3x3_tile.hip);
-//   * two workgroups per CU (<= 66 KB LDS, <= 256 VGPR): one stages while the other computes.
+//   * two or three workgroups per CU (48-64 KB LDS): one stages while the others compute; 64-row tiles so that a
+//     24 x 64 x 64 map is 1536 workgroups = full rounds (row_bm below).
 // LDS images: activation tile [BM][CIN] and weight slice [BN][64] bf16, 16-byte slots XOR-swizzled by the
-// row so that the ds_read_b128 fragment reads are bank-conflict free.  Epilogue: conv_epilogue.h.
+// row so that the ds_read_b128 fragment reads are bank-conflict free.  Epilogue: conv_epilogue.h (forward modes through
+// an fp32 LDS tile with fully coalesced rows, BatchNorm-backward mode direct).
 #include "common.h"
 #include "kernels.h"
 #include "conv_epilogue.h"
@@ -26,11 +28,10 @@ __global__ __launch_bounds__(256, (CIN == 128 && BM == 64) ? 3 : 2) void conv1x1
     constexpr int KT = CIN / 64;
     constexpr int PSTEP = 256 / CPP;                 // rows staged per pass
     constexpr int NPASS = BM / PSTEP;
-    // ONE shared object: [A tile][2 weight slices][statistics scratch]
-    __shared__ __attribute__((aligned(16))) bf16 lds[BM * CIN + 2 * BN * 64 + 2 * BN * 2 * 2];
+    // ONE shared object: [A tile][2 weight slices]; the epilogue borrows the ring half that was read last
+    __shared__ __attribute__((aligned(16))) bf16 lds[BM * CIN + 2 * BN * 64];
     bf16* As = lds;
     bf16* wbuf = lds + BM * CIN;
-    float* red = reinterpret_cast<float*>(lds + BM * CIN + 2 * BN * 64);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);

@@ -1,4 +1,5 @@
-// Epilogue shared by the MFMA convolution kernels (conv_igemm.hip, conv3x3_tile.hip).
+// Epilogues shared by the MFMA convolution kernels (conv_igemm.hip, conv3x3_tile.hip, conv1x1_tile.hip):
+// pa_conv_epilogue (direct), pa_conv_epilogue_lds (through an LDS tile), pa_conv_epilogue_auto (picks per mode).
 //
 // Accumulator layout it expects: a 256-thread workgroup as 2 (wm: pixels) x 2 (wn: channels) waves,
 // wave tile (16*MI pixels) x (16*NI channels); fragment (ni, mi) is the 16x16 MFMA output whose ROWS
