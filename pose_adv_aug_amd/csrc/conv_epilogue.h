@@ -4,8 +4,9 @@
 // Accumulator layout it expects: a 256-thread workgroup as 2 (wm: pixels) x 2 (wn: channels) waves,
 // wave tile (16*MI pixels) x (16*NI channels); fragment (ni, mi) is the 16x16 MFMA output whose ROWS
 // are output channels and whose COLUMNS (lane & 15) are pixels.  The weight rows were staged permuted
-// (pa_weight_row_of_lds_row) so that lane group q = lane >> 4 of a wave owns the 4*NI CONSECUTIVE
-// channels  q*4*NI + 4*ni + reg : all epilogue traffic (addends, xref, stores) is 16-byte accesses.
+// (pa_weight_row_of_lds_row) so that lane group q = lane >> 4 of a wave owns, for each 32-channel chunk ch,
+// the 8 CONSECUTIVE channels 32*ch + 8*q .. +7: all epilogue traffic (addends, xref, stores) is 16-byte
+// accesses and the four lane groups together cover one contiguous 64-byte run per pixel.
 #pragma once
 #include "common.h"
 #include "kernels.h"
@@ -15,7 +16,9 @@ template <int BN, int NI>
 __device__ __forceinline__ int pa_weight_row_of_lds_row(int lr) {
     const int wt = lr / (BN / 2), l = lr - wt * (BN / 2);
     const int ni = l >> 4, rr = l & 15;
-    return wt * (BN / 2) + (rr >> 2) * (4 * NI) + 4 * ni + (rr & 3);
+    // lane group q = rr >> 2 of fragment ni owns channels 32*(ni>>1) + 8*q + 4*(ni&1) + (rr&3): the 8-channel chunk ch = ni>>1
+    // of the four lane groups is ONE contiguous 64-byte run per pixel (4 x 16 B), not four pieces 32 bytes apart
+    return wt * (BN / 2) + 32 * (ni >> 1) + 8 * (rr >> 2) + 4 * (ni & 1) + (rr & 3);
 }
 
 // pix(mi) -> flattened NHWC pixel index of fragment column (lane & 15) of fragment row-block mi, or -1
@@ -26,11 +29,11 @@ __device__ __forceinline__ void pa_conv_epilogue(const PaConvArgs& a, f32x4 (&ac
     const int tid = threadIdx.x, lane = tid & 63;
     const int N = a.Cout;
     constexpr int CH = NI / 2;                       // 8-channel chunks per lane
-    const int nb = n0 + wn * (BN / 2) + (lane >> 4) * (4 * NI);
+    const int nb = n0 + wn * (BN / 2) + (lane >> 4) * 8;
     float s1[NI][4], s2[NI][4];
 #pragma unroll
     for (int ch = 0; ch < CH; ++ch) {               // chunk-outer / pixel-inner keeps the per-channel constants short-lived
-        const int n = nb + 8 * ch;
+        const int n = nb + 32 * ch;
         float bias[8], es[8], et[8], emu[8], eis[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -87,7 +90,7 @@ __device__ __forceinline__ void pa_conv_epilogue(const PaConvArgs& a, f32x4 (&ac
 #pragma unroll
                 for (int o = 1; o < 16; o <<= 1) { x1 += __shfl_xor(x1, o, 64); x2 += __shfl_xor(x2, o, 64); }
                 if ((lane & 15) == 0) {
-                    const int col = wn * (BN / 2) + (lane >> 4) * (4 * NI) + 4 * ni + j;
+                    const int col = wn * (BN / 2) + 32 * (ni >> 1) + (lane >> 4) * 8 + 4 * (ni & 1) + j;
                     red[(wm * BN + col) * 2] = x1;
                     red[(wm * BN + col) * 2 + 1] = x2;
                 }
@@ -131,13 +134,13 @@ __device__ __forceinline__ void pa_conv_epilogue_lds(const PaConvArgs& a, f32x4 
     for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; bias[j] = a.bias ? a.bias[n + j] : 0.f; }
     // writer side: lane (q = lane >> 4, p = lane & 15) of wave (wm, wn) holds channels wn*BN/2 + q*4*NI + 4*ni + reg of pixel p
     const int wrow = wm * 16 + (lane & 15);
-    const int wslot0 = (wn * (BN / 2) + (lane >> 4) * (4 * NI)) / 4;          // first 16-byte slot (4 floats) of the lane's channels
+    const int wslot0 = (wn * (BN / 2)) / 4 + 2 * (lane >> 4);                // 16-byte slot (4 floats) of fragment 0; fragment ni: + 8*(ni>>1) + (ni&1)
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
         if (mi) __syncthreads();                     // the previous pass has been read
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni)
-            *reinterpret_cast<f32x4*>(T + wrow * BN + (((wslot0 + ni) ^ (wrow & 7)) << 2)) = acc[ni][mi];
+            *reinterpret_cast<f32x4*>(T + wrow * BN + (((wslot0 + 8 * (ni >> 1) + (ni & 1)) ^ (wrow & 7)) << 2)) = acc[ni][mi];
         __syncthreads();
 #pragma unroll
         for (int sw = 0; sw < SW; ++sw) {
