@@ -21,6 +21,15 @@ __device__ __forceinline__ int pa_weight_row_of_lds_row(int lr) {
     return wt * (BN / 2) + 32 * (ni >> 1) + 8 * (rr >> 2) + 4 * (ni & 1) + (rr & 3);
 }
 
+// inverse: which LDS row holds output channel c (0 .. BN-1, relative to the tile's n0)?
+template <int BN, int NI>
+__device__ __forceinline__ int pa_lds_row_of_weight_row(int c) {
+    const int wt = c / (BN / 2), l = c - wt * (BN / 2);
+    const int ch = l >> 5, rem = l & 31;
+    const int q = rem >> 3, h = (rem >> 2) & 1, j = rem & 3;
+    return wt * (BN / 2) + (2 * ch + h) * 16 + 4 * q + j;
+}
+
 // pix(mi) -> flattened NHWC pixel index of fragment column (lane & 15) of fragment row-block mi, or -1
 // `red` = at least 2*BN*2 floats of LDS that are dead by now; stat_row = this workgroup's partial row
 template <int BN, int NI, int MI, class PixFn>

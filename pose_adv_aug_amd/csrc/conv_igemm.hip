@@ -137,14 +137,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(PaConvArgs a) {
         }
 #pragma unroll
         for (int i = 0; i < BI; ++i) {
-            // weight rows are STORED permuted: output channel nl = q*(4*NI) + 4*ni + j of a wave's tile goes
-            // to LDS row ni*16 + 4*q + j, so that MFMA row i = 4*(lane>>4) + reg of fragment ni is channel
-            // (lane>>4)*(4*NI) + 4*ni + reg: a lane's NI fragments hold 4*NI CONSECUTIVE channels
-            // (16-byte epilogue accesses) while the fragment reads stay conflict-free
-            const int row = r + 32 * i;
-            const int wt = row / (BN / 2), nl = row - wt * (BN / 2);
-            const int q = nl / (4 * NI), rem = nl - q * (4 * NI);
-            const int lrow = wt * (BN / 2) + (rem >> 2) * 16 + 4 * q + (rem & 3);
+            // weight rows are STORED permuted (conv_epilogue.h: pa_lds_row_of_weight_row) so that a lane's fragments
+            // hold 8 CONSECUTIVE channels per 32-channel chunk (16-byte epilogue accesses) while the fragment reads
+            // stay conflict-free
+            const int lrow = pa_lds_row_of_weight_row<BN, NI>(r + 32 * i);
             *reinterpret_cast<bf16x8*>(Bs + lrow * 64 + ((cc ^ (lrow & 7)) << 3)) = rb[i];
         }
     };

@@ -52,6 +52,10 @@ SHAPES = [
     (3, 256, 128, 64, 64, 1),    # 96 row tiles of 128 pixels
     (3, 64, 128, 65, 63, 1),     # ragged M = 12285 -> last row tile partly empty
     (4, 64, 64, 64, 64, 1),      # 64-channel blocks on both sides
+    # shapes that reach the GENERIC kernel with 128-channel tiles (weight-row permutation of conv_igemm.hip)
+    (4, 64, 128, 64, 64, 1),     # 128 row tiles of 128 < 192 -> generic <64,128>
+    (8, 192, 128, 64, 64, 1),    # 192 input channels: not a tile-kernel shape, generic <128,128>
+    (8, 192, 128, 64, 64, 3),
     # low-resolution levels: one workgroup = 2 images of 8x8 / 8 images of 4x4 (ragged image counts)
     (3, 128, 128, 8, 8, 3),
     (5, 64, 128, 4, 4, 3),
