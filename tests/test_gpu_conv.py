@@ -56,6 +56,12 @@ SHAPES = [
     (4, 64, 128, 64, 64, 1),     # 128 row tiles of 128 < 192 -> generic <64,128>
     (8, 192, 128, 64, 64, 1),    # 192 input channels: not a tile-kernel shape, generic <128,128>
     (8, 192, 128, 64, 64, 3),
+    # remaining template instances of the tile kernels (row tiles >= 192, channel blocks of 64 on either side)
+    (3, 128, 64, 64, 64, 1),
+    (3, 256, 64, 64, 64, 1),
+    (6, 64, 128, 64, 64, 1),
+    (6, 64, 64, 64, 64, 1),
+    (24, 64, 64, 64, 64, 3),     # 64-channel 3x3 at 768 tiles (16 x 8 tiles, both channel blocks 64)
     # low-resolution levels: one workgroup = 2 images of 8x8 / 8 images of 4x4 (ragged image counts)
     (3, 128, 128, 8, 8, 3),
     (5, 64, 128, 4, 4, 3),
