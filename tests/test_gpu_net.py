@@ -43,7 +43,7 @@ def test_layout_roundtrip():
     assert torch.equal(back, x.bfloat16().float())
 
 
-@pytest.mark.parametrize('C_,H,B', [(128, 16, 2), (256, 8, 3), (128, 4, 1), (256, 64, 2)])
+@pytest.mark.parametrize('C_,H,B', [(128, 16, 2), (256, 8, 3), (128, 4, 1), (256, 64, 2), (256, 64, 6), (128, 64, 8), (256, 32, 8)])
 def test_residual_block_fwd_bwd(C_, H, B):
     """_Residual(C, C): 1x1 -> 3x3 -> 1x1 (+identity) with train-mode BatchNorm; forward, input gradient,
     every parameter gradient and the running statistics.  Ragged M (B*H*H not a multiple of the tile)
