@@ -323,7 +323,7 @@ int pa_asn_backward(pa_net* asn, pa_net* pose, const float* target_scale, const 
 const float* pa_asn_probs(const pa_net* asn) { return asn->n.asn_probs; }
 int pa_asn_set_log_eps(pa_net* asn, float eps) { asn->n.asn_log_eps = eps; return 0; }
 
-void pa_net_destroy(pa_net* net) { delete net; }
+void pa_net_destroy(pa_net* net) { if (net) { net->n.release_streams(); delete net; } }
 
 int pa_net_num_tensors(const pa_net* net) { return (int)net->n.tensors.size(); }
 

@@ -141,6 +141,7 @@ struct Net {
     hipEvent_t ev_w[16]; int ev_w_next = 0;
     hipEvent_t ev_wdone;
     int ensure_streams();
+    void release_streams();                    // destroys the side streams / events (pa_net_destroy)
     int fork_to(int k);                        // side[k] waits for everything enqueued on st so far
     int record_join(int k);                    // mark the end of the work enqueued on side[k]
     int wait_join(int k);                      // st waits for that mark

@@ -522,6 +522,19 @@ int Net::ensure_streams() {
     streams_ready = true;
     return 0;
 }
+void Net::release_streams() {
+    for (int k = 0; k < 4; ++k) {
+        if (side[k]) { (void)hipStreamSynchronize(side[k]); (void)hipStreamDestroy(side[k]); (void)hipEventDestroy(ev_fork[k]); (void)hipEventDestroy(ev_join[k]); side[k] = nullptr; }
+    }
+    if (wstream) {
+        (void)hipStreamSynchronize(wstream); (void)hipStreamDestroy(wstream); wstream = nullptr;
+        for (int i = 0; i < 16; ++i) (void)hipEventDestroy(ev_w[i]);
+        (void)hipEventDestroy(ev_wdone);
+    }
+    for (ProfEntry& e : prof.entries) { (void)hipEventDestroy(e.e0); (void)hipEventDestroy(e.e1); }
+    prof.entries.clear(); prof.used = 0;
+    streams_ready = false;
+}
 int Net::fork_to(int k) { PA_CHECK(hipEventRecord(ev_fork[k], st)); PA_CHECK(hipStreamWaitEvent(side[k], ev_fork[k], 0)); return 0; }
 int Net::record_join(int k) { PA_CHECK(hipEventRecord(ev_join[k], side[k])); return 0; }
 int Net::wait_join(int k) { PA_CHECK(hipStreamWaitEvent(st, ev_join[k], 0)); return 0; }
