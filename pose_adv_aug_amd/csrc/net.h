@@ -140,6 +140,11 @@ struct Net {
     hipStream_t wstream = nullptr;
     hipEvent_t ev_w[16]; int ev_w_next = 0;
     hipEvent_t ev_wdone;
+    // weight-gradient launches are collected and flushed in groups: ONE event record on the producing stream per group
+    // (an event record between two kernels of a queue costs a 15-20 us bubble on it: ~100 records per step were 1.5 ms)
+    struct PendingWgrad { PaWgradArgs a; int cls; double bytes, flops; bool stem; };
+    std::vector<PendingWgrad> pending_wgrads;
+    int flush_wgrads();                        // record on `st`, make wstream wait, launch the collected weight gradients
     int ensure_streams();
     void release_streams();                    // destroys the side streams / events (pa_net_destroy)
     int fork_to(int k);                        // side[k] waits for everything enqueued on st so far

@@ -357,16 +357,15 @@ int Net::conv_wgrad(ConvLayer& c, const PaOperand& dy, const PaOperand& x, int B
     a.B = B_; a.H = H; a.W = W; a.Cin = c.pcin; a.Cout = c.pcout; a.taps = c.k == 7 ? 1 : c.taps(); a.splits = c.splits;
     double wb, wf; conv_work(B_ * H * W, c.k == 7 ? 147 : c.Cin, c.Cout, c.k == 7 ? 1 : c.taps(), true, wb, wf);
     if (c.k == 7) wb = 2.0 * B_ * (4.0 * H * W * 4 + (double)H * W * 64) + 4.0 * 64 * 147;
-    hipStream_t ws = st;
-    if (multi_stream && wstream && !immediate_reduce) {
-        hipEvent_t ev = ev_w[ev_w_next]; ev_w_next = (ev_w_next + 1) & 15;
-        PA_CHECK(hipEventRecord(ev, st));
-        PA_CHECK(hipStreamWaitEvent(wstream, ev, 0));
-        ws = wstream;
+    const int cls = c.k == 7 ? PA_PROF_STEM_WGRAD : (c.k == 3 ? PA_PROF_WGRAD3 : PA_PROF_WGRAD1);
+    if (multi_stream && wstream && !immediate_reduce) {        // deferred: flush_wgrads() launches it on the weight-gradient stream
+        PendingWgrad p; p.a = a; p.cls = cls; p.bytes = wb; p.flops = wf; p.stem = c.k == 7;
+        pending_wgrads.push_back(p);
+        return 0;
     }
-    ProfEntry* pe = prof.begin(c.k == 7 ? PA_PROF_STEM_WGRAD : (c.k == 3 ? PA_PROF_WGRAD3 : PA_PROF_WGRAD1), wb, wf, ws);
-    int rc = (c.k == 7) ? pa_launch_stem_wgrad(a, ws) : pa_launch_wgrad(a, ws);
-    prof.end(pe, ws);
+    ProfEntry* pe = prof.begin(cls, wb, wf, st);
+    int rc = (c.k == 7) ? pa_launch_stem_wgrad(a, st) : pa_launch_wgrad(a, st);
+    prof.end(pe, st);
     if (rc) return rc;
     if (immediate_reduce) {
         if (c.k == 7) {
@@ -376,6 +375,23 @@ int Net::conv_wgrad(ConvLayer& c, const PaOperand& dy, const PaOperand& x, int B
             TRY(pa_launch_wgrad_reduce(red_jobs + c.red_index, 1, c.Cout * c.Cin * c.taps() + c.Cout, st));
         }
     }
+    return 0;
+}
+
+// Operands of the collected launches are final on `st` at this point (their producers were enqueued before).  The
+// gradient buffers they read are written once per step, so deferring a launch is always safe.
+int Net::flush_wgrads() {
+    if (pending_wgrads.empty()) return 0;
+    hipEvent_t ev = ev_w[ev_w_next]; ev_w_next = (ev_w_next + 1) & 15;
+    PA_CHECK(hipEventRecord(ev, st));
+    PA_CHECK(hipStreamWaitEvent(wstream, ev, 0));
+    for (PendingWgrad& p : pending_wgrads) {
+        ProfEntry* pe = prof.begin(p.cls, p.bytes, p.flops, wstream);
+        int rc = p.stem ? pa_launch_stem_wgrad(p.a, wstream) : pa_launch_wgrad(p.a, wstream);
+        prof.end(pe, wstream);
+        if (rc) { pending_wgrads.clear(); return rc; }
+    }
+    pending_wgrads.clear();
     return 0;
 }
 
@@ -410,7 +426,7 @@ int Residual::bwd_a(Net& n, const Act& in) {
     const PaOperand g1 = n.gradop(x1);
     TRY(n.conv_wgrad(c1, g1, n.op(in), B, H, W));
     if (has_adapter) TRY(n.conv_wgrad(ad, g3, n.op(in), B, H, W));
-    return 0;
+    return n.flush_wgrads();                   // one event for the block's 3-4 weight gradients
 }
 
 int Residual::bwd_b(Net& n, const Act& in, const PaOperand& extra) {
@@ -624,6 +640,7 @@ int Net::backward_pose() {
 
 int Net::reduce_grads() {
     if (immediate_reduce) return 0;             // every layer was reduced right after its weight-gradient launch
+    TRY(flush_wgrads());
     if (multi_stream && wstream) {              // all weight-gradient slabs are complete
         PA_CHECK(hipEventRecord(ev_wdone, wstream));
         PA_CHECK(hipStreamWaitEvent(st, ev_wdone, 0));
