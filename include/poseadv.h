@@ -97,6 +97,16 @@ int pa_sample_aug(const float* meta, const int32_t* scale_idx, const int32_t* ro
 int pa_sample_categorical(const float* logits, int B, int K, uint64_t seed, uint64_t step, unsigned slot,
                           float* probs, int32_t* idx, void* stream);
 
+/* _Hourglass._sample_mask (models/asn_stacked_hg.py:102-136): softmax over the `cells` (= 16) mask logits of each sample,
+ * `dropout_num` (= 2) distinct cells drawn with those probabilities (the law of np.random.choice(replace=False)),
+ * masks [B][cells] fp32 = 1 except 0 at the drawn cells, indexes int32 [B][dropout_num] (may be NULL), probs [B][cells]
+ * (may be NULL).  uniforms: NULL = the engine's counter-based stream (seed, step); else float64 [B][dropout_num] in (0,1). */
+int pa_sample_dropout_masks(const float* logits, int B, int cells, int dropout_num, uint64_t seed, uint64_t step,
+                            const double* uniforms, float* probs, float* masks, int32_t* indexes, void* stream);
+/* _Hourglass._dropout (models/asn_stacked_hg.py:79-100) on one NHWC bf16 tensor [B][H][W][C]: the [B][16] 4x4 cell mask,
+ * nearest-upsampled to H x W (H, W multiples of 4), times every channel. */
+int pa_cell_mask(const void* x_bf16, const float* masks, void* out_bf16, int B, int H, int W, int C, void* stream);
+
 /* torch.optim.RMSprop(alpha, eps, momentum=0) step (stack-hg.py:51-52) on flat fp32 arrays;
  * gscale multiplies the gradient first (1/world after a sum all-reduce). */
 int pa_rmsprop_step(float* param, const float* grad, float* square_avg, size_t n, float lr, float alpha,
@@ -134,6 +144,9 @@ pa_net* pa_hg_create(int num_stacks, int num_classes, int chan, int B, int res);
 /* create_asn(chan, chan, scale_num, rotation_num, is_aug=True) (models/asn_stacked_hg.py:441-444) bound
  * to the feature shapes of a pose net with neck resolution res/64. */
 pa_net* pa_asn_create(int chan, int scale_num, int rotation_num, int B, int res);
+/* create_asn(chan, chan, is_dropout=True) (models/asn_stacked_hg.py:378-379,437-439): the same trunk with the occlusion
+ * head out_conv = Conv2d(chan, 1, 1) on the 4x4 map.  res must be 256 (the mask is the 4x4 neck map). */
+pa_net* pa_asn_create_dropout(int chan, int B, int res);
 void pa_net_destroy(pa_net* net);
 
 /* state_dict description (names, shapes, offsets) in the reference's registration order */
@@ -167,7 +180,9 @@ int pa_hg_backward(pa_net* net);
 
 /* Half-hourglass forward (models/asn_stacked_hg.py:300-304 with is_half_hg): stem + the down path of
  * hg[0] up to the neck -- everything the agent reads.  train != 0 updates the BatchNorm running
- * statistics of those layers, as the reference does on the agent-augmentation steps (Appendix A.9). */
+ * statistics of those layers, as the reference does on the agent-augmentation steps (Appendix A.9);
+ * train == 2: batch statistics without touching the running estimates (the occlusion branch's whole-hourglass
+ * call runs this pass, samples the masks and then the full forward, which does the one update). */
 int pa_hg_forward_half(pa_net* net, const float* img, const void* img4, int train);
 
 /* ASN.forward (models/asn_stacked_hg.py:401-436) on the pose net's detached features of the last
@@ -183,6 +198,18 @@ int pa_asn_backward(pa_net* asn, pa_net* pose, const float* target_scale, const 
 /* eps of log(softmax + eps) in that loss: 1e-7 (default, joint-train-pose-s-r-agent.py:399-404) or 0 for the agent
  * pre-training, which uses LogSoftmax (pretrain-s-r-agent.py:177-190). */
 int pa_asn_set_log_eps(pa_net* asn, float eps);
+
+/* Occlusion branch.
+ * pa_asn_forward_masks: ASN.forward(is_dropout=True) (:437-439) on the pose net's detached features: mask_logits [B][16]
+ * (cell = 4 * y + x), device, may be NULL.  train as in pa_asn_forward.
+ * pa_asn_backward_masks: backward of the agent from a caller-provided d(loss)/d(mask_logits) [B][16] into the agent's flat
+ * gradient (the reference ships no loss for this branch); nothing reaches the pose net.
+ * pa_hg_set_dropout_masks: masks [B][16] fp32 (caller-owned device memory, e.g. from pa_sample_dropout_masks), or NULL to
+ * switch the branch off.  While set, pa_hg_forward multiplies the neck and the four skip tensors of EVERY stack's hourglass by
+ * the nearest-upsampled mask (:172-190, :322-324) and pa_hg_backward differentiates through it. */
+int pa_asn_forward_masks(pa_net* asn, pa_net* pose, int train, float* mask_logits);
+int pa_asn_backward_masks(pa_net* asn, pa_net* pose, const float* dlogits);
+int pa_hg_set_dropout_masks(pa_net* net, const float* masks);
 
 /* Evaluation.accuracy (pylib/Evaluation.py:54-75) of stack i's heat maps against the Gaussian target
  * of the joints given to the last forward: acc [nidx+1]. */

@@ -11,7 +11,8 @@ table-driven rather than hand-unrolled.
   Hourglass       models/asn_stacked_hg.py:51-213  (4 levels, num_modules residuals per site)
   HourglassNet    models/asn_stacked_hg.py:215-342 (stem + stacks + re-injection)
   reference init  models/asn_stacked_hg.py:258-270 (conv U(+-1/sqrt(k*k*Cin)), BN gamma U(0,1))
-  ASN (aug path)  models/asn_stacked_hg.py:349-439
+  ASN             models/asn_stacked_hg.py:349-439 (scale/rotation head and occlusion-mask head)
+  occlusion       models/asn_stacked_hg.py:79-136,172-190 (_dropout, _sample_mask, routing :308-321)
 """
 import math
 from collections import OrderedDict
@@ -74,9 +75,23 @@ class Hourglass(nn.Module):
             x = x + skips[lvl - 1]
         return x
 
-    def forward(self, x):
+    def forward(self, x, dropout_masks=None):
         neck, skips = self.encode(x)
+        if dropout_masks is not None:        # :183-189: later stacks reuse the masks sampled in stack 0
+            neck, skips = self.dropout_all(neck, skips, dropout_masks)
         return self.decode(neck, skips)
+
+    @staticmethod
+    def dropout(x, masks):
+        """_dropout (:79-100): the n x 1 x 4 x 4 cell mask, nearest-upsampled to the map, multiplies every channel."""
+        scale = x.shape[2] // 4              # py2 integer division (:86)
+        if scale != 1:
+            masks = F.interpolate(masks, scale_factor=scale, mode='nearest')
+        return x * masks.expand(x.size())
+
+    def dropout_all(self, neck, skips, masks):
+        # :174-178 / :184-188: the neck and the four skip tensors, not the down path
+        return self.dropout(neck, masks), [self.dropout(s, masks) for s in skips]
 
     def agent_features(self, x):
         """Detached feature dict handed to the agent (:159-164)."""
@@ -128,20 +143,33 @@ class HourglassNet(nn.Module):
         x = self.residual2(x)
         return self.residual3(x)
 
-    def forward(self, x, asn=None, is_half_hg=False, is_aug=False):
+    def forward(self, x, asn=None, is_half_hg=False, is_aug=False, is_dropout=False, choice=None):
         """:282-342.  Returns list of per-stack heatmaps; with an agent and
-        is_half_hg the two agent logit tensors (:300-304)."""
+        is_half_hg the two agent logit tensors (:300-304).  Occlusion branch (is_dropout, :308-321):
+        the agent's 4x4 mask logits; with the whole hourglass two cells per sample are drawn from their
+        softmax (`choice`: np.random.choice-compatible callable) and zeroed in the neck / skip tensors of
+        EVERY stack; returns (outs, pred_mask, indexes)."""
         x = self.stem(x)
         outs = []
         logits = None
+        dropout_masks = indexes = None
         for i in range(self.num_stacks):
             if i == 0 and asn is not None:
-                assert is_aug
+                assert is_aug != is_dropout
                 feats, neck, skips = self.hg[0].agent_features(x)
-                logits = asn(feats, is_aug=True)
-                if is_half_hg:
-                    return logits
+                if is_aug:
+                    logits = asn(feats, is_aug=True)
+                    if is_half_hg:
+                        return logits
+                else:
+                    logits = asn(feats, is_dropout=True)
+                    if is_half_hg:
+                        return logits
+                    dropout_masks, indexes = sample_mask(logits, choice)
+                    neck, skips = self.hg[0].dropout_all(neck, skips, dropout_masks)
                 y = self.hg[0].decode(neck, skips)
+            elif dropout_masks is not None:
+                y = self.hg[i](x, dropout_masks=dropout_masks)
             else:
                 y = self.hg[i](x)
             y = self.linear[i](self.post_res[i](y))
@@ -150,8 +178,62 @@ class HourglassNet(nn.Module):
             if i < self.num_stacks - 1:
                 x = x + self.forth_conv[i](y) + self.in_conv[i](heat)   # :331-334
         if asn is not None:
+            if is_dropout:
+                return outs, logits, indexes
             return outs, logits[0], logits[1]
         return outs
+
+
+def sample_mask(pred_masks, choice=None, dropout_num=2):
+    """_Hourglass._sample_mask (:102-136): softmax over the H*W cells of each sample's n x 1 x H x W mask
+    logits, `dropout_num` DISTINCT cells drawn with those probabilities (np.random.choice(replace=False)),
+    mask = 1 everywhere except the drawn cells.  Returns (masks n x 1 x H x W, indexes n x dropout_num int64)."""
+    import numpy as np
+    choice = choice or np.random.choice
+    n, c, h, w = pred_masks.shape
+    assert c == 1 and h == w
+    probs = torch.softmax(pred_masks.reshape(n, -1), 1).detach().cpu().numpy()
+    masks = torch.ones(pred_masks.shape)
+    indexes = torch.zeros(n, dropout_num, dtype=torch.long)
+    for i in range(n):
+        picked = choice(h * w, dropout_num, p=probs[i], replace=False)
+        for j, cell in enumerate(picked):
+            masks[i, 0, int(cell) // w, int(cell) % w] = 0
+            indexes[i, j] = int(cell)
+    return masks, indexes
+
+
+def masks_from_indexes(indexes, n_cells_side=4):
+    """the mask tensor _sample_mask builds for given cell indexes (n x k) -- used to replay a stored draw"""
+    n = indexes.shape[0]
+    masks = torch.ones(n, 1, n_cells_side, n_cells_side)
+    for i in range(n):
+        for cell in indexes[i].tolist():
+            masks[i, 0, cell // n_cells_side, cell % n_cells_side] = 0
+    return masks
+
+
+def sample_cells_inverse_cdf(probs, uniforms):
+    """The LAW of np.random.choice(K, k, p, replace=False) as sequential inverse-CDF draws: cell j is drawn from p
+    with the already drawn cells zeroed and renormalised (P(a then b) = p_a p_b / (1 - p_a), which is what numpy's
+    draw-k / keep-the-unique / redraw loop yields).  probs n x K float64, uniforms n x k in (0,1) -> n x k int64.
+    The engine's device sampler (pa_sample_dropout_masks) is checked against this with its own uniforms."""
+    import numpy as np
+    probs = np.asarray(probs, dtype=np.float64)
+    n, K = probs.shape
+    k = uniforms.shape[1]
+    out = np.zeros((n, k), dtype=np.int64)
+    for i in range(n):
+        p = probs[i].copy()
+        for j in range(k):
+            cdf = np.cumsum(p)
+            pick = int(np.searchsorted(cdf, uniforms[i, j] * cdf[-1], side='right'))
+            pick = min(pick, K - 1)
+            while p[pick] == 0.0 and pick > 0:      # u*total landed on a zeroed cell's flat step (measure zero)
+                pick -= 1
+            out[i, j] = pick
+            p[pick] = 0.0
+    return out
 
 
 def create_hg(num_stacks, num_modules, num_classes, chan):
@@ -161,23 +243,27 @@ def create_hg(num_stacks, num_modules, num_classes, chan):
 
 
 class ASN(nn.Module):
-    """Scale/rotation agent, aug branch only (:349-439; the dropout branch is
-    out of scope, SURVEY.md section 2.1 #3)."""
+    """Scale/rotation agent (is_aug) or occlusion agent (is_dropout): the same trunk, a two-Linear head on the
+    average-pooled 4x4 map or a 1x1 conv giving one logit per cell (:349-439)."""
 
-    def __init__(self, chan_in, chan_out, scale_num, rotation_num):
+    def __init__(self, chan_in, chan_out, scale_num=None, rotation_num=None, is_aug=True, is_dropout=False):
         super().__init__()
+        assert is_aug != is_dropout          # :351
         for k in ('skip1', 'skip2', 'skip3', 'skip4', 'neck'):
             setattr(self, 'residual_' + k, Residual(chan_in, chan_out))
         for k in (1, 2, 3, 4):
             setattr(self, 'merge%d' % k, Residual(chan_out, chan_out))
         self.deep_merge = _res_stack(chan_out, 3)
-        self.fc_scale = nn.Linear(chan_out, scale_num)
-        self.fc_rotation = nn.Linear(chan_out, rotation_num)
+        if is_aug:                  # :373-377
+            self.fc_scale = nn.Linear(chan_out, scale_num)
+            self.fc_rotation = nn.Linear(chan_out, rotation_num)
+        if is_dropout:              # :378-379
+            self.out_conv = nn.Conv2d(chan_out, 1, 1, bias=True)
         reference_init_(self)       # Linear layers keep torch's default init (:380-392 skips them)
 
-    def forward(self, feats, is_aug=True):
-        # :401-436
-        assert is_aug
+    def forward(self, feats, is_aug=False, is_dropout=False):
+        # :401-439
+        assert is_aug != is_dropout
         x = self.residual_skip1(feats['skip1'])
         lower = [self.residual_skip2(feats['skip2']), self.residual_skip3(feats['skip3']),
                  self.residual_skip4(feats['skip4']), self.residual_neck(feats['neck'])]
@@ -185,14 +271,15 @@ class ASN(nn.Module):
             x = F.max_pool2d(x, 2, 2) + lower[k - 1]
             x = getattr(self, 'merge%d' % k)(x)
         x = self.deep_merge(x)
+        if is_dropout:
+            return self.out_conv(x)          # n x 1 x 4 x 4 mask logits (:437-439)
         x = F.avg_pool2d(x, 4).flatten(1)
         return self.fc_scale(x), self.fc_rotation(x)
 
 
 def create_asn(chan_in, chan_out, scale_num=None, rotation_num=None, is_aug=False, is_dropout=False):
     # models/asn_stacked_hg.py:441-444
-    assert is_aug and not is_dropout, 'only the scale/rotation (aug) agent is in scope'
-    return ASN(chan_in, chan_out, scale_num, rotation_num)
+    return ASN(chan_in, chan_out, scale_num, rotation_num, is_aug=is_aug, is_dropout=is_dropout)
 
 
 # ---------------------------------------------------------------------------

@@ -57,6 +57,12 @@ _PROTOS = {
     'pa_nhwc_to_nchw': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     'pa_hg_create': (_vp, [_i, _i, _i, _i, _i]),
     'pa_asn_create': (_vp, [_i, _i, _i, _i, _i]),
+    'pa_asn_create_dropout': (_vp, [_i, _i, _i]),
+    'pa_asn_forward_masks': (_i, [_vp, _vp, _i, _vp]),
+    'pa_asn_backward_masks': (_i, [_vp, _vp, _vp]),
+    'pa_hg_set_dropout_masks': (_i, [_vp, _vp]),
+    'pa_sample_dropout_masks': (_i, [_vp, _i, _i, _i, _u64, _u64, _vp, _vp, _vp, _vp, _vp]),
+    'pa_cell_mask': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'pa_net_destroy': (None, [_vp]),
     'pa_net_num_tensors': (_i, [_vp]),
     'pa_net_tensor_info': (_i, [_vp, _i, C.c_char_p, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_sz), C.POINTER(_sz),

@@ -77,6 +77,17 @@ int pa_sample_categorical(const float* logits, int B, int K, uint64_t seed, uint
     if (K > 64) { pa_set_error_msg("pa_sample_categorical: K <= 64"); return 1; }
     TRY(pa_launch_sample_categorical(logits, B, K, seed, step, slot, probs, idx, ST(s))); return 0;
 }
+int pa_sample_dropout_masks(const float* logits, int B, int cells, int dropout_num, uint64_t seed, uint64_t step, const double* uniforms,
+                            float* probs, float* masks, int32_t* indexes, void* s) {
+    if (cells < 1 || cells > 64 || dropout_num < 0 || dropout_num >= cells || !masks) {
+        pa_set_error_msg("pa_sample_dropout_masks: need 1 <= cells <= 64, 0 <= dropout_num < cells, masks != NULL"); return 1;
+    }
+    TRY(pa_launch_sample_dropout_masks(logits, B, cells, dropout_num, seed, step, uniforms, probs, masks, indexes, ST(s))); return 0;
+}
+int pa_cell_mask(const void* x, const float* masks, void* out, int B, int H, int W, int C, void* s) {
+    PaEpilogue e; memset(&e, 0, sizeof e); e.mode = PA_OUT_PLAIN;
+    TRY(pa_launch_cell_mask(pa_plain(reinterpret_cast<const bf16*>(x)), masks, e, reinterpret_cast<bf16*>(out), B, H, W, C, ST(s))); return 0;
+}
 int pa_rmsprop_step(float* p, const float* g, float* v, size_t n, float lr, float alpha, float eps, float gscale, void* s) {
     TRY(pa_launch_rmsprop(p, g, v, n, lr, alpha, eps, gscale, ST(s))); return 0;
 }
@@ -295,11 +306,61 @@ pa_net* pa_asn_create(int chan, int scale_num, int rotation_num, int B, int res)
     return p;
 }
 
+pa_net* pa_asn_create_dropout(int chan, int B, int res) {
+    g_err[0] = 0;
+    if (chan % 128 != 0 || chan > 512 || res != 256 || B < 1) {      // the 4x4 cell mask is the neck map of a 256 input (reference :79-100)
+        pa_set_error_msg("pa_asn_create_dropout: need chan % 128 == 0 and res == 256 (4x4 neck map)");
+        return nullptr;
+    }
+    pa_net* p = new (std::nothrow) pa_net;
+    if (!p) return nullptr;
+    Net& n = p->n;
+    n.chan = chan; n.B = B; n.res = res; n.stacks = 0; n.asn_dropout = true;
+    n.declare_asn();
+    n.workspace_bytes = n.layout_asn(nullptr);
+    return p;
+}
+
+static int check_agent_pair(const pa_net* asn, const pa_net* pose, const char* who) {
+    if (!asn->n.is_agent || pose->n.is_agent || asn->n.B != pose->n.B || asn->n.chan != pose->n.chan || asn->n.res != pose->n.res) {
+        char buf[160]; snprintf(buf, sizeof buf, "%s: agent and pose net must be built for the same batch, width and resolution", who);
+        pa_set_error_msg(buf);
+        return 1;
+    }
+    return 0;
+}
+
+int pa_asn_forward_masks(pa_net* asn, pa_net* pose, int train, float* mask_logits) {
+    g_err[0] = 0;
+    TRY(check_agent_pair(asn, pose, "pa_asn_forward_masks"));
+    asn->n.bn_update = (train == 2) ? 0 : 1;
+    const int r = asn->n.asn_forward_masks(pose->n, train != 0, mask_logits);
+    asn->n.bn_update = 1;
+    return r;
+}
+
+int pa_asn_backward_masks(pa_net* asn, pa_net* pose, const float* dlogits) {
+    g_err[0] = 0;
+    TRY(check_agent_pair(asn, pose, "pa_asn_backward_masks"));
+    if (!dlogits) { pa_set_error_msg("pa_asn_backward_masks: dlogits == NULL"); return 1; }
+    return asn->n.asn_backward_masks(pose->n, dlogits);
+}
+
+int pa_hg_set_dropout_masks(pa_net* net, const float* masks) {
+    g_err[0] = 0;
+    if (net->n.is_agent) { pa_set_error_msg("pa_hg_set_dropout_masks: not a pose net"); return 1; }
+    if (masks && net->n.res != 256) { pa_set_error_msg("pa_hg_set_dropout_masks: the 4x4 cell mask needs res == 256 (4x4 neck map)"); return 1; }
+    net->n.drop_mask = masks;
+    return 0;
+}
+
 int pa_hg_forward_half(pa_net* net, const float* img, const void* img4, int train) {
     g_err[0] = 0;
     if (!img && !img4) { pa_set_error_msg("pa_hg_forward_half: need img or img4"); return 1; }
-    TRY(net->n.forward_half(img, reinterpret_cast<const bf16*>(img4), train != 0));
-    return 0;
+    net->n.bn_update = (train == 2) ? 0 : 1;        // train == 2: batch statistics, running estimates untouched
+    const int r = net->n.forward_half(img, reinterpret_cast<const bf16*>(img4), train != 0);
+    net->n.bn_update = 1;
+    return r;
 }
 
 int pa_asn_forward(pa_net* asn, pa_net* pose, int train, float* logits_scale, float* logits_rot) {
@@ -427,7 +488,8 @@ int pa_net_set_multi_stream(pa_net* net, int on) {
 // debug / test hook: copy an internal activation (BatchNorm+ReLU applied) or its gradient buffer out as
 // NCHW fp32.  which: "stem", "res1", "pool0", "res2", "res3", "hg<i>.skip<k>", "hg<i>.pool<k>",
 // "hg<i>.down<k>", "hg<i>.neck", "hg<i>.up<k>", "hg<i>.merge<k>", "post<i>", "lin<i>", "xin<i>" (k = 1..4)
-// and "<name>.x1"/".x2" for the inner tensors of a residual block.  grad != 0 -> the raw gradient buffer.
+// and "<name>.x1"/".x2" for the inner tensors of a residual block; "hg<i>.maskedskip<k>", "hg<i>.maskedneck" (occlusion branch).
+// grad != 0 -> the raw gradient buffer.
 int pa_hg_debug_tensor(pa_net* net, const char* which, int grad, float* out, int* shape4) {
     Net& n = net->n;
     std::string w(which);
@@ -451,6 +513,8 @@ int pa_hg_debug_tensor(pa_net* net, const char* which, int grad, float* out, int
         std::string r = w.substr(4);
         Hourglass& h = n.hg[i];
         if (r.rfind("neck", 0) == 0) a = pick_res(h.neck, r.substr(4));
+        else if (r == "maskedneck") a = &h.neckm;                                  // occlusion branch: neck * cell mask
+        else if (r.rfind("maskedskip", 0) == 0) a = &h.skipm[r[10] - '1'];
         else {
             int k = r[r.find_first_of("1234")] - '1';
             std::string rest = r.substr(r.find_first_of("1234") + 1);

@@ -142,6 +142,41 @@ __global__ void asn_fc_wgrad_kernel(const float* dlogits, const float* feat, int
 }
 
 // ------------------------------------------------------------------------------------------------
+// Occlusion agent head (reference :378-379, :437-439): out_conv = Conv2d(C, 1, 1) on the 4x4 map -> one logit per cell.
+// One wave per (sample, cell).
+__global__ void asn_mask_head_fwd_kernel(PaOperand x, int C, const float* w, const float* bias, float* logits) {
+    const size_t row = blockIdx.x;                     // b * HW + cell
+    float acc = 0.f;
+    for (int c = threadIdx.x; c < C; c += 64) {
+        float v = (float)x.p[row * C + c];
+        if (x.mode == PA_LD_BNRELU) v = fmaxf(fmaf(x.k0[c], v, x.k1[c]), 0.f);
+        acc = fmaf(v, w[c], acc);
+    }
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (threadIdx.x == 0) logits[row] = acc + bias[0];
+}
+
+// given d(loss)/d(logits) [B*HW]: d/d(activation) (plain, bf16), d/d(out_conv.weight), d/d(out_conv.bias); one workgroup
+__global__ void asn_mask_head_bwd_kernel(PaOperand x, const float* dlogits, const float* w, int rows, int C, bf16* dact, float* dw, float* db) {
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float acc = 0.f;
+        const float wc = w[c];
+        for (int r = 0; r < rows; ++r) {
+            float v = (float)x.p[(size_t)r * C + c];
+            if (x.mode == PA_LD_BNRELU) v = fmaxf(fmaf(x.k0[c], v, x.k1[c]), 0.f);
+            acc = fmaf(dlogits[r], v, acc);
+            dact[(size_t)r * C + c] = (bf16)(dlogits[r] * wc);
+        }
+        dw[c] = acc;
+    }
+    if (threadIdx.x == 0) {
+        float s = 0.f;
+        for (int r = 0; r < rows; ++r) s += dlogits[r];
+        db[0] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 void Net::declare_asn() {
     is_agent = true;
     const char* names[5] = {"residual_skip1.", "residual_skip2.", "residual_skip3.", "residual_skip4.", "residual_neck."};
@@ -149,10 +184,15 @@ void Net::declare_asn() {
     char buf[32];
     for (int k = 0; k < 4; ++k) { snprintf(buf, sizeof buf, "merge%d.", k + 1); asn_merge[k].declare(*this, buf, chan, chan, false); }
     for (int k = 0; k < 3; ++k) { snprintf(buf, sizeof buf, "deep_merge.%d.", k); asn_deep[k].declare(*this, buf, chan, chan, false); }
-    p_fcs_w = add_param("fc_scale.weight", {scale_num, chan});
-    p_fcs_b = add_param("fc_scale.bias", {scale_num});
-    p_fcr_w = add_param("fc_rotation.weight", {rot_num, chan});
-    p_fcr_b = add_param("fc_rotation.bias", {rot_num});
+    if (asn_dropout) {
+        p_oc_w = add_param("out_conv.weight", {1, chan, 1, 1});
+        p_oc_b = add_param("out_conv.bias", {1});
+    } else {
+        p_fcs_w = add_param("fc_scale.weight", {scale_num, chan});
+        p_fcs_b = add_param("fc_scale.bias", {scale_num});
+        p_fcr_w = add_param("fc_rotation.weight", {rot_num, chan});
+        p_fcr_b = add_param("fc_rotation.bias", {rot_num});
+    }
     n_params = (n_params + 3) & ~(size_t)3;
 }
 
@@ -173,7 +213,7 @@ size_t Net::layout_asn(char* base) {
     }
     for (int k = 0; k < 3; ++k) asn_deep[k].layout(*this, a, B, H >> 4, H >> 4, true);
     asn_feat = a.get<float>((size_t)B * chan);
-    asn_logits = a.get<float>((size_t)B * (scale_num + rot_num));
+    asn_logits = a.get<float>((size_t)B * (asn_dropout ? 16 : scale_num + rot_num));
     asn_probs = a.get<float>((size_t)B * (scale_num + rot_num));
     asn_dlogits = a.get<float>((size_t)B * (scale_num + rot_num));
     layout_shared(a);
@@ -197,11 +237,11 @@ int Net::forward_half(const float* img_nchw, const bf16* img4_in, bool train) {
     TRY(res3.fwd(*this, res2.x3));
     TRY(hg[0].encode(*this, xin[0]));
     if (multi_stream)                      // no decoder here: join the skip branches before anyone reads them
-        for (int k = 0; k < 4; ++k) TRY(wait_join(k));
+        for (int k = 0; k < 4; ++k) if (forks(k)) TRY(wait_join(k));
     return 0;
 }
 
-int Net::asn_forward(Net& pose, bool train, float* logits_s, float* logits_r) {
+int Net::asn_forward_trunk(Net& pose, bool train, const Act** top) {
     train_bn = train;
     st = pose.st;
     TRY(begin_step());
@@ -218,6 +258,35 @@ int Net::asn_forward(Net& pose, bool train, float* logits_s, float* logits_r) {
         x = &asn_merge[k].x3;
     }
     for (int k = 0; k < 3; ++k) { TRY(asn_deep[k].fwd(*this, *x)); x = &asn_deep[k].x3; }
+    *top = x;
+    return 0;
+}
+
+// ASN.forward(is_dropout=True): [B][16] mask logits (cell = 4 * y + x)
+int Net::asn_forward_masks(Net& pose, bool train, float* mask_logits) {
+    if (!asn_dropout) { pa_set_error_msg("asn_forward_masks: this agent was created with the scale/rotation head"); return 1; }
+    const Act* x = nullptr;
+    TRY(asn_forward_trunk(pose, train, &x));
+    hipLaunchKernelGGL(asn_mask_head_fwd_kernel, dim3(x->M()), dim3(64), 0, st, op(*x), chan, params + p_oc_w, params + p_oc_b, asn_logits);
+    TRY((int)hipGetLastError());
+    if (mask_logits) PA_CHECK(hipMemcpyAsync(mask_logits, asn_logits, (size_t)x->M() * sizeof(float), hipMemcpyDeviceToDevice, st));
+    return 0;
+}
+
+int Net::asn_backward_masks(Net& pose, const float* dlogits) {
+    if (!asn_dropout) { pa_set_error_msg("asn_backward_masks: this agent was created with the scale/rotation head"); return 1; }
+    const Act& top = asn_deep[2].x3;
+    bf16* dact = asn_pa[3].grad;
+    hipLaunchKernelGGL(asn_mask_head_bwd_kernel, dim3(1), dim3(256), 0, st, op(top), dlogits, params + p_oc_w, top.M(), chan, dact,
+                       grads + p_oc_w, grads + p_oc_b);
+    TRY((int)hipGetLastError());
+    return asn_backward_trunk(pose, dact);
+}
+
+int Net::asn_forward(Net& pose, bool train, float* logits_s, float* logits_r) {
+    if (asn_dropout) { pa_set_error_msg("asn_forward: this agent was created with the occlusion-mask head"); return 1; }
+    const Act* x = nullptr;
+    TRY(asn_forward_trunk(pose, train, &x));
     const int HW = x->H * x->W, K = scale_num + rot_num;
     hipLaunchKernelGGL(asn_head_fwd_kernel, dim3(B), dim3(256), (chan + K) * sizeof(float), st, op(*x), HW, chan,
                        params + p_fcs_w, params + p_fcs_b, params + p_fcr_w, params + p_fcr_b, scale_num, rot_num, asn_feat,
@@ -232,8 +301,7 @@ int Net::asn_forward(Net& pose, bool train, float* logits_s, float* logits_r) {
 
 // gradient of the KL loss w.r.t. every agent parameter; the pose net's features are constants (detached)
 int Net::asn_backward(Net& pose, const float* target_s, const float* target_r, float* loss_out) {
-    Hourglass& h = pose.hg[0];
-    const Act* feats[5] = {&h.skip[0].x3, &h.skip[1].x3, &h.skip[2].x3, &h.skip[3].x3, &h.neck.x3};
+    if (asn_dropout) { pa_set_error_msg("asn_backward: this agent was created with the occlusion-mask head"); return 1; }
     const Act& top = asn_deep[2].x3;
     const int HW = top.H * top.W, K = scale_num + rot_num;
     bf16* dact = asn_pa[3].grad;                   // scratch of the right size [B][4][4][C]; rewritten later in this pass
@@ -243,6 +311,15 @@ int Net::asn_backward(Net& pose, const float* target_s, const float* target_r, f
     hipLaunchKernelGGL(asn_fc_wgrad_kernel, dim3(8), dim3(256), 0, st, asn_dlogits, asn_feat, B, scale_num, rot_num, chan,
                        grads + p_fcs_w, grads + p_fcs_b, grads + p_fcr_w, grads + p_fcr_b);
     TRY((int)hipGetLastError());
+    TRY(asn_backward_trunk(pose, dact));
+    if (loss_out) PA_CHECK(hipMemcpyAsync(loss_out, loss_dev, sizeof(float), hipMemcpyDeviceToDevice, st));
+    return 0;
+}
+
+int Net::asn_backward_trunk(Net& pose, const bf16* dact) {
+    Hourglass& h = pose.hg[0];
+    const Act* feats[5] = {&h.skip[0].x3, &h.skip[1].x3, &h.skip[2].x3, &h.skip[3].x3, &h.neck.x3};
+    const Act& top = asn_deep[2].x3;
     TRY(pa_launch_ep_apply(pa_plain(dact), final_ep(top), top.grad, (size_t)top.M(), top.C, st));
     TRY(finish_grad(top));
     TRY(asn_deep[2].bwd(*this, asn_deep[1].x3, pa_none(), true)); TRY(finish_grad(asn_deep[1].x3));
@@ -260,7 +337,5 @@ int Net::asn_backward(Net& pose, const float* target_s, const float* target_r, f
         TRY(asn_in[k + 1].bwd(*this, *feats[k + 1], pa_none(), false));
     }
     TRY(asn_in[0].bwd(*this, *feats[0], pa_none(), false));
-    TRY(reduce_grads());
-    if (loss_out) PA_CHECK(hipMemcpyAsync(loss_out, loss_dev, sizeof(float), hipMemcpyDeviceToDevice, st));
-    return 0;
+    return reduce_grads();
 }

@@ -565,6 +565,46 @@ int pa_launch_ep_apply(const PaOperand& g, const PaEpilogue& ep, bf16* out, size
     return (int)hipGetLastError();
 }
 
+// Occlusion mask of the reference's _Hourglass._dropout (models/asn_stacked_hg.py:79-100): out = ep(value(x) * m),
+// m = mask[b][4*(y / (H/4)) + x / (W/4)] -- the n x 1 x 4 x 4 cell mask, nearest-upsampled to the H x W map, times every
+// channel.  Forward: ep = plain.  Backward: x = the gradient of the masked tensor, ep = the epilogue that finishes the
+// gradient of the tensor that was masked (ReLU mask + BatchNorm-backward reductions).
+__global__ __launch_bounds__(1024) void cell_mask_kernel(PaOperand x, const float* mask, PaEpilogue ep, bf16* out, int B, int H, int W, int C) {
+    extern __shared__ float red[];
+    const int CG = C / 8;
+    float s1[8], s2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+    const int c = (threadIdx.x % CG) * 8;
+    const size_t total = (size_t)B * H * W * CG;
+    const int ch = H / 4, cw = W / 4;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+        const size_t pix = t / CG;
+        const size_t idx = pix * C + c;
+        const int xw = (int)(pix % W);
+        const size_t q = pix / W;
+        const int y = (int)(q % H), b = (int)(q / H);
+        const float m = mask[(size_t)b * 16 + 4 * (y / ch) + xw / cw];
+        float v[8];
+        load8_rt(x, idx, c, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] *= m;
+        *reinterpret_cast<bf16x8*>(out + idx) = epilogue8(ep, idx, c, v, s1, s2);
+    }
+    if (ep.mode != PA_OUT_PLAIN) flush_stats(red, ep.stats, C, c, s1, s2);
+}
+
+int pa_launch_cell_mask(const PaOperand& x, const float* mask, const PaEpilogue& ep, bf16* out, int B, int H, int W, int C,
+                        hipStream_t st) {
+    if (H % 4 != 0 || W % 4 != 0 || C % 8 != 0) { pa_set_error_msg("pa_launch_cell_mask: the map must be a multiple of the 4x4 cell grid"); return 1; }
+    size_t total = (size_t)B * H * W * (C / 8);
+    int blocks, threads;
+    stream_launch_dims(total, blocks, threads);
+    if (ep.rows_out) *ep.rows_out = blocks;
+    hipLaunchKernelGGL(cell_mask_kernel, dim3(blocks), dim3(threads), (threads / 64) * 2 * C * sizeof(float), st, x, mask, ep, out, B, H, W, C);
+    return (int)hipGetLastError();
+}
+
 __global__ void fill_kernel(float* p, float v, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
 }

@@ -90,5 +90,7 @@ int pa_launch_nhwc_to_nchw_f32(const float* src, float* dst, int B, int H, int W
 int pa_launch_nchw_f32_to_nhwc_bf16(const float* src, bf16* dst, int B, int C, int H, int W, hipStream_t st);
 int pa_launch_nhwc_bf16_to_nchw_f32(const PaOperand& src, float* dst, int B, int C, int H, int W, hipStream_t st);
 
+int pa_launch_cell_mask(const PaOperand& x, const float* mask, const PaEpilogue& ep, bf16* out, int B, int H, int W, int C,
+                        hipStream_t st);
 int pa_launch_ep_apply(const PaOperand& g, const PaEpilogue& ep, bf16* out, size_t M, int C, hipStream_t st, int* stat_rows = nullptr);
 int pa_launch_fill(float* p, float v, size_t n, hipStream_t st);

@@ -95,6 +95,7 @@ struct Residual {
 struct Hourglass {
     Residual down[4], up[4], skip[4], neck;
     Act pooled[4], merged[4];     // pool outputs p_k (k=1..4), upsample-add outputs o_k
+    Act skipm[4], neckm;          // occlusion branch only: skip / neck outputs times the 4x4 cell mask (reference :79-100)
     bf16* poolgrad[4] = {nullptr, nullptr, nullptr, nullptr};   // gradient of the pool routed back to its input
     void declare(Net& n, const std::string& prefix, int chan);
     void layout(Net& n, Arena& a, int B, int H, int W, bool need_grad);
@@ -135,6 +136,8 @@ struct Net {
     hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_fork[4], ev_join[4];
     bool streams_ready = false, multi_stream = true;
+    int fork_mask = 0xF;                       // bit k: hourglass level k forks its skip block (PA_FORK_LEVELS)
+    bool forks(int k) const { return multi_stream && ((fork_mask >> k) & 1); }
     // weight-gradient launches only feed the slab reducer at the end of the backward pass: they run on their own
     // stream behind an event recorded where their operands are final, off the dgrad / BatchNorm critical chain
     hipStream_t wstream = nullptr;
@@ -168,6 +171,9 @@ struct Net {
     std::vector<Act> lin_out, xin;                 // xin[i] = input of stack i
     std::vector<float*> heat; std::vector<bf16*> heat64, dheat64, dheat_in, forth_tmp, lgrad_tmp;
     double* pts_dev = nullptr;                     // [B][16][2] heat-map coords (caller provided per step)
+    // occlusion (dropout) branch, reference :172-190: [B][16] cell masks (caller-owned device memory) applied to the neck and the
+    // four skip tensors of every stack in forward_pose / backward_pose; nullptr = off
+    const float* drop_mask = nullptr;
 
     // ---- declaration helpers
     size_t add_param(const std::string& name, std::initializer_list<int> shape);
@@ -215,6 +221,13 @@ struct Net {
     int asn_forward(Net& pose, bool train, float* logits_s, float* logits_r);
     float asn_log_eps = 1e-7f;                 // log(softmax + eps) of the agent's KL loss
     int asn_backward(Net& pose, const float* target_s, const float* target_r, float* loss_out);
+    int asn_backward_trunk(Net& pose, const bf16* dact);     // from the gradient of deep_merge's output down to every trunk parameter
+    // occlusion agent (create_asn(is_dropout=True), reference :378-379,437-439): out_conv 1x1 chan -> 1 on the 4x4 map
+    bool asn_dropout = false;
+    size_t p_oc_w = 0, p_oc_b = 0;
+    int asn_forward_trunk(Net& pose, bool train, const Act** top);
+    int asn_forward_masks(Net& pose, bool train, float* mask_logits);
+    int asn_backward_masks(Net& pose, const float* dlogits);
 };
 
 PaOperand pa_plain(const bf16* p);

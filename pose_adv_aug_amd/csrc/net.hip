@@ -168,6 +168,8 @@ void Hourglass::layout(Net& n, Arena& a, int B, int H, int W, bool need_grad) {
         up[k].layout(n, a, B, H >> (k + 1), W >> (k + 1), need_grad);
         merged[k] = n.new_act(a, B, H >> k, W >> k, C, nullptr, need_grad);
     }
+    for (int k = 0; k < 4; ++k) skipm[k] = n.new_act(a, B, H >> k, W >> k, C, nullptr, need_grad);
+    neckm = n.new_act(a, B, H >> 4, W >> 4, C, nullptr, need_grad);
 }
 
 size_t Net::layout_all(char* base) {
@@ -459,27 +461,37 @@ struct StreamScope {
 int Hourglass::encode(Net& n, const Act& in) {
     const Act* cur = &in;
     for (int k = 0; k < 4; ++k) {
-        if (n.multi_stream) {
+        auto skip_branch = [&]() -> int {
+            TRY(skip[k].fwd(n, *cur));
+            if (n.drop_mask) TRY(pa_launch_cell_mask(n.op(skip[k].x3), n.drop_mask, ep_plain(), skipm[k].raw, cur->B, cur->H, cur->W, cur->C, n.st));
+            return 0;
+        };
+        if (n.forks(k)) {
             TRY(n.fork_to(k));
-            { StreamScope sc(n, n.side[k]); TRY(skip[k].fwd(n, *cur)); }
+            { StreamScope sc(n, n.side[k]); TRY(skip_branch()); }
             TRY(n.record_join(k));
         } else {
-            TRY(skip[k].fwd(n, *cur));
+            TRY(skip_branch());
         }
         TRY(pa_launch_maxpool_fwd(n.op(*cur), pooled[k].raw, cur->B, cur->H, cur->W, cur->C, n.st));
         TRY(down[k].fwd(n, pooled[k]));
         cur = &down[k].x3;
     }
-    return neck.fwd(n, *cur);
+    TRY(neck.fwd(n, *cur));
+    if (n.drop_mask) {
+        const Act& x = neck.x3;
+        TRY(pa_launch_cell_mask(n.op(x), n.drop_mask, ep_plain(), neckm.raw, x.B, x.H, x.W, x.C, n.st));
+    }
+    return 0;
 }
 
 int Hourglass::decode(Net& n) {
-    const Act* low = &neck.x3;
+    const Act* low = n.drop_mask ? &neckm : &neck.x3;
     for (int k = 3; k >= 0; --k) {
         TRY(up[k].fwd(n, *low));
         const Act& m = merged[k];
-        if (n.multi_stream) TRY(n.wait_join(k));
-        TRY(pa_launch_upadd_fwd(n.op(up[k].x3), n.op(skip[k].x3), m.raw, m.B, m.H, m.W, m.C, n.st));
+        if (n.forks(k)) TRY(n.wait_join(k));
+        TRY(pa_launch_upadd_fwd(n.op(up[k].x3), n.op(n.drop_mask ? skipm[k] : skip[k].x3), m.raw, m.B, m.H, m.W, m.C, n.st));
         low = &merged[k];
     }
     return 0;
@@ -490,18 +502,27 @@ int Hourglass::decode(Net& n) {
 int Hourglass::bwd(Net& n, const Act& in, const PaOperand& extra0) {
     for (int k = 0; k < 4; ++k) {
         const Act& m = merged[k];
-        TRY(pa_launch_upadd_bwd(m.grad, n.final_ep(up[k].x3), up[k].x3.grad, n.final_ep(skip[k].x3), skip[k].x3.grad,
-                                m.B, m.H, m.W, m.C, n.st));
+        if (n.drop_mask) {              // the skip tensor entered the sum through the cell mask: d skip = mask * d (masked skip)
+            TRY(pa_launch_upadd_bwd(m.grad, n.final_ep(up[k].x3), up[k].x3.grad, ep_plain(), skipm[k].grad, m.B, m.H, m.W, m.C, n.st));
+            TRY(pa_launch_cell_mask(pa_plain(skipm[k].grad), n.drop_mask, n.final_ep(skip[k].x3), skip[k].x3.grad, m.B, m.H, m.W, m.C, n.st));
+        } else {
+            TRY(pa_launch_upadd_bwd(m.grad, n.final_ep(up[k].x3), up[k].x3.grad, n.final_ep(skip[k].x3), skip[k].x3.grad,
+                                    m.B, m.H, m.W, m.C, n.st));
+        }
         TRY(n.finish_grad(up[k].x3));
         TRY(n.finish_grad(skip[k].x3));
-        if (n.multi_stream) {          // parameter / inner gradients of the skip block next to the deeper levels
+        if (n.forks(k)) {          // parameter / inner gradients of the skip block next to the deeper levels
             const Act& x = (k == 0) ? in : down[k - 1].x3;
             TRY(n.fork_to(k));
             { StreamScope sc(n, n.side[k]); TRY(skip[k].bwd_a(n, x)); }
             TRY(n.record_join(k));
         }
-        const Act& upin = (k == 3) ? neck.x3 : merged[k + 1];
+        const Act& upin = (k == 3) ? (n.drop_mask ? neckm : neck.x3) : merged[k + 1];
         TRY(up[k].bwd(n, upin, pa_none(), true));
+    }
+    if (n.drop_mask) {
+        const Act& x = neck.x3;
+        TRY(pa_launch_cell_mask(pa_plain(neckm.grad), n.drop_mask, n.final_ep(x), x.grad, x.B, x.H, x.W, x.C, n.st));
     }
     TRY(n.finish_grad(neck.x3));
     TRY(neck.bwd(n, down[3].x3, pa_none(), true));
@@ -511,7 +532,7 @@ int Hourglass::bwd(Net& n, const Act& in, const PaOperand& extra0) {
         const Act& x = (k == 0) ? in : down[k - 1].x3;
         TRY(pa_launch_maxpool_bwd(pooled[k].grad, n.op(x), (k == 0) ? extra0 : pa_none(), ep_plain(), poolgrad[k],
                                   x.B, x.H, x.W, x.C, n.st));
-        if (n.multi_stream) {
+        if (n.forks(k)) {
             TRY(n.wait_join(k));
             TRY(skip[k].bwd_b(n, x, pa_plain(poolgrad[k])));
         } else {
@@ -525,6 +546,7 @@ int Hourglass::bwd(Net& n, const Act& in, const PaOperand& extra0) {
 int Net::ensure_streams() {
     if (streams_ready) return 0;
     if (getenv("PA_SINGLE_STREAM")) { multi_stream = false; streams_ready = true; return 0; }
+    if (const char* e = getenv("PA_FORK_LEVELS")) fork_mask = atoi(e);
     for (int k = 0; k < 4; ++k) {
         PA_CHECK(hipStreamCreateWithFlags(&side[k], hipStreamNonBlocking));
         PA_CHECK(hipEventCreateWithFlags(&ev_fork[k], hipEventDisableTiming));

@@ -25,3 +25,5 @@ int pa_launch_sample_categorical(const float* logits, int B, int K, unsigned lon
                                  float* probs, int* idx, hipStream_t st);
 int pa_launch_flip_lr_nhwc4(const bf16* src, bf16* dst, int B, int H, int W, hipStream_t st);
 int pa_launch_flip_tta_merge(const float* a, const float* b, float* out, int B, int H, int W, hipStream_t st);
+int pa_launch_sample_dropout_masks(const float* logits, int B, int K, int k, unsigned long long seed, unsigned long long step,
+                                   const double* uniforms, float* probs, float* masks, int* indexes, hipStream_t st);

@@ -630,6 +630,52 @@ int pa_launch_sample_categorical(const float* logits, int B, int K, unsigned lon
     return (int)hipGetLastError();
 }
 
+// _Hourglass._sample_mask (reference models/asn_stacked_hg.py:102-136): softmax over the K = H*W cells of each sample's mask
+// logits, `k` DISTINCT cells drawn with those probabilities, mask = 1 except at the drawn cells.  np.random.choice(K, k, p,
+// replace=False) draws k, keeps the unique ones and redraws the rest with the found cells zeroed: that is sequential drawing
+// without replacement (P(a then b) = p_a p_b / (1 - p_a)), done here by inverse CDF in float64 over the fp32 softmax.
+// uniforms (optional, [B][k] in (0,1)) replace the engine's own counter-based stream (parity tests).
+__global__ void sample_dropout_masks_kernel(const float* logits, int B, int K, int k, unsigned long long seed, unsigned long long step,
+                                            const double* uniforms, float* probs, float* masks, int* indexes) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const float* l = logits + (size_t)b * K;
+    float p[64];
+    float mx = l[0];
+    for (int c = 1; c < K; ++c) mx = fmaxf(mx, l[c]);
+    float sum = 0.f;
+    for (int c = 0; c < K; ++c) { p[c] = expf(l[c] - mx); sum += p[c]; }
+    for (int c = 0; c < K; ++c) {
+        p[c] = p[c] / sum;
+        if (probs) probs[(size_t)b * K + c] = p[c];
+        masks[(size_t)b * K + c] = 1.f;
+    }
+    for (int j = 0; j < k; ++j) {
+        double total = 0.0;
+        for (int c = 0; c < K; ++c) total += (double)p[c];
+        const double u = (uniforms ? uniforms[(size_t)b * k + j] : pa_uniform(seed, step, b, 16 + j)) * total;
+        double cdf = 0.0;
+        int pick = -1, last = 0;
+        for (int c = 0; c < K; ++c) {
+            cdf += (double)p[c];
+            if (p[c] > 0.f) last = c;
+            if (pick < 0 && u < cdf) pick = c;
+        }
+        if (pick < 0) pick = last;
+        while (p[pick] == 0.f && pick > 0) --pick;
+        masks[(size_t)b * K + pick] = 0.f;
+        if (indexes) indexes[(size_t)b * k + j] = pick;
+        p[pick] = 0.f;
+    }
+}
+
+int pa_launch_sample_dropout_masks(const float* logits, int B, int K, int k, unsigned long long seed, unsigned long long step,
+                                   const double* uniforms, float* probs, float* masks, int* indexes, hipStream_t st) {
+    hipLaunchKernelGGL(sample_dropout_masks_kernel, dim3((B + 63) / 64), dim3(64), 0, st, logits, B, K, k, seed, step, uniforms, probs,
+                       masks, indexes);
+    return (int)hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------------
 // validation with flip test-time augmentation (reference stack-hg.py:222-230)
 // mirror the 4-channel-padded NHWC bf16 network input along W (img.numpy()[:, :, :, ::-1])

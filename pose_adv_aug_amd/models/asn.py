@@ -1,4 +1,5 @@
-"""ASN scale/rotation agent of the reference (models/asn_stacked_hg.py:349-439, aug branch) on the HIP engine."""
+"""ASN agent of the reference (models/asn_stacked_hg.py:349-439) on the HIP engine: the scale/rotation head (is_aug) or the
+occlusion-mask head (is_dropout)."""
 import torch
 
 from .._lib import lib, check, ptr
@@ -6,15 +7,51 @@ from .asn_stacked_hg import _HipModule
 
 
 class ASN(_HipModule):
-    def __init__(self, chan, scale_num, rotation_num, res=256, default_batch=24):
+    def __init__(self, chan, scale_num, rotation_num, res=256, default_batch=24, is_dropout=False):
         super().__init__()
         self.chan, self.scale_num, self.rotation_num, self.res = chan, scale_num, rotation_num, res
+        self.is_dropout = bool(is_dropout)
         self.default_batch = default_batch
         self._last_B = None
         self._last_pose = None
 
     def _create(self, B):
+        if self.is_dropout:
+            return lib().pa_asn_create_dropout(self.chan, B, self.res)
         return lib().pa_asn_create(self.chan, self.scale_num, self.rotation_num, B, self.res)
+
+    # ---- occlusion agent (create_asn(is_dropout=True))
+    def _forward_masks_from_pose(self, pose, x=None, img4=None, update_running=True):
+        """hg(img, asn, is_half_hg=True, is_dropout=True) (models/asn_stacked_hg.py:313-316): half hourglass of the pose net
+        + ASN.forward(is_dropout=True) -> mask logits [B][1][4][4].  update_running=False: the pose net's running BatchNorm
+        estimates are left alone (the whole-hourglass call updates them once, in its full forward)."""
+        B = x.shape[0] if x is not None else img4.shape[0]
+        hp = pose._net(B)
+        pose._last_B = B
+        xin = x.contiguous().float() if x is not None else None
+        mode = (1 if update_running else 2) if pose.training else 0
+        check(lib().pa_hg_forward_half(hp, ptr(xin), ptr(img4), mode), 'pa_hg_forward_half')
+        if pose.training and update_running:
+            pose._nbt += 1
+        return self.forward_masks(pose)
+
+    def forward_masks(self, pose, update_running=True):
+        B = pose._last_B
+        hp, ha = pose._net(B), self._net(B)
+        out = torch.empty((B, 1, 4, 4), dtype=torch.float32, device=self.flat_params.device)
+        mode = (1 if update_running else 2) if self.training else 0
+        check(lib().pa_asn_forward_masks(ha, hp, mode, ptr(out)), 'pa_asn_forward_masks')
+        if self.training and update_running:
+            self._nbt += 1
+        self._last_B, self._last_pose = B, pose
+        return out
+
+    def backward_masks(self, grad_pred_mask):
+        """pred_mask.backward(grad) of the reference's autograd: d(loss)/d(mask logits) [B][1][4][4] -> flat_grads (the
+        reference ships no loss for the occlusion agent; the caller supplies the gradient of its own)."""
+        B, pose = self._last_B, self._last_pose
+        g = grad_pred_mask.to(self.flat_params.device, torch.float32).reshape(B, 16).contiguous()
+        check(lib().pa_asn_backward_masks(self._net(B), pose._net(B), ptr(g)), 'pa_asn_backward_masks')
 
     def _forward_from_pose(self, pose, x=None, img4=None, is_half_hg=True, update_running=True):
         """hg(img, asn, is_half_hg=True, is_aug=True) of the reference (models/asn_stacked_hg.py:300-304): the

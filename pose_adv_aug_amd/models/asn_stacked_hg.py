@@ -200,28 +200,60 @@ class HourglassNet(_HipModule):
     def _create(self, B):
         return lib().pa_hg_create(self.num_stacks, self.num_classes, self.chan, B, self.res)
 
-    def forward(self, x=None, asn=None, is_half_hg=False, is_aug=False, is_dropout=False, img4=None, pts=None):
+    def forward(self, x=None, asn=None, is_half_hg=False, is_aug=False, is_dropout=False, img4=None, pts=None,
+                dropout_masks=None, seed=0):
         """models/asn_stacked_hg.py:282-342.  x: [B][3][res][res] fp32 GPU tensor (or img4: the bf16
         NHWC4 output of the on-device warp).  Returns the list of per-stack heat maps [B][16][res/4][res/4]
-        (fp32, NCHW) like the reference.  With `asn` and is_half_hg the agent's two logit tensors."""
-        if is_dropout:
-            raise NotImplementedError('the occlusion (dropout) agent is outside the hot path (SURVEY.md 2.1 #3)')
+        (fp32, NCHW) like the reference.  With `asn` and is_half_hg the agent's two logit tensors.
+        Occlusion branch (:308-324): with an is_dropout agent, is_half_hg gives the [B][1][4][4] mask logits; the whole
+        hourglass draws two cells per sample from their softmax on the device (stream: `seed` and a per-module call
+        counter), zeroes them in the neck / skip tensors of every stack and returns (outs, pred_mask, indexes); the
+        drawn masks stay in `last_dropout_masks` for loss_and_backward(dropout_masks=...).  `dropout_masks`
+        ([B][1][4][4], without an agent) applies given masks (:183-189)."""
         if asn is not None:
-            assert is_aug
-            return asn._forward_from_pose(self, x, img4, is_half_hg)
+            assert is_aug != is_dropout                      # :299
+            if is_aug:
+                return asn._forward_from_pose(self, x, img4, is_half_hg)
+            assert dropout_masks is None                     # :160
+            pred_mask = asn._forward_masks_from_pose(self, x, img4, update_running=is_half_hg)
+            if is_half_hg:
+                return pred_mask
+            masks, indexes = sample_mask(pred_mask, seed=seed, step=self._drop_calls)
+            self._drop_calls += 1
+            self.last_dropout_masks = masks
+            return self._forward(x, img4, pts, masks), pred_mask, indexes
+        return self._forward(x, img4, pts, dropout_masks)
+
+    __call__ = forward
+    _drop_calls = 0
+    last_dropout_masks = None
+
+    def _set_masks(self, h, masks):
+        """pa_hg_set_dropout_masks with a [B][1][4][4] (or [B][16]) mask tensor, None = off; returns the tensor to keep alive"""
+        if masks is None:
+            check(lib().pa_hg_set_dropout_masks(h, None), 'pa_hg_set_dropout_masks')
+            return None
+        m = masks.to(self.flat_params.device, torch.float32).reshape(masks.shape[0], 16).contiguous()
+        check(lib().pa_hg_set_dropout_masks(h, ptr(m)), 'pa_hg_set_dropout_masks')
+        return m
+
+    def _forward(self, x, img4, pts, dropout_masks=None):
         B = x.shape[0] if x is not None else img4.shape[0]
         h = self._net(B)
         self._last_B = B
         p = pts.to(torch.float64).contiguous() if pts is not None else None
         losses = torch.zeros(self.num_stacks, dtype=torch.float32, device=self.flat_params.device) if pts is not None else None
-        check(lib().pa_hg_forward(h, ptr(x.contiguous().float()) if x is not None else None, ptr(img4), ptr(p),
-                                  1 if self.training else 0, ptr(losses)), 'pa_hg_forward')
+        keep = self._set_masks(h, dropout_masks)
+        try:
+            check(lib().pa_hg_forward(h, ptr(x.contiguous().float()) if x is not None else None, ptr(img4), ptr(p),
+                                      1 if self.training else 0, ptr(losses)), 'pa_hg_forward')
+        finally:
+            if keep is not None:                             # (stream-ordered: `keep` outlives the kernels that read it)
+                self._set_masks(h, None)
         if self.training:
             self._nbt += 1
         self._last_losses = losses
         return self.heatmaps(B)
-
-    __call__ = forward
 
     def heatmaps(self, B=None):
         B = B or self._last_B
@@ -233,21 +265,28 @@ class HourglassNet(_HipModule):
             outs.append(o)
         return outs
 
-    def loss_and_backward(self, x=None, pts=None, img4=None, want_outputs=False):
+    def loss_and_backward(self, x=None, pts=None, img4=None, want_outputs=False, dropout_masks=None):
         """One pass of stack-hg.py:153-164 without the optimizer: forward in the current mode, loss
         sum_stacks mean((out - gaussian(pts))^2) with the target generated on the fly from `pts`
-        ([B][16][2] heat-map coordinates), backward into flat_grads.  Returns (loss 0-d GPU tensor, outputs)."""
+        ([B][16][2] heat-map coordinates), backward into flat_grads.  Returns (loss 0-d GPU tensor, outputs).
+        dropout_masks ([B][1][4][4]): the occlusion masks of the reference's dropout branch, in every stack."""
         B = x.shape[0] if x is not None else img4.shape[0]
         h = self._net(B)
         self._last_B = B
         p = pts.to(torch.float64).contiguous()
         losses = torch.zeros(self.num_stacks, dtype=torch.float32, device=self.flat_params.device)
-        check(lib().pa_hg_forward(h, ptr(x.contiguous().float()) if x is not None else None, ptr(img4), ptr(p),
-                                  1 if self.training else 0, ptr(losses)), 'pa_hg_forward')
-        if self.training:
-            self._nbt += 1
-        check(lib().pa_hg_backward(h), 'pa_hg_backward')
-        return losses.sum(), (self.heatmaps(B) if want_outputs else None)
+        keep = self._set_masks(h, dropout_masks)
+        try:
+            check(lib().pa_hg_forward(h, ptr(x.contiguous().float()) if x is not None else None, ptr(img4), ptr(p),
+                                      1 if self.training else 0, ptr(losses)), 'pa_hg_forward')
+            if self.training:
+                self._nbt += 1
+            check(lib().pa_hg_backward(h), 'pa_hg_backward')
+            outs = self.heatmaps(B) if want_outputs else None
+        finally:
+            if keep is not None:
+                self._set_masks(h, None)
+        return losses.sum(), outs
 
     def accuracy(self, idxs, stack=-1):
         """Evaluation.accuracy (pylib/Evaluation.py:54-75) of the last forward's heat maps against the
@@ -290,6 +329,35 @@ class HourglassNet(_HipModule):
         return acc, person
 
 
+def sample_mask(pred_masks, dropout_num=2, seed=0, step=0, uniforms=None):
+    """_Hourglass._sample_mask (models/asn_stacked_hg.py:102-136) on the device: softmax over the 16 cells of each sample's
+    [B][1][4][4] mask logits, `dropout_num` distinct cells drawn with those probabilities (the law of
+    np.random.choice(replace=False); the engine's own counter-based stream, or `uniforms` [B][dropout_num] float64).
+    Returns (masks [B][1][4][4] fp32 with zeros at the drawn cells, indexes [B][dropout_num] int64)."""
+    assert pred_masks.dim() == 4 and pred_masks.shape[1] == 1 and pred_masks.shape[2] == pred_masks.shape[3]
+    B, cells = pred_masks.shape[0], pred_masks.shape[2] * pred_masks.shape[3]
+    dev = pred_masks.device
+    lg = pred_masks.reshape(B, cells).float().contiguous()
+    masks = torch.empty((B, cells), dtype=torch.float32, device=dev)
+    idx = torch.empty((B, dropout_num), dtype=torch.int32, device=dev)
+    u = uniforms.to(dev, torch.float64).contiguous() if uniforms is not None else None
+    check(lib().pa_sample_dropout_masks(ptr(lg), B, cells, dropout_num, int(seed), int(step), ptr(u), None, ptr(masks), ptr(idx),
+                                        stream()), 'pa_sample_dropout_masks')
+    return masks.view(pred_masks.shape), idx.long()
+
+
+def dropout(x, masks):
+    """_Hourglass._dropout (models/asn_stacked_hg.py:79-100) on an NCHW fp32 tensor (operator-level entry; the networks apply
+    it inside pa_hg_forward): the [B][1][4][4] cell mask, nearest-upsampled to the map, times every channel."""
+    B, Cc, H, W = x.shape
+    pad = (-Cc) % 8
+    xh = torch.nn.functional.pad(x.permute(0, 2, 3, 1), (0, pad)).to(torch.bfloat16).contiguous()
+    out = torch.empty_like(xh)
+    m = masks.to(x.device, torch.float32).reshape(B, 16).contiguous()
+    check(lib().pa_cell_mask(ptr(xh), ptr(m), ptr(out), B, H, W, Cc + pad, stream()), 'pa_cell_mask')
+    return out[..., :Cc].permute(0, 3, 1, 2).float()
+
+
 def create_hg(num_stacks, num_modules, num_classes, chan, res=256, default_batch=24):
     """models/asn_stacked_hg.py:344-347."""
     return HourglassNet(num_modules=num_modules, num_stacks=num_stacks, chan=chan, num_classes=num_classes,
@@ -298,10 +366,9 @@ def create_hg(num_stacks, num_modules, num_classes, chan, res=256, default_batch
 
 def create_asn(chan_in, chan_out, scale_num=None, rotation_num=None, is_aug=False, is_dropout=False, res=256,
                default_batch=24):
-    """models/asn_stacked_hg.py:441-444 (scale/rotation agent only)."""
+    """models/asn_stacked_hg.py:441-444: the scale/rotation agent (is_aug) or the occlusion agent (is_dropout)."""
     from .asn import ASN
-    if not is_aug or is_dropout:
-        raise NotImplementedError('only the scale/rotation (is_aug) agent is on the hot path')
+    assert is_aug != is_dropout                              # :351
     if chan_in != chan_out:
         raise ValueError('the reference always builds the agent with chan_in == chan_out')
-    return ASN(chan_out, scale_num, rotation_num, res=res, default_batch=default_batch)
+    return ASN(chan_out, scale_num, rotation_num, res=res, default_batch=default_batch, is_dropout=is_dropout)

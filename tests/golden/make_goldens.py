@@ -11,6 +11,7 @@ seeds + the reference's outputs.  Steps:
   2. lib2to3 fixers print/import/dict/xrange
   3. restore py2 integer division where it matters (out_num/2, height / 4, res/10)
   4. numpy-2 strictness: squeeze 1-element scale/rot arrays handed to GetTransform
+  5. occlusion branch only: drop the `.cuda()` of _sample_mask's mask buffer (no GPU here), `/ width` -> `// width`
 Only data (arrays) is written to the repo.
 """
 import os
@@ -50,7 +51,10 @@ def transliterate():
             s, n = re.subn(a, b, s)
             assert n > 0, (rel, a)
         open(p, 'w').write(s)
-    patch('models/asn_stacked_hg.py', [(r'out_num/2', 'out_num//2'), (r'height / 4', 'height // 4')])
+    patch('models/asn_stacked_hg.py', [(r'out_num/2', 'out_num//2'), (r'height / 4', 'height // 4'),
+                                       # occlusion branch (:102-136): no GPU in this container; py2 integer division
+                                       (r'torch\.ones\(pred_masks\.size\(\)\)\.cuda\(\)', 'torch.ones(pred_masks.size())'),
+                                       (r'dropout_indexes\[j\] / width', 'dropout_indexes[j] // width')])
     patch('pylib/HumanAcc.py', [(r'normalize = res/10', 'normalize = res//10')])
     sys.path.insert(0, TMP)
 
@@ -252,7 +256,59 @@ def gen_nets(R):
     print('census', n_hg, n_asn, len(keys))
 
 
+def gen_dropout(R):
+    """Occlusion (dropout) agent branch, SURVEY.md section 8f rank 4 (models/asn_stacked_hg.py:79-136,172-190,308-321,437-439):
+    mask logits of the half hourglass, the reference's own draw under np.random.seed, the masked two-stack forward,
+    pose-net gradients of the MSE loss through the masks, agent gradients for a given upstream gradient of the logits."""
+    import warnings
+    from tests import inputs
+    from oracle.model import deterministic_fill_
+    M = R['M']
+    warnings.simplefilter('ignore')
+    net = M.create_hg(num_stacks=2, num_modules=1, num_classes=16, chan=16)
+    asn = M.create_asn(chan_in=16, chan_out=16, is_dropout=True)
+    deterministic_fill_(net, seed=51)
+    deterministic_fill_(asn, seed=52)
+    net.train(); asn.train()
+    img = t(inputs.images(151, 2, 256))
+    pts = inputs.heat_pts(152, 2, res=64)
+    heat = t(inputs.heatmaps_from_pts(pts, res=64))
+    import copy
+    net_half = copy.deepcopy(net); asn_half = copy.deepcopy(asn)
+    half = net_half(img, asn_half, is_half_hg=True, is_dropout=True)
+    np.random.seed(153)
+    out, pred_mask, indexes = net(img, asn, is_dropout=True)
+    assert torch.allclose(half, pred_mask)
+    loss = 0
+    for o in out:
+        d = (o - heat) ** 2
+        loss = loss + d.sum() / d.numel()
+    net.zero_grad(); asn.zero_grad()
+    loss.backward(retain_graph=True)
+    assert all(p.grad is None for p in asn.parameters())            # the agent sees detached features, the masks are constants
+    pose_grads = [p.grad.clone() for p in net.parameters()]
+    gy = t(inputs.rng(154).standard_normal((2, 1, 4, 4)).astype(np.float32))
+    pred_mask.backward(gy)
+    # _dropout alone on a random tensor (:79-100)
+    x = t(inputs.rng(155).standard_normal((2, 3, 16, 16)).astype(np.float32))
+    masks = torch.ones(2, 1, 4, 4); masks[0, 0, 1, 2] = 0; masks[1, 0, 3, 0] = 0; masks[1, 0, 0, 0] = 0
+    dx = net.hg[0]._dropout(x, masks)
+    # the sampler under a fixed numpy seed, on sharper logits
+    np.random.seed(156)
+    lg = t(inputs.rng(157).normal(0, 2.0, (6, 1, 4, 4)).astype(np.float32))
+    smask, sidx = net.hg[0]._sample_mask(lg)
+    np.savez_compressed(os.path.join(OUT, 'dropout_c16.npz'), pred_mask=pred_mask.detach().numpy(), indexes=indexes.numpy(),
+                        out=np.stack([o.detach().numpy() for o in out]), loss=np.array(float(loss)),
+                        pose_grad_digest=digest(pose_grads), asn_grad_digest=digest([p.grad for p in asn.parameters()]),
+                        asn_keys=np.array(list(asn.state_dict().keys())),
+                        nparams=np.array(sum(p.numel() for p in asn.parameters())),
+                        drop_x_out=dx.numpy(), drop_masks=masks.numpy(),
+                        sample_masks=smask.numpy(), sample_idx=sidx.numpy())
+    print('dropout', float(loss), indexes.tolist())
+
+
 if __name__ == '__main__':
     R = load_ref()
     gen_pylib(R)
     gen_nets(R)
+    gen_dropout(R)

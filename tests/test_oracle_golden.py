@@ -198,3 +198,60 @@ def test_census_full_size():
     assert list(net.state_dict().keys()) == [str(k) for k in g['hg_keys']]
     asn = om.create_asn(256, 256, 7, 7, is_aug=True)
     assert sum(p.numel() for p in asn.parameters()) == int(g['n_asn']) == 2577934
+
+
+def test_occlusion_agent_branch():
+    """mask logits, the reference's own draw (np.random.seed replay), the masked two-stack
+    forward, the pose-net gradients through the masks and the agent's gradients -- against the transliterated reference."""
+    import copy
+    g = load('dropout_c16.npz')
+    net = om.create_hg(2, 1, 16, 16)
+    asn = om.create_asn(16, 16, is_dropout=True)
+    assert list(asn.state_dict().keys()) == [str(k) for k in g['asn_keys']]
+    assert sum(p.numel() for p in asn.parameters()) == int(g['nparams'])
+    om.deterministic_fill_(net, seed=51)
+    om.deterministic_fill_(asn, seed=52)
+    net.train(); asn.train()
+    img = t(inputs.images(151, 2, 256))
+    heat = t(inputs.heatmaps_from_pts(inputs.heat_pts(152, 2, res=64), res=64))
+    half = copy.deepcopy(net)(img, copy.deepcopy(asn), is_half_hg=True, is_dropout=True)
+    assert np.allclose(half.detach().numpy(), g['pred_mask'], atol=1e-5)
+    np.random.seed(153)
+    out, pred_mask, indexes = net(img, asn, is_dropout=True)
+    assert np.array_equal(indexes.numpy(), g['indexes'])
+    assert np.allclose(pred_mask.detach().numpy(), g['pred_mask'], atol=1e-5)
+    assert np.allclose(np.stack([o.detach().numpy() for o in out]), g['out'], atol=2e-5)
+    loss = sum(((o - heat) ** 2).sum() / o.numel() for o in out)
+    assert abs(float(loss) - float(g['loss'])) < 1e-6
+    net.zero_grad(); asn.zero_grad()
+    loss.backward(retain_graph=True)
+    assert all(p.grad is None for p in asn.parameters())
+    assert np.allclose(digest([p.grad for p in net.parameters()]), g['pose_grad_digest'], rtol=2e-3, atol=1e-6)
+    pred_mask.backward(t(inputs.rng(154).standard_normal((2, 1, 4, 4)).astype(np.float32)))
+    assert np.allclose(digest([p.grad for p in asn.parameters()]), g['asn_grad_digest'], rtol=2e-3, atol=1e-6)
+    # _dropout and _sample_mask on their own
+    x = t(inputs.rng(155).standard_normal((2, 3, 16, 16)).astype(np.float32))
+    assert np.array_equal(om.Hourglass.dropout(x, t(g['drop_masks'])).numpy(), g['drop_x_out'])
+    np.random.seed(156)
+    lg = t(inputs.rng(157).normal(0, 2.0, (6, 1, 4, 4)).astype(np.float32))
+    smask, sidx = om.sample_mask(lg)
+    assert np.array_equal(sidx.numpy(), g['sample_idx']) and np.array_equal(smask.numpy(), g['sample_masks'])
+    assert np.array_equal(om.masks_from_indexes(sidx).numpy(), g['sample_masks'])
+
+
+def test_occlusion_sampler_law():
+    """sequential inverse-CDF draws == the distribution of np.random.choice(K, 2, p, replace=False)"""
+    rng = np.random.RandomState(5)
+    p = np.array([0.5, 0.25, 0.15, 0.1])
+    n = 40000
+    ref = np.stack([rng.choice(4, 2, p=p, replace=False) for _ in range(n)])
+    mine = om.sample_cells_inverse_cdf(np.tile(p, (n, 1)), np.random.RandomState(6).random_sample((n, 2)))
+    assert (mine[:, 0] != mine[:, 1]).all()
+    for a in range(4):
+        for b in range(4):
+            if a == b:
+                continue
+            want = p[a] * p[b] / (1 - p[a])
+            f_ref = np.mean((ref[:, 0] == a) & (ref[:, 1] == b))
+            f_mine = np.mean((mine[:, 0] == a) & (mine[:, 1] == b))
+            assert abs(f_ref - want) < 0.01 and abs(f_mine - want) < 0.01, (a, b, want, f_ref, f_mine)
