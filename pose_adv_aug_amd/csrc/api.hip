@@ -286,6 +286,7 @@ pa_net* pa_hg_create(int num_stacks, int num_classes, int chan, int B, int res) 
     if (!p) return nullptr;
     Net& n = p->n;
     n.stacks = num_stacks; n.classes = num_classes; n.chan = chan; n.B = B; n.res = res;
+    n.immediate_reduce = getenv("PA_SHARED_SLAB") != nullptr;
     n.declare_pose();
     n.workspace_bytes = n.layout_all(nullptr);
     return p;
@@ -301,6 +302,7 @@ pa_net* pa_asn_create(int chan, int scale_num, int rotation_num, int B, int res)
     if (!p) return nullptr;
     Net& n = p->n;
     n.chan = chan; n.B = B; n.res = res; n.scale_num = scale_num; n.rot_num = rotation_num; n.stacks = 0;
+    n.immediate_reduce = getenv("PA_SHARED_SLAB") != nullptr;
     n.declare_asn();
     n.workspace_bytes = n.layout_asn(nullptr);
     return p;
@@ -316,6 +318,7 @@ pa_net* pa_asn_create_dropout(int chan, int B, int res) {
     if (!p) return nullptr;
     Net& n = p->n;
     n.chan = chan; n.B = B; n.res = res; n.stacks = 0; n.asn_dropout = true;
+    n.immediate_reduce = getenv("PA_SHARED_SLAB") != nullptr;
     n.declare_asn();
     n.workspace_bytes = n.layout_asn(nullptr);
     return p;

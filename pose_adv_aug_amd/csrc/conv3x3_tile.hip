@@ -58,7 +58,9 @@ __global__ __launch_bounds__(256, (TW == 16 ? (TH == 4 ? 3 : 2) : 1)) void conv3
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave & 1, wn = wave >> 1;
     const int tiles_x = a.W / TW, tiles_y = a.H / TH;
-    int t = blockIdx.x;
+    // consecutive workgroups go to different XCDs (round robin), each with its own L2: give every XCD one contiguous range
+    // of tiles so that the halo rows / columns shared by neighbouring tiles are found in that L2
+    int t = a.xcd ? (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
     const int tx = t % tiles_x; t /= tiles_x;
     const int ty = t % tiles_y;
     const int b = (t / tiles_y) * IMG;                 // first image of this workgroup
@@ -258,9 +260,13 @@ int pa_launch_conv3x3_tile(const PaConvArgs& a, hipStream_t st, int* stat_rows) 
     // the low-resolution levels have 3..12 pixel tiles: 64-channel halves double the number of workgroups
     const bool bigN = a.Cout % 128 == 0 && !n64 && !small;
     dim3 grid(tiles, a.Cout / (bigN ? 128 : 64));
-    if (half) launch_tile_shape<16, 4>(a, grid, bigN, st);
-    else if (!small) launch_tile_shape<16, 8>(a, grid, bigN, st);
-    else if (a.H == 8) launch_tile_shape<8, 8>(a, grid, bigN, st);
-    else launch_tile_shape<4, 4>(a, grid, bigN, st);
+    static int xcd = -1;
+    if (xcd < 0) xcd = getenv("PA_CONV3_NOXCD") ? 0 : 1;          // +0.3 % on the step (halo re-reads served by the XCD's own L2)
+    PaConvArgs b = a;
+    b.xcd = (xcd && !small && tiles % 8 == 0) ? 1 : 0;
+    if (half) launch_tile_shape<16, 4>(b, grid, bigN, st);
+    else if (!small) launch_tile_shape<16, 8>(b, grid, bigN, st);
+    else if (a.H == 8) launch_tile_shape<8, 8>(b, grid, bigN, st);
+    else launch_tile_shape<4, 4>(b, grid, bigN, st);
     return (int)hipGetLastError();
 }

@@ -11,6 +11,7 @@ struct PaConvArgs {
     PaEpilogue ep;
     bf16* out;           // [M][Cout]
     int B, H, W, Cin, Cout, taps;
+    int xcd;             // set by the launchers: workgroup i works on tile (i % 8) * (tiles / 8) + i / 8 (one contiguous range per XCD)
 };
 // stat_rows (optional) receives the number of partial-statistics rows the launch writes (= grid.x)
 int pa_launch_conv(const PaConvArgs& a, hipStream_t st, int* stat_rows = nullptr);

@@ -360,8 +360,8 @@ int Net::conv_wgrad(ConvLayer& c, const PaOperand& dy, const PaOperand& x, int B
     double wb, wf; conv_work(B_ * H * W, c.k == 7 ? 147 : c.Cin, c.Cout, c.k == 7 ? 1 : c.taps(), true, wb, wf);
     if (c.k == 7) wb = 2.0 * B_ * (4.0 * H * W * 4 + (double)H * W * 64) + 4.0 * 64 * 147;
     const int cls = c.k == 7 ? PA_PROF_STEM_WGRAD : (c.k == 3 ? PA_PROF_WGRAD3 : PA_PROF_WGRAD1);
-    if (multi_stream && wstream && !immediate_reduce) {        // deferred: flush_wgrads() launches it on the weight-gradient stream
-        PendingWgrad p; p.a = a; p.cls = cls; p.bytes = wb; p.flops = wf; p.stem = c.k == 7;
+    if (multi_stream && wstream) {        // deferred: flush_wgrads() launches it on the weight-gradient stream
+        PendingWgrad p; p.a = a; p.cls = cls; p.bytes = wb; p.flops = wf; p.stem = c.k == 7; p.c = &c;
         pending_wgrads.push_back(p);
         return 0;
     }
@@ -392,6 +392,32 @@ int Net::flush_wgrads() {
         int rc = p.stem ? pa_launch_stem_wgrad(p.a, wstream) : pa_launch_wgrad(p.a, wstream);
         prof.end(pe, wstream);
         if (rc) { pending_wgrads.clear(); return rc; }
+        if (immediate_reduce) {            // ONE slab shared by all layers: reduce before the next launch overwrites it
+            if (p.stem) {
+                TRY(pa_launch_stem_wgrad_reduce(p.c->part, p.c->splits, grads + p.c->p_w, wstream));
+                PA_CHECK(hipMemsetAsync(grads + p.c->p_b, 0, 64 * sizeof(float), wstream));
+            } else {
+                TRY(pa_launch_wgrad_reduce(red_jobs + p.c->red_index, 1, p.c->Cout * p.c->Cin * p.c->taps() + p.c->Cout, wstream));
+            }
+        }
+    }
+    if (reduce_early && !immediate_reduce) {                    // the group's slabs are summed while they are still in the Infinity Cache
+        int lo = 1 << 30, hi = -1, cnt = 0, mx = 0;
+        for (PendingWgrad& p : pending_wgrads) {
+            if (p.stem) {
+                TRY(pa_launch_stem_wgrad_reduce(p.c->part, p.c->splits, grads + p.c->p_w, wstream));
+                PA_CHECK(hipMemsetAsync(grads + p.c->p_b, 0, 64 * sizeof(float), wstream));
+                continue;
+            }
+            const int ri = p.c->red_index, el = p.c->Cout * p.c->Cin * p.c->taps() + p.c->Cout;
+            lo = ri < lo ? ri : lo; hi = ri > hi ? ri : hi; ++cnt; mx = el > mx ? el : mx;
+        }
+        if (cnt > 0 && hi - lo + 1 == cnt) {
+            TRY(pa_launch_wgrad_reduce(red_jobs + lo, cnt, mx, wstream));
+        } else {
+            for (PendingWgrad& p : pending_wgrads)
+                if (!p.stem) TRY(pa_launch_wgrad_reduce(red_jobs + p.c->red_index, 1, p.c->Cout * p.c->Cin * p.c->taps() + p.c->Cout, wstream));
+        }
     }
     pending_wgrads.clear();
     return 0;
@@ -547,6 +573,7 @@ int Net::ensure_streams() {
     if (streams_ready) return 0;
     if (getenv("PA_SINGLE_STREAM")) { multi_stream = false; streams_ready = true; return 0; }
     if (const char* e = getenv("PA_FORK_LEVELS")) fork_mask = atoi(e);
+    reduce_early = getenv("PA_WREDUCE_LATE") == nullptr;
     for (int k = 0; k < 4; ++k) {
         PA_CHECK(hipStreamCreateWithFlags(&side[k], hipStreamNonBlocking));
         PA_CHECK(hipEventCreateWithFlags(&ev_fork[k], hipEventDisableTiming));
@@ -661,12 +688,13 @@ int Net::backward_pose() {
 }
 
 int Net::reduce_grads() {
-    if (immediate_reduce) return 0;             // every layer was reduced right after its weight-gradient launch
     TRY(flush_wgrads());
     if (multi_stream && wstream) {              // all weight-gradient slabs are complete
         PA_CHECK(hipEventRecord(ev_wdone, wstream));
         PA_CHECK(hipStreamWaitEvent(st, ev_wdone, 0));
+        if (reduce_early || immediate_reduce) return 0;
     }
+    if (immediate_reduce) return 0;             // every layer was reduced right after its weight-gradient launch
     TRY(pa_launch_wgrad_reduce(red_jobs, n_red, red_max, st));
     if (!is_agent) {
         TRY(pa_launch_stem_wgrad_reduce(stem_conv.part, stem_conv.splits, grads + stem_conv.p_w, st));
