@@ -136,11 +136,16 @@ struct Net {
     hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_fork[4], ev_join[4];
     bool streams_ready = false, multi_stream = true;
+    // distinct side streams (PA_SIDE_STREAMS); level k uses side[k % n_side].  ONE stream for all four skip branches measured
+    // best (3128 vs 3090 img/s with four): main + side + weight-gradient stream = 3 hardware queues (the runtime has 4)
+    int n_side = 1;
     int fork_mask = 0xF;                       // bit k: hourglass level k forks its skip block (PA_FORK_LEVELS)
     bool forks(int k) const { return multi_stream && ((fork_mask >> k) & 1); }
     // weight-gradient launches only feed the slab reducer at the end of the backward pass: they run on their own
     // stream behind an event recorded where their operands are final, off the dgrad / BatchNorm critical chain
     hipStream_t wstream = nullptr;
+    hipStream_t wstreams[4] = {nullptr, nullptr, nullptr, nullptr}; int n_w = 1, w_rr = 0;   // wstream == wstreams[0]; groups go round robin
+    hipEvent_t ev_wdone_x[4];
     hipEvent_t ev_w[16]; int ev_w_next = 0;
     hipEvent_t ev_wdone;
     // weight-gradient launches are collected and flushed in groups: ONE event record on the producing stream per group
@@ -150,6 +155,7 @@ struct Net {
     // Infinity Cache) instead of by one 280 us reduction on the main stream at the end of the step: +1.1 % (PA_WREDUCE_LATE = old)
     bool reduce_early = true;
     std::vector<PendingWgrad> pending_wgrads;
+    int flush_every = 1, flush_ctr = 0; bool on_side = false;   // main-stream blocks flush every flush_every-th time (PA_WFLUSH_EVERY)
     int flush_wgrads();                        // record on `st`, make wstream wait, launch the collected weight gradients
     int ensure_streams();
     void release_streams();                    // destroys the side streams / events (pa_net_destroy)

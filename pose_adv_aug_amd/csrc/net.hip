@@ -5,6 +5,8 @@
 #include <stdio.h>
 #include <string.h>
 
+static int g_nosync = -1;      // PA_EXPERIMENT_NOSYNC: timing experiment only (results are garbage): no cross-stream waits
+static bool nosync() { if (g_nosync < 0) g_nosync = getenv("PA_EXPERIMENT_NOSYNC") ? atoi(getenv("PA_EXPERIMENT_NOSYNC")) : 0; return g_nosync != 0; }
 #define TRY(x) do { int _r = (x); if (_r) return _r; } while (0)
 
 PaOperand pa_plain(const bf16* p) { PaOperand o; o.p = p; o.q = nullptr; o.k0 = o.k1 = o.k2 = nullptr; o.mode = PA_LD_PLAIN; return o; }
@@ -384,20 +386,23 @@ int Net::conv_wgrad(ConvLayer& c, const PaOperand& dy, const PaOperand& x, int B
 // gradient buffers they read are written once per step, so deferring a launch is always safe.
 int Net::flush_wgrads() {
     if (pending_wgrads.empty()) return 0;
-    hipEvent_t ev = ev_w[ev_w_next]; ev_w_next = (ev_w_next + 1) & 15;
-    PA_CHECK(hipEventRecord(ev, st));
-    PA_CHECK(hipStreamWaitEvent(wstream, ev, 0));
+    hipStream_t ws = wstreams[w_rr]; w_rr = (w_rr + 1) % n_w;
+    if (!(nosync() && (g_nosync & 4))) {
+        hipEvent_t ev = ev_w[ev_w_next]; ev_w_next = (ev_w_next + 1) & 15;
+        PA_CHECK(hipEventRecord(ev, st));
+        PA_CHECK(hipStreamWaitEvent(ws, ev, 0));
+    }
     for (PendingWgrad& p : pending_wgrads) {
-        ProfEntry* pe = prof.begin(p.cls, p.bytes, p.flops, wstream);
-        int rc = p.stem ? pa_launch_stem_wgrad(p.a, wstream) : pa_launch_wgrad(p.a, wstream);
-        prof.end(pe, wstream);
+        ProfEntry* pe = prof.begin(p.cls, p.bytes, p.flops, ws);
+        int rc = p.stem ? pa_launch_stem_wgrad(p.a, ws) : pa_launch_wgrad(p.a, ws);
+        prof.end(pe, ws);
         if (rc) { pending_wgrads.clear(); return rc; }
         if (immediate_reduce) {            // ONE slab shared by all layers: reduce before the next launch overwrites it
             if (p.stem) {
-                TRY(pa_launch_stem_wgrad_reduce(p.c->part, p.c->splits, grads + p.c->p_w, wstream));
-                PA_CHECK(hipMemsetAsync(grads + p.c->p_b, 0, 64 * sizeof(float), wstream));
+                TRY(pa_launch_stem_wgrad_reduce(p.c->part, p.c->splits, grads + p.c->p_w, ws));
+                PA_CHECK(hipMemsetAsync(grads + p.c->p_b, 0, 64 * sizeof(float), ws));
             } else {
-                TRY(pa_launch_wgrad_reduce(red_jobs + p.c->red_index, 1, p.c->Cout * p.c->Cin * p.c->taps() + p.c->Cout, wstream));
+                TRY(pa_launch_wgrad_reduce(red_jobs + p.c->red_index, 1, p.c->Cout * p.c->Cin * p.c->taps() + p.c->Cout, ws));
             }
         }
     }
@@ -405,18 +410,18 @@ int Net::flush_wgrads() {
         int lo = 1 << 30, hi = -1, cnt = 0, mx = 0;
         for (PendingWgrad& p : pending_wgrads) {
             if (p.stem) {
-                TRY(pa_launch_stem_wgrad_reduce(p.c->part, p.c->splits, grads + p.c->p_w, wstream));
-                PA_CHECK(hipMemsetAsync(grads + p.c->p_b, 0, 64 * sizeof(float), wstream));
+                TRY(pa_launch_stem_wgrad_reduce(p.c->part, p.c->splits, grads + p.c->p_w, ws));
+                PA_CHECK(hipMemsetAsync(grads + p.c->p_b, 0, 64 * sizeof(float), ws));
                 continue;
             }
             const int ri = p.c->red_index, el = p.c->Cout * p.c->Cin * p.c->taps() + p.c->Cout;
             lo = ri < lo ? ri : lo; hi = ri > hi ? ri : hi; ++cnt; mx = el > mx ? el : mx;
         }
         if (cnt > 0 && hi - lo + 1 == cnt) {
-            TRY(pa_launch_wgrad_reduce(red_jobs + lo, cnt, mx, wstream));
+            TRY(pa_launch_wgrad_reduce(red_jobs + lo, cnt, mx, ws));
         } else {
             for (PendingWgrad& p : pending_wgrads)
-                if (!p.stem) TRY(pa_launch_wgrad_reduce(red_jobs + p.c->red_index, 1, p.c->Cout * p.c->Cin * p.c->taps() + p.c->Cout, wstream));
+                if (!p.stem) TRY(pa_launch_wgrad_reduce(red_jobs + p.c->red_index, 1, p.c->Cout * p.c->Cin * p.c->taps() + p.c->Cout, ws));
         }
     }
     pending_wgrads.clear();
@@ -454,6 +459,7 @@ int Residual::bwd_a(Net& n, const Act& in) {
     const PaOperand g1 = n.gradop(x1);
     TRY(n.conv_wgrad(c1, g1, n.op(in), B, H, W));
     if (has_adapter) TRY(n.conv_wgrad(ad, g3, n.op(in), B, H, W));
+    if (!n.on_side && (++n.flush_ctr % n.flush_every) != 0) return 0;
     return n.flush_wgrads();                   // one event for the block's 3-4 weight gradients
 }
 
@@ -479,9 +485,9 @@ int Residual::bwd(Net& n, const Act& in, const PaOperand& extra, bool in_needs_g
 // The skip branch of level k (a full-resolution residual block) does not depend on the low-resolution path
 // below it: it is enqueued on side stream k and joined where its result is consumed.
 struct StreamScope {
-    Net& n; hipStream_t saved;
-    StreamScope(Net& n_, hipStream_t s) : n(n_), saved(n_.st) { n.st = s; }
-    ~StreamScope() { n.st = saved; }
+    Net& n; hipStream_t saved; bool saved_side;
+    StreamScope(Net& n_, hipStream_t s) : n(n_), saved(n_.st), saved_side(n_.on_side) { n.st = s; n.on_side = true; }
+    ~StreamScope() { n.st = saved; n.on_side = saved_side; }
 };
 
 int Hourglass::encode(Net& n, const Act& in) {
@@ -573,14 +579,21 @@ int Net::ensure_streams() {
     if (streams_ready) return 0;
     if (getenv("PA_SINGLE_STREAM")) { multi_stream = false; streams_ready = true; return 0; }
     if (const char* e = getenv("PA_FORK_LEVELS")) fork_mask = atoi(e);
+    if (const char* e = getenv("PA_SIDE_STREAMS")) n_side = atoi(e) < 1 ? 1 : (atoi(e) > 4 ? 4 : atoi(e));
     reduce_early = getenv("PA_WREDUCE_LATE") == nullptr;
+    if (const char* e = getenv("PA_WFLUSH_EVERY")) flush_every = atoi(e) > 0 ? atoi(e) : 1;
     for (int k = 0; k < 4; ++k) {
-        PA_CHECK(hipStreamCreateWithFlags(&side[k], hipStreamNonBlocking));
+        if (k < n_side) PA_CHECK(hipStreamCreateWithFlags(&side[k], hipStreamNonBlocking));
+        else side[k] = side[k % n_side];            // levels share streams (in-order per stream: fork/join events keep it correct)
         PA_CHECK(hipEventCreateWithFlags(&ev_fork[k], hipEventDisableTiming));
         PA_CHECK(hipEventCreateWithFlags(&ev_join[k], hipEventDisableTiming));
     }
     if (!getenv("PA_NO_WSTREAM")) {
         PA_CHECK(hipStreamCreateWithFlags(&wstream, hipStreamNonBlocking));
+        wstreams[0] = wstream;
+        if (const char* e = getenv("PA_WSTREAMS")) n_w = atoi(e) < 1 ? 1 : (atoi(e) > 4 ? 4 : atoi(e));
+        for (int i = 1; i < n_w; ++i) PA_CHECK(hipStreamCreateWithFlags(&wstreams[i], hipStreamNonBlocking));
+        for (int i = 0; i < n_w; ++i) PA_CHECK(hipEventCreateWithFlags(&ev_wdone_x[i], hipEventDisableTiming));
         for (int i = 0; i < 16; ++i) PA_CHECK(hipEventCreateWithFlags(&ev_w[i], hipEventDisableTiming));
         PA_CHECK(hipEventCreateWithFlags(&ev_wdone, hipEventDisableTiming));
     }
@@ -589,10 +602,15 @@ int Net::ensure_streams() {
 }
 void Net::release_streams() {
     for (int k = 0; k < 4; ++k) {
-        if (side[k]) { (void)hipStreamSynchronize(side[k]); (void)hipStreamDestroy(side[k]); (void)hipEventDestroy(ev_fork[k]); (void)hipEventDestroy(ev_join[k]); side[k] = nullptr; }
+        if (side[k]) {
+            if (k < n_side) { (void)hipStreamSynchronize(side[k]); (void)hipStreamDestroy(side[k]); }
+            (void)hipEventDestroy(ev_fork[k]); (void)hipEventDestroy(ev_join[k]); side[k] = nullptr;
+        }
     }
     if (wstream) {
-        (void)hipStreamSynchronize(wstream); (void)hipStreamDestroy(wstream); wstream = nullptr;
+        for (int i = 1; i < n_w; ++i) { (void)hipStreamSynchronize(wstreams[i]); (void)hipStreamDestroy(wstreams[i]); wstreams[i] = nullptr; }
+        for (int i = 0; i < n_w; ++i) (void)hipEventDestroy(ev_wdone_x[i]);
+        (void)hipStreamSynchronize(wstream); (void)hipStreamDestroy(wstream); wstream = nullptr; wstreams[0] = nullptr;
         for (int i = 0; i < 16; ++i) (void)hipEventDestroy(ev_w[i]);
         (void)hipEventDestroy(ev_wdone);
     }
@@ -600,9 +618,9 @@ void Net::release_streams() {
     prof.entries.clear(); prof.used = 0;
     streams_ready = false;
 }
-int Net::fork_to(int k) { PA_CHECK(hipEventRecord(ev_fork[k], st)); PA_CHECK(hipStreamWaitEvent(side[k], ev_fork[k], 0)); return 0; }
-int Net::record_join(int k) { PA_CHECK(hipEventRecord(ev_join[k], side[k])); return 0; }
-int Net::wait_join(int k) { PA_CHECK(hipStreamWaitEvent(st, ev_join[k], 0)); return 0; }
+int Net::fork_to(int k) { if (nosync() && (g_nosync & 1)) return 0; PA_CHECK(hipEventRecord(ev_fork[k], st)); PA_CHECK(hipStreamWaitEvent(side[k], ev_fork[k], 0)); return 0; }
+int Net::record_join(int k) { if (nosync() && (g_nosync & 2)) return 0; PA_CHECK(hipEventRecord(ev_join[k], side[k])); return 0; }
+int Net::wait_join(int k) { if (nosync() && (g_nosync & 2)) return 0; PA_CHECK(hipStreamWaitEvent(st, ev_join[k], 0)); return 0; }
 
 // ------------------------------------------------------------------------------------------------
 int Net::prepare_weights() { return pa_launch_weight_prep(prep_jobs, n_prep, prep_max, st); }
@@ -690,8 +708,12 @@ int Net::backward_pose() {
 int Net::reduce_grads() {
     TRY(flush_wgrads());
     if (multi_stream && wstream) {              // all weight-gradient slabs are complete
-        PA_CHECK(hipEventRecord(ev_wdone, wstream));
-        PA_CHECK(hipStreamWaitEvent(st, ev_wdone, 0));
+        if (!(nosync() && (g_nosync & 8))) {
+            for (int i = 0; i < n_w; ++i) {
+                PA_CHECK(hipEventRecord(ev_wdone_x[i], wstreams[i]));
+                PA_CHECK(hipStreamWaitEvent(st, ev_wdone_x[i], 0));
+            }
+        }
         if (reduce_early || immediate_reduce) return 0;
     }
     if (immediate_reduce) return 0;             // every layer was reduced right after its weight-gradient launch
