@@ -264,12 +264,26 @@ int pa_conv2d_time(int mode, int variant, int B, int Cin, int Cout, int H, int W
         }
     };
     for (int i = 0; i < 3; ++i) TRY(once());
-    PA_CHECK(hipEventRecord(e0, n.st));
-    for (int i = 0; i < iters; ++i) TRY(once());
-    PA_CHECK(hipEventRecord(e1, n.st));
-    PA_CHECK(hipEventSynchronize(e1));
     float ms = 0.f;
-    PA_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    if (variant & 16) {            // COLD: 640 MB of other traffic between launches (the Infinity Cache holds 256 MB), one event pair per launch
+        char* scratch = a.get<char>((size_t)640 << 20);
+        for (int i = 0; i < iters; ++i) {
+            PA_CHECK(hipMemsetAsync(scratch, i & 1, (size_t)640 << 20, n.st));
+            PA_CHECK(hipEventRecord(e0, n.st));
+            TRY(once());
+            PA_CHECK(hipEventRecord(e1, n.st));
+            PA_CHECK(hipEventSynchronize(e1));
+            float t = 0.f;
+            PA_CHECK(hipEventElapsedTime(&t, e0, e1));
+            ms += t;
+        }
+    } else {
+        PA_CHECK(hipEventRecord(e0, n.st));
+        for (int i = 0; i < iters; ++i) TRY(once());
+        PA_CHECK(hipEventRecord(e1, n.st));
+        PA_CHECK(hipEventSynchronize(e1));
+        PA_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    }
     *ms_out = ms / iters;
     hipEventDestroy(e0); hipEventDestroy(e1);
     return 0;

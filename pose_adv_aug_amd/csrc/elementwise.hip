@@ -360,6 +360,91 @@ __global__ __launch_bounds__(1024) void upadd_bwd_kernel(const bf16* dout, PaEpi
     if (eps.mode != PA_OUT_PLAIN) flush_stats(red, eps.stats, C, c, k1, k2);
 }
 
+
+// ---- streaming variants for the hot configurations (both epilogues BatchNorm-backward).  Measured COLD (operands not in
+// the Infinity Cache, tools/bench_cold.py) the generic kernels above move 1.7-2.1 TB/s: runtime mode branches, 56 scratch
+// accesses and per-use loads of the per-channel constants serialise their loads.  Here the modes are template parameters,
+// the per-channel constants sit in LDS as float4 {scale, shift, mean, invstd}, and ALL loads of an item (9 x 16 bytes) are
+// issued before the first use, so that a 1024-thread workgroup keeps ~150 KB in flight.
+struct Bwd8 {            // one BatchNorm-backward epilogue on 8 channels: dz = g * [s*x+t > 0], sums of dz and dz*xhat
+    __device__ __forceinline__ static bf16x8 apply(const float4* cst, int c, const bf16x8& xr, const float (&g)[8], float (&s1)[8], float (&s2)[8]) {
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float4 k = cst[c + j];
+            const float x = (float)xr[j];
+            const float dz = (fmaf(k.x, x, k.y) > 0.f) ? g[j] : 0.f;
+            o[j] = (bf16)dz;
+            const float dzr = (float)o[j];
+            s1[j] += dzr;
+            s2[j] += dzr * (x - k.z) * k.w;
+        }
+        return o;
+    }
+};
+
+__device__ __forceinline__ void stage_bwd_consts(float4* dst, const PaEpilogue& ep, int C) {
+    for (int i = threadIdx.x; i < C; i += blockDim.x) dst[i] = make_float4(ep.scale[i], ep.shift[i], ep.mean[i], ep.invstd[i]);
+}
+
+__global__ __launch_bounds__(1024) void upadd_bwd_bb_kernel(const bf16* __restrict__ dout, PaEpilogue epl, bf16* __restrict__ dlow,
+                                                            PaEpilogue eps, bf16* __restrict__ dskip, int rows, int W, int C) {
+    // rows = B * H/2 low-resolution rows; row r covers high-resolution rows 2r, 2r+1 (H = 2*Hl: no batch/row split needed).
+    // blockDim is a multiple of the items of a row (Wl * C/8) or the other way round (launcher): no per-iteration division.
+    extern __shared__ float red[];     // [nwaves][2*C] partial statistics, then the two constant tables
+    float4* cl = reinterpret_cast<float4*>(red + (blockDim.x / 64) * 2 * C);
+    float4* cs = cl + C;
+    stage_bwd_consts(cl, epl, C);
+    stage_bwd_consts(cs, eps, C);
+    __syncthreads();
+    const int CG = C / 8, Wl = W / 2;
+    const unsigned row_items = (unsigned)Wl * CG;
+    float l1[8], l2[8], k1[8], k2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { l1[j] = l2[j] = k1[j] = k2[j] = 0.f; }
+    const int c = (threadIdx.x % CG) * 8;
+    const unsigned rows_per_it = row_items >= blockDim.x ? 1u : blockDim.x / row_items;
+    const unsigned rsub = row_items >= blockDim.x ? 0u : threadIdx.x / row_items;
+    const unsigned i0 = row_items >= blockDim.x ? threadIdx.x : threadIdx.x % row_items;
+    const bf16* __restrict__ xsk = eps.xref;
+    const bf16* __restrict__ xlo = epl.xref;
+    for (unsigned rb = blockIdx.x * rows_per_it; rb < (unsigned)rows; rb += gridDim.x * rows_per_it) {
+        const unsigned r = rb + rsub;
+        if (r >= (unsigned)rows) continue;
+        for (unsigned i = i0; i < row_items; i += blockDim.x) {
+            const unsigned xl = i / (unsigned)CG;
+            int cc = c;
+            asm volatile("" : "+v"(cc));      // opaque per iteration: the constant tables stay in LDS (hoisted they are 64 registers)
+            const unsigned top = ((2u * r) * (unsigned)W + 2u * xl) * (unsigned)C + (unsigned)c;
+            const unsigned wc = (unsigned)W * (unsigned)C;
+            const unsigned off[4] = {top, top + (unsigned)C, top + wc, top + wc + (unsigned)C};
+            const unsigned li = (r * (unsigned)Wl + xl) * (unsigned)C + (unsigned)c;
+            bf16x8 g[4], xs[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                g[k] = *reinterpret_cast<const bf16x8*>(dout + off[k]);
+                xs[k] = *reinterpret_cast<const bf16x8*>(xsk + off[k]);
+            }
+            const bf16x8 xlow = *reinterpret_cast<const bf16x8*>(xlo + li);
+            __builtin_amdgcn_sched_barrier(0);        // all nine loads are issued; the constant reads below stay next to their use
+            float sum[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sum[j] = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { v[j] = (float)g[k][j]; sum[j] += v[j]; }
+                *reinterpret_cast<bf16x8*>(dskip + off[k]) = Bwd8::apply(cs, cc, xs[k], v, k1, k2);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            *reinterpret_cast<bf16x8*>(dlow + li) = Bwd8::apply(cl, cc, xlow, sum, l1, l2);
+        }
+    }
+    flush_stats(red, epl.stats, C, c, l1, l2);
+    flush_stats(red, eps.stats, C, c, k1, k2);
+}
+
 int pa_launch_upadd_bwd(const bf16* dout, const PaEpilogue& ep_low, bf16* dlow, const PaEpilogue& ep_skip, bf16* dskip,
                         int B, int H, int W, int C, hipStream_t st, int* stat_rows) {
     size_t total = (size_t)B * (H / 2) * (W / 2) * (C / 8);
@@ -368,6 +453,15 @@ int pa_launch_upadd_bwd(const bf16* dout, const PaEpilogue& ep_low, bf16* dlow, 
     if (stat_rows) *stat_rows = blocks;
     if (ep_low.rows_out) *ep_low.rows_out = blocks;
     if (ep_skip.rows_out) *ep_skip.rows_out = blocks;
+    static int old = -1;
+    if (old < 0) old = getenv("PA_ELTWISE_OLD") ? 1 : 0;
+    const size_t row_items = (size_t)(W / 2) * (C / 8);
+    if (!old && ep_low.mode == PA_OUT_BWD && ep_skip.mode == PA_OUT_BWD && threads % (C / 8) == 0 &&
+        (row_items % threads == 0 || threads % row_items == 0) && (size_t)B * H * W * C < ((size_t)1 << 31)) {
+        hipLaunchKernelGGL(upadd_bwd_bb_kernel, dim3(blocks), dim3(threads), (threads / 64) * 2 * C * sizeof(float) + 2 * C * sizeof(float4), st,
+                           dout, ep_low, dlow, ep_skip, dskip, B * (H / 2), W, C);
+        return (int)hipGetLastError();
+    }
     hipLaunchKernelGGL(upadd_bwd_kernel, dim3(blocks), dim3(threads), (threads / 64) * 2 * C * sizeof(float), st, dout, ep_low, dlow, ep_skip, dskip,
                        B, H, W, C);
     return (int)hipGetLastError();
