@@ -192,6 +192,27 @@ __device__ __forceinline__ void flush_stats(float* red, float* gstats, int C, in
     }
 }
 
+struct Bwd8 {            // one BatchNorm-backward epilogue on 8 channels: dz = g * [s*x+t > 0], sums of dz and dz*xhat
+    __device__ __forceinline__ static bf16x8 apply(const float4* cst, int c, const bf16x8& xr, const float (&g)[8], float (&s1)[8], float (&s2)[8]) {
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float4 k = cst[c + j];
+            const float x = (float)xr[j];
+            const float dz = (fmaf(k.x, x, k.y) > 0.f) ? g[j] : 0.f;
+            o[j] = (bf16)dz;
+            const float dzr = (float)o[j];
+            s1[j] += dzr;
+            s2[j] += dzr * (x - k.z) * k.w;
+        }
+        return o;
+    }
+};
+
+__device__ __forceinline__ void stage_bwd_consts(float4* dst, const PaEpilogue& ep, int C) {
+    for (int i = threadIdx.x; i < C; i += blockDim.x) dst[i] = make_float4(ep.scale[i], ep.shift[i], ep.mean[i], ep.invstd[i]);
+}
+
 // ------------------------------------------------------------------------------------------------
 // 2x2/2 max pool (reference models/asn_stacked_hg.py:69,227), input transform applied on load
 __global__ void maxpool_fwd_kernel(PaOperand in, bf16* out, int B, int H, int W, int C) {
@@ -284,6 +305,94 @@ __global__ __launch_bounds__(1024) void maxpool_bwd_kernel(const bf16* dout, PaO
     if (ep.mode != PA_OUT_PLAIN) flush_stats(red, ep.stats, C, c, s1, s2);
 }
 
+
+// maxpool backward, streaming variant (see upadd_bwd_bb_kernel): row r of the pooled map covers input rows 2r, 2r+1.
+// INMODE: PLAIN / BNRELU value of the pooled tensor (argmax); HASADD: plain addend; EPMODE: PLAIN or BatchNorm-backward.
+template <int INMODE, bool HASADD, int EPMODE>
+__global__ __launch_bounds__(1024) void maxpool_bwd_s_kernel(const bf16* __restrict__ dout, PaOperand in, const bf16* __restrict__ add,
+                                                             PaEpilogue ep, bf16* __restrict__ din, int rows, int W, int C) {
+    extern __shared__ float red[];     // [nwaves][2*C] partial statistics, then constants: float4 {scale, shift, mean, invstd} or float2 {k0, k1}
+    float4* cst = reinterpret_cast<float4*>(red + (blockDim.x / 64) * 2 * C);
+    float2* kin = reinterpret_cast<float2*>(cst + (EPMODE == PA_OUT_BWD ? C : 0));
+    if (EPMODE == PA_OUT_BWD) stage_bwd_consts(cst, ep, C);
+    if (INMODE == PA_LD_BNRELU)
+        for (int i = threadIdx.x; i < C; i += blockDim.x) kin[i] = make_float2(in.k0[i], in.k1[i]);
+    __syncthreads();
+    const int CG = C / 8, Wo = W / 2;
+    const unsigned row_items = (unsigned)Wo * CG;
+    float s1[8], s2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+    const int c = (threadIdx.x % CG) * 8;
+    const unsigned rows_per_it = row_items >= blockDim.x ? 1u : blockDim.x / row_items;
+    const unsigned rsub = row_items >= blockDim.x ? 0u : threadIdx.x / row_items;
+    const unsigned i0 = row_items >= blockDim.x ? threadIdx.x : threadIdx.x % row_items;
+    const bf16* __restrict__ xin = in.p;
+    for (unsigned rb = blockIdx.x * rows_per_it; rb < (unsigned)rows; rb += gridDim.x * rows_per_it) {
+        const unsigned r = rb + rsub;
+        if (r >= (unsigned)rows) continue;
+        for (unsigned i = i0; i < row_items; i += blockDim.x) {
+            const unsigned xo = i / (unsigned)CG;
+            int cc = c;
+            asm volatile("" : "+v"(cc));
+            const unsigned top = ((2u * r) * (unsigned)W + 2u * xo) * (unsigned)C + (unsigned)c;
+            const unsigned wc = (unsigned)W * (unsigned)C;
+            const unsigned off[4] = {top, top + (unsigned)C, top + wc, top + wc + (unsigned)C};
+            const bf16x8 g = *reinterpret_cast<const bf16x8*>(dout + (r * (unsigned)Wo + xo) * (unsigned)C + (unsigned)c);
+            bf16x8 x[4], e[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                x[k] = *reinterpret_cast<const bf16x8*>(xin + off[k]);
+                if (HASADD) e[k] = *reinterpret_cast<const bf16x8*>(add + off[k]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            float v[4][8];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float t = (float)x[k][j];
+                    if (INMODE == PA_LD_BNRELU) { const float2 kk = kin[cc + j]; t = fmaxf(fmaf(kk.x, t, kk.y), 0.f); }
+                    v[k][j] = t;
+                }
+            int arg[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                int a = 0; float m = v[0][j];
+#pragma unroll
+                for (int k = 1; k < 4; ++k) if (v[k][j] > m) { m = v[k][j]; a = k; }
+                arg[j] = a;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float rr[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) rr[j] = (arg[j] == k ? (float)g[j] : 0.f) + (HASADD ? (float)e[k][j] : 0.f);
+                bf16x8 o;
+                if (EPMODE == PA_OUT_BWD) {
+                    o = Bwd8::apply(cst, cc, x[k], rr, s1, s2);      // the tensor being differentiated IS the pooled tensor (launcher checks)
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) o[j] = (bf16)rr[j];
+                }
+                *reinterpret_cast<bf16x8*>(din + off[k]) = o;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    if (EPMODE == PA_OUT_BWD) flush_stats(red, ep.stats, C, c, s1, s2);
+}
+
+template <int INMODE, bool HASADD>
+static void launch_maxpool_bwd_s(const bf16* dout, const PaOperand& in, const bf16* add, const PaEpilogue& ep, bf16* din, int rows, int W, int C,
+                                 int blocks, int threads, hipStream_t st) {
+    const size_t lds = (threads / 64) * 2 * C * sizeof(float) + C * sizeof(float4) + C * sizeof(float2);
+    if (ep.mode == PA_OUT_BWD)
+        hipLaunchKernelGGL((maxpool_bwd_s_kernel<INMODE, HASADD, PA_OUT_BWD>), dim3(blocks), dim3(threads), lds, st, dout, in, add, ep, din, rows, W, C);
+    else
+        hipLaunchKernelGGL((maxpool_bwd_s_kernel<INMODE, HASADD, PA_OUT_PLAIN>), dim3(blocks), dim3(threads), lds, st, dout, in, add, ep, din, rows, W, C);
+}
+
 int pa_launch_maxpool_bwd(const bf16* dout, const PaOperand& in, const PaOperand& add, const PaEpilogue& ep, bf16* din,
                           int B, int H, int W, int C, hipStream_t st, int* stat_rows) {
     size_t total = (size_t)B * (H / 2) * (W / 2) * (C / 8);
@@ -291,6 +400,28 @@ int pa_launch_maxpool_bwd(const bf16* dout, const PaOperand& in, const PaOperand
     stream_launch_dims(total, blocks, threads);
     if (stat_rows) *stat_rows = blocks;
     if (ep.rows_out) *ep.rows_out = blocks;
+    {
+        static int old = -1;
+        if (old < 0) old = getenv("PA_ELTWISE_OLD") ? 1 : 0;
+        const size_t row_items = (size_t)(W / 2) * (C / 8);
+        const bool in_ok = in.mode == PA_LD_PLAIN || in.mode == PA_LD_BNRELU;
+        const bool add_ok = add.mode == PA_LD_NONE || add.mode == PA_LD_PLAIN;
+        // BatchNorm-backward epilogue: only when it refers to the pooled tensor itself (its raw values are already in registers)
+        const bool ep_ok = ep.mode == PA_OUT_PLAIN || (ep.mode == PA_OUT_BWD && ep.xref == in.p);
+        if (!old && in_ok && add_ok && ep_ok && threads % (C / 8) == 0 && (row_items % threads == 0 || threads % row_items == 0) &&
+            (size_t)B * H * W * C < ((size_t)1 << 31)) {
+            const int rows = B * (H / 2);
+            const bool has_add = add.mode == PA_LD_PLAIN;
+            if (in.mode == PA_LD_BNRELU) {
+                if (has_add) launch_maxpool_bwd_s<PA_LD_BNRELU, true>(dout, in, add.p, ep, din, rows, W, C, blocks, threads, st);
+                else launch_maxpool_bwd_s<PA_LD_BNRELU, false>(dout, in, nullptr, ep, din, rows, W, C, blocks, threads, st);
+            } else {
+                if (has_add) launch_maxpool_bwd_s<PA_LD_PLAIN, true>(dout, in, add.p, ep, din, rows, W, C, blocks, threads, st);
+                else launch_maxpool_bwd_s<PA_LD_PLAIN, false>(dout, in, nullptr, ep, din, rows, W, C, blocks, threads, st);
+            }
+            return (int)hipGetLastError();
+        }
+    }
     hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(blocks), dim3(threads), (threads / 64) * 2 * C * sizeof(float), st, dout, in, add, ep, din, B, H, W, C);
     return (int)hipGetLastError();
 }
@@ -366,27 +497,6 @@ __global__ __launch_bounds__(1024) void upadd_bwd_kernel(const bf16* dout, PaEpi
 // accesses and per-use loads of the per-channel constants serialise their loads.  Here the modes are template parameters,
 // the per-channel constants sit in LDS as float4 {scale, shift, mean, invstd}, and ALL loads of an item (9 x 16 bytes) are
 // issued before the first use, so that a 1024-thread workgroup keeps ~150 KB in flight.
-struct Bwd8 {            // one BatchNorm-backward epilogue on 8 channels: dz = g * [s*x+t > 0], sums of dz and dz*xhat
-    __device__ __forceinline__ static bf16x8 apply(const float4* cst, int c, const bf16x8& xr, const float (&g)[8], float (&s1)[8], float (&s2)[8]) {
-        bf16x8 o;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float4 k = cst[c + j];
-            const float x = (float)xr[j];
-            const float dz = (fmaf(k.x, x, k.y) > 0.f) ? g[j] : 0.f;
-            o[j] = (bf16)dz;
-            const float dzr = (float)o[j];
-            s1[j] += dzr;
-            s2[j] += dzr * (x - k.z) * k.w;
-        }
-        return o;
-    }
-};
-
-__device__ __forceinline__ void stage_bwd_consts(float4* dst, const PaEpilogue& ep, int C) {
-    for (int i = threadIdx.x; i < C; i += blockDim.x) dst[i] = make_float4(ep.scale[i], ep.shift[i], ep.mean[i], ep.invstd[i]);
-}
-
 __global__ __launch_bounds__(1024) void upadd_bwd_bb_kernel(const bf16* __restrict__ dout, PaEpilogue epl, bf16* __restrict__ dlow,
                                                             PaEpilogue eps, bf16* __restrict__ dskip, int rows, int W, int C) {
     // rows = B * H/2 low-resolution rows; row r covers high-resolution rows 2r, 2r+1 (H = 2*Hl: no batch/row split needed).
