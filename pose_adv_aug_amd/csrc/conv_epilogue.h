@@ -31,61 +31,83 @@ __device__ __forceinline__ int pa_lds_row_of_weight_row(int c) {
 }
 
 // pix(mi) -> flattened NHWC pixel index of fragment column (lane & 15) of fragment row-block mi, or -1
-// `red` = at least 2*BN*2 floats of LDS that are dead by now; stat_row = this workgroup's partial row
+// `red` = at least 14*BN floats of LDS that are dead by now (every wave is past its last read of them: the callers
+// barrier before the epilogue); stat_row = this workgroup's partial row.
+// The per-channel constants (BatchNorm-backward scale/shift/mean/invstd, the transforms of the two addends, the bias)
+// are staged ONCE per call into LDS: read from global per use they were ~180 of the ~200 load instructions of a
+// data-gradient epilogue, all in front of the data loads in the in-order vmcnt queue.  Per 8-channel chunk the
+// operand loads of all MI pixels are issued together, before the first use.
 template <int BN, int NI, int MI, class PixFn>
 __device__ __forceinline__ void pa_conv_epilogue(const PaConvArgs& a, f32x4 (&acc)[NI][MI], int n0, int wm, int wn,
                                                  PixFn pix, float* red, int stat_row) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int N = a.Cout;
     constexpr int CH = NI / 2;                       // 8-channel chunks per lane
-    const int nb = n0 + wn * (BN / 2) + (lane >> 4) * 8;
+    float4* cep = reinterpret_cast<float4*>(red + 4 * BN);      // [BN] {scale, shift, mean, invstd}
+    float4* ca1 = cep + BN;                                      // [BN] {k0, k1, k2, bias}
+    float4* ca2 = ca1 + BN;                                      // [BN] {k0, k1, k2, -}
+    const int m1 = a.add1.mode, m2 = a.add2.mode;
+    for (int i = tid; i < BN; i += 256) {
+        const int n = n0 + i;
+        if (a.ep.mode == PA_OUT_BWD) cep[i] = make_float4(a.ep.scale[n], a.ep.shift[n], a.ep.mean[n], a.ep.invstd[n]);
+        float4 k = make_float4(0.f, 0.f, 0.f, a.bias ? a.bias[n] : 0.f);
+        if (m1 == PA_LD_BNRELU || m1 == PA_LD_LIN2) { k.x = a.add1.k0[n]; k.y = a.add1.k1[n]; if (m1 == PA_LD_LIN2) k.z = a.add1.k2[n]; }
+        ca1[i] = k;
+        if (m2 == PA_LD_BNRELU || m2 == PA_LD_LIN2) ca2[i] = make_float4(a.add2.k0[n], a.add2.k1[n], m2 == PA_LD_LIN2 ? a.add2.k2[n] : 0.f, 0.f);
+    }
+    __syncthreads();
+    const int lb = wn * (BN / 2) + (lane >> 4) * 8;              // tile-relative channel of this lane's chunk 0
+    const int nb = n0 + lb;
     float s1[NI][4], s2[NI][4];
 #pragma unroll
-    for (int ch = 0; ch < CH; ++ch) {               // chunk-outer / pixel-inner keeps the per-channel constants short-lived
-        const int n = nb + 32 * ch;
-        float bias[8], es[8], et[8], emu[8], eis[8];
+    for (int ch = 0; ch < CH; ++ch) {
+        const int n = nb + 32 * ch, ln = lb + 32 * ch;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            s1[2 * ch + (j >> 2)][j & 3] = 0.f; s2[2 * ch + (j >> 2)][j & 3] = 0.f;
-            bias[j] = a.bias ? a.bias[n + j] : 0.f;
-            if (a.ep.mode == PA_OUT_BWD) {
-                es[j] = a.ep.scale[n + j]; et[j] = a.ep.shift[n + j]; emu[j] = a.ep.mean[n + j]; eis[j] = a.ep.invstd[n + j];
-            }
-        }
+        for (int j = 0; j < 8; ++j) { s1[2 * ch + (j >> 2)][j & 3] = 0.f; s2[2 * ch + (j >> 2)][j & 3] = 0.f; }
+        // ---- every operand of the chunk in flight first
+        size_t idx[MI];
+        bf16x8 xr[MI], p1[MI], q1[MI], p2[MI], q2[MI];
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
             const int m = pix(mi);
-            if (m < 0) continue;
-            const size_t idx = (size_t)m * N + n;
-            float e1[8], e2[8];
-            pa_read8(a.add1, idx, n, e1);
-            pa_read8(a.add2, idx, n, e2);
+            idx[mi] = m < 0 ? (size_t)0 : (size_t)m * N + n;     // clamped: unconditional loads, the store is guarded
+            if (a.ep.mode == PA_OUT_BWD) xr[mi] = *reinterpret_cast<const bf16x8*>(a.ep.xref + idx[mi]);
+            if (m1 != PA_LD_NONE) p1[mi] = *reinterpret_cast<const bf16x8*>(a.add1.p + idx[mi]);
+            if (m1 == PA_LD_LIN2) q1[mi] = *reinterpret_cast<const bf16x8*>(a.add1.q + idx[mi]);
+            if (m2 != PA_LD_NONE) p2[mi] = *reinterpret_cast<const bf16x8*>(a.add2.p + idx[mi]);
+            if (m2 == PA_LD_LIN2) q2[mi] = *reinterpret_cast<const bf16x8*>(a.add2.q + idx[mi]);
+        }
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            if (pix(mi) < 0) continue;
             bf16x8 o;
-            if (a.ep.mode == PA_OUT_BWD) {
-                bf16x8 xr = *reinterpret_cast<const bf16x8*>(a.ep.xref + idx);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int ni = 2 * ch + (j >> 2);
-                    float v = acc[ni][mi][j & 3] + bias[j] + e1[j] + e2[j];
-                    float x = (float)xr[j];
-                    float dz = (fmaf(es[j], x, et[j]) > 0.f) ? v : 0.f;
+            for (int j = 0; j < 8; ++j) {
+                const int ni = 2 * ch + (j >> 2);
+                const float4 k1 = ca1[ln + j];
+                float v = acc[ni][mi][j & 3] + k1.w;
+                if (m1 == PA_LD_PLAIN) v += (float)p1[mi][j];
+                else if (m1 == PA_LD_LIN2) v += fmaf(k1.x, (float)p1[mi][j], fmaf(k1.y, (float)q1[mi][j], k1.z));
+                else if (m1 == PA_LD_BNRELU) v += fmaxf(fmaf(k1.x, (float)p1[mi][j], k1.y), 0.f);
+                if (m2 == PA_LD_PLAIN) v += (float)p2[mi][j];
+                else if (m2 == PA_LD_LIN2) { const float4 k2 = ca2[ln + j]; v += fmaf(k2.x, (float)p2[mi][j], fmaf(k2.y, (float)q2[mi][j], k2.z)); }
+                else if (m2 == PA_LD_BNRELU) { const float4 k2 = ca2[ln + j]; v += fmaxf(fmaf(k2.x, (float)p2[mi][j], k2.y), 0.f); }
+                if (a.ep.mode == PA_OUT_BWD) {
+                    const float4 e = cep[ln + j];
+                    const float x = (float)xr[mi][j];
+                    const float dz = (fmaf(e.x, x, e.y) > 0.f) ? v : 0.f;
                     o[j] = (bf16)dz;
-                    float dzr = (float)o[j];
+                    const float dzr = (float)o[j];
                     s1[ni][j & 3] += dzr;
-                    s2[ni][j & 3] += dzr * (x - emu[j]) * eis[j];
-                }
-            } else {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int ni = 2 * ch + (j >> 2);
-                    float v = acc[ni][mi][j & 3] + bias[j] + e1[j] + e2[j];
+                    s2[ni][j & 3] += dzr * (x - e.z) * e.w;
+                } else {
                     o[j] = (bf16)v;
-                    float rv = (float)o[j];
+                    const float rv = (float)o[j];
                     s1[ni][j & 3] += rv;
                     s2[ni][j & 3] += rv * rv;
                 }
             }
-            *reinterpret_cast<bf16x8*>(a.out + idx) = o;
+            *reinterpret_cast<bf16x8*>(a.out + idx[mi]) = o;
         }
     }
     if (a.ep.mode != PA_OUT_PLAIN) {
