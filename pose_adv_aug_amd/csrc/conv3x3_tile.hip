@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256, (TW == 16 ? (TH == 4 ? 3 : 2) : 1)) void conv3
     const int tiles_x = a.W / TW, tiles_y = a.H / TH;
     // consecutive workgroups go to different XCDs (round robin), each with its own L2: give every XCD one contiguous range
     // of tiles so that the halo rows / columns shared by neighbouring tiles are found in that L2
-    int t = a.xcd ? (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    int t = (a.xcd & 1) ? (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
     const int tx = t % tiles_x; t /= tiles_x;
     const int ty = t % tiles_y;
     const int b = (t / tiles_y) * IMG;                 // first image of this workgroup
@@ -263,7 +263,7 @@ int pa_launch_conv3x3_tile(const PaConvArgs& a, hipStream_t st, int* stat_rows) 
     static int xcd = -1;
     if (xcd < 0) xcd = getenv("PA_CONV3_NOXCD") ? 0 : 1;          // +0.3 % on the step (halo re-reads served by the XCD's own L2)
     PaConvArgs b = a;
-    b.xcd = (xcd && !small && tiles % 8 == 0) ? 1 : 0;
+    b.xcd = (a.xcd & 2) | ((xcd && !small && tiles % 8 == 0) ? 1 : 0);
     if (half) launch_tile_shape<16, 4>(b, grid, bigN, st);
     else if (!small) launch_tile_shape<16, 8>(b, grid, bigN, st);
     else if (a.H == 8) launch_tile_shape<8, 8>(b, grid, bigN, st);

@@ -218,13 +218,125 @@ __device__ __forceinline__ void pa_conv_epilogue_lds(const PaConvArgs& a, f32x4 
     }
 }
 
-// forward epilogues through LDS (coalesced rows), backward epilogue direct; pix(wm, mi, p) as above
+// BatchNorm-BACKWARD epilogue through the same LDS tile (coalesced 256-byte rows for the reference tensor, the addends and
+// the output).  Differences from the forward variant that make it pay: (1) the operands of TWO 32-row passes (reference
+// tensor, both addends incl. the second operand of a LIN2 addend) and the thread's per-channel constants are requested
+// together, before the first pass barrier, so one memory round trip covers the whole workgroup tile of a 64-row kernel;
+// (2) a thread owns the same 8 channels for all its pixels, so the constants live in registers; (3) the second reduction
+// is accumulated as sum(dz * x) and turned into sum(dz * xhat) = invstd * (sum(dz*x) - mean * sum(dz)) once per
+// workgroup row, which removes mean / invstd from the per-element work.
 template <int BN, int NI, int MI, class PixFn>
+__device__ __forceinline__ void pa_conv_epilogue_lds_bwd(const PaConvArgs& a, f32x4 (&acc)[NI][MI], int n0, int wm, int wn,
+                                                         PixFn pix, float* T, int stat_row) {
+    constexpr int CPR = BN / 8;
+    constexpr int RPS = 256 / CPR;
+    constexpr int SW = 32 / RPS;
+    constexpr int G = MI >= 2 ? 2 : 1;               // passes per operand request
+    constexpr int IT = G * SW;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int N = a.Cout;
+    const int chunk = tid % CPR, rsub = tid / CPR;
+    const int n = n0 + chunk * 8;
+    const int m1 = a.add1.mode, m2 = a.add2.mode;
+    float s1[8], s2[8], es[8], et[8], ka[8], kb[8], kc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+    const int wrow = wm * 16 + (lane & 15);
+    const int wslot0 = (wn * (BN / 2)) / 4 + 2 * (lane >> 4);
+#pragma unroll
+    for (int g = 0; g < MI; g += G) {
+        // ---- request everything the next G passes need
+        size_t idx[IT];
+        bool ok[IT];
+        bf16x8 xr[IT], p1[IT], q1[IT], p2[IT];
+#pragma unroll
+        for (int pp = 0; pp < G; ++pp)
+#pragma unroll
+            for (int sw = 0; sw < SW; ++sw) {
+                const int it = pp * SW + sw, r = sw * RPS + rsub;
+                const int m = pix(r >> 4, g + pp, r & 15);
+                ok[it] = m >= 0;
+                idx[it] = ok[it] ? (size_t)m * N + n : (size_t)0;
+                xr[it] = *reinterpret_cast<const bf16x8*>(a.ep.xref + idx[it]);
+                if (m1 != PA_LD_NONE) p1[it] = *reinterpret_cast<const bf16x8*>(a.add1.p + idx[it]);
+                if (m1 == PA_LD_LIN2) q1[it] = *reinterpret_cast<const bf16x8*>(a.add1.q + idx[it]);
+                if (m2 != PA_LD_NONE) p2[it] = *reinterpret_cast<const bf16x8*>(a.add2.p + idx[it]);
+            }
+        if (g == 0) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                es[j] = a.ep.scale[n + j]; et[j] = a.ep.shift[n + j];
+                if (m1 == PA_LD_LIN2) { ka[j] = a.add1.k0[n + j]; kb[j] = a.add1.k1[n + j]; kc[j] = a.add1.k2[n + j]; }
+            }
+        }
+#pragma unroll
+        for (int pp = 0; pp < G; ++pp) {
+            const int mi = g + pp;
+            if (mi) __syncthreads();                 // the previous pass has been read
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+                *reinterpret_cast<f32x4*>(T + wrow * BN + (((wslot0 + 8 * (ni >> 1) + (ni & 1)) ^ (wrow & 7)) << 2)) = acc[ni][mi];
+            __syncthreads();
+#pragma unroll
+            for (int sw = 0; sw < SW; ++sw) {
+                const int it = pp * SW + sw, r = sw * RPS + rsub;
+                if (!ok[it]) continue;
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(T + r * BN + (((2 * chunk) ^ (r & 7)) << 2));
+                const f32x4 v1 = *reinterpret_cast<const f32x4*>(T + r * BN + (((2 * chunk + 1) ^ (r & 7)) << 2));
+                bf16x8 o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float v = (j < 4 ? v0[j & 3] : v1[j & 3]);
+                    if (m1 == PA_LD_PLAIN) v += (float)p1[it][j];
+                    else if (m1 == PA_LD_LIN2) v += fmaf(ka[j], (float)p1[it][j], fmaf(kb[j], (float)q1[it][j], kc[j]));
+                    if (m2 != PA_LD_NONE) v += (float)p2[it][j];
+                    const float x = (float)xr[it][j];
+                    const float dz = (fmaf(es[j], x, et[j]) > 0.f) ? v : 0.f;
+                    o[j] = (bf16)dz;
+                    const float dzr = (float)o[j];
+                    s1[j] += dzr;
+                    s2[j] += dzr * x;
+                }
+                *reinterpret_cast<bf16x8*>(a.out + idx[it]) = o;
+            }
+        }
+    }
+    // ---- statistics row: lanes l, l + CPR, ... of a wave share a chunk, then the 4 waves through LDS
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+#pragma unroll
+        for (int o = CPR; o < 64; o <<= 1) { s1[j] += __shfl_xor(s1[j], o, 64); s2[j] += __shfl_xor(s2[j], o, 64); }
+    }
+    __syncthreads();                                 // T is dead
+    const int wave = tid >> 6;
+    if (lane < CPR) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { T[(wave * BN + chunk * 8 + j) * 2] = s1[j]; T[(wave * BN + chunk * 8 + j) * 2 + 1] = s2[j]; }
+    }
+    __syncthreads();
+    for (int c = tid; c < BN; c += 256) {
+        const float a1 = T[c * 2] + T[(BN + c) * 2] + T[(2 * BN + c) * 2] + T[(3 * BN + c) * 2];
+        const float a2 = T[c * 2 + 1] + T[(BN + c) * 2 + 1] + T[(2 * BN + c) * 2 + 1] + T[(3 * BN + c) * 2 + 1];
+        f32x2 v = {a1, a.ep.invstd[n0 + c] * (a2 - a.ep.mean[n0 + c] * a1)};
+        *reinterpret_cast<f32x2*>(a.ep.stats + ((size_t)stat_row * N + n0 + c) * 2) = v;
+    }
+}
+
+// forward epilogues through LDS (coalesced rows), backward epilogue direct; pix(wm, mi, p) as above
+template <int BN, int NI, int MI, bool BWD_LDS = true, class PixFn>
 __device__ __forceinline__ void pa_conv_epilogue_auto(const PaConvArgs& a, f32x4 (&acc)[NI][MI], int n0, int wm, int wn,
                                                       PixFn pix, float* T, int stat_row) {
     if (a.ep.mode == PA_OUT_BWD) {
-        const int p = threadIdx.x & 15;
-        pa_conv_epilogue<BN, NI, MI>(a, acc, n0, wm, wn, [&](int mi) { return pix(wm, mi, p); }, T, stat_row);
+        // supported operand modes of the LDS variant: addend 1 plain / LIN2, addend 2 plain, no bias (every data gradient of
+        // the networks); anything else takes the direct epilogue
+        const bool lds_ok = BWD_LDS && a.xcd < 2 && a.bias == nullptr && (a.add1.mode == PA_LD_NONE || a.add1.mode == PA_LD_PLAIN || a.add1.mode == PA_LD_LIN2) &&
+                            (a.add2.mode == PA_LD_NONE || a.add2.mode == PA_LD_PLAIN);
+        if (lds_ok) {
+            pa_conv_epilogue_lds_bwd<BN, NI, MI>(a, acc, n0, wm, wn, pix, T, stat_row);
+        } else {
+            const int p = threadIdx.x & 15;
+            pa_conv_epilogue<BN, NI, MI>(a, acc, n0, wm, wn, [&](int mi) { return pix(wm, mi, p); }, T, stat_row);
+        }
     } else {
         pa_conv_epilogue_lds<BN, NI, MI>(a, acc, n0, wm, wn, pix, T, stat_row);
     }

@@ -220,7 +220,11 @@ int pa_launch_stem_conv(const PaConvArgs& a, hipStream_t st, int* stat_rows) {
     return (int)hipGetLastError();
 }
 
-int pa_launch_conv(const PaConvArgs& a, hipStream_t st, int* stat_rows) {
+int pa_launch_conv(const PaConvArgs& a0, hipStream_t st, int* stat_rows) {
+    static int bwd_direct = -1;
+    if (bwd_direct < 0) bwd_direct = getenv("PA_EPI_BWD_DIRECT") ? 2 : 0;      // A/B: direct BatchNorm-backward epilogue
+    PaConvArgs a = a0;
+    a.xcd = bwd_direct;
     if ((a.taps != 1 && a.taps != 9) || a.Cin % 64 != 0 || a.Cout % 64 != 0 || a.Cin > 512) {
         pa_set_error_msg("pa_launch_conv: channel counts must be multiples of 64 and taps 1 or 9");
         return 1;
