@@ -241,7 +241,103 @@ __global__ void maxpool_fwd_kernel(PaOperand in, bf16* out, int B, int H, int W,
     }
 }
 
+
+// ---- streaming forward variants (row indexing, template modes, thread-fixed channel constants in registers, all loads of an
+// item issued first): OP 0 = 2x2 max pool of value(in), OP 1 = nearest-upsample(low) + value(skip); item = one low-resolution
+// pixel x 8 channels (4 high-resolution pixels).  Operand modes PLAIN / BNRELU.
+template <int OP, int MA, int MB>
+__global__ __launch_bounds__(256) void pool_up_fwd_s_kernel(PaOperand a, PaOperand b, bf16* __restrict__ out, int rows, int W, int C) {
+    // rows = B * H/2 (low-resolution rows); W = high-resolution width
+    const int CG = C / 8, Wl = W / 2;
+    const unsigned row_items = (unsigned)Wl * CG;
+    const int c = (threadIdx.x % CG) * 8;
+    float a0[8], a1[8], b0[8], b1[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        if (MA == PA_LD_BNRELU) { a0[j] = a.k0[c + j]; a1[j] = a.k1[c + j]; }
+        if (OP == 1 && MB == PA_LD_BNRELU) { b0[j] = b.k0[c + j]; b1[j] = b.k1[c + j]; }
+    }
+    const unsigned rows_per_it = row_items >= blockDim.x ? 1u : blockDim.x / row_items;
+    const unsigned rsub = row_items >= blockDim.x ? 0u : threadIdx.x / row_items;
+    const unsigned i0 = row_items >= blockDim.x ? threadIdx.x : threadIdx.x % row_items;
+    const bf16* __restrict__ pa = a.p;
+    const bf16* __restrict__ pb = b.p;
+    for (unsigned rb = blockIdx.x * rows_per_it; rb < (unsigned)rows; rb += gridDim.x * rows_per_it) {
+        const unsigned r = rb + rsub;
+        if (r >= (unsigned)rows) continue;
+        for (unsigned i = i0; i < row_items; i += blockDim.x) {
+            const unsigned xl = i / (unsigned)CG;
+            const unsigned top = ((2u * r) * (unsigned)W + 2u * xl) * (unsigned)C + (unsigned)c;
+            const unsigned wc = (unsigned)W * (unsigned)C;
+            const unsigned off[4] = {top, top + (unsigned)C, top + wc, top + wc + (unsigned)C};
+            const unsigned li = (r * (unsigned)Wl + xl) * (unsigned)C + (unsigned)c;
+            bf16x8 hi[4], lo;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) hi[k] = *reinterpret_cast<const bf16x8*>((OP == 0 ? pa : pb) + off[k]);
+            if (OP == 1) lo = *reinterpret_cast<const bf16x8*>(pa + li);
+            if (OP == 0) {
+                bf16x8 o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float m = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        float v = (float)hi[k][j];
+                        if (MA == PA_LD_BNRELU) v = fmaxf(fmaf(a0[j], v, a1[j]), 0.f);
+                        m = k == 0 ? v : fmaxf(m, v);
+                    }
+                    o[j] = (bf16)m;
+                }
+                *reinterpret_cast<bf16x8*>(out + li) = o;
+            } else {
+                float l[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float v = (float)lo[j];
+                    if (MA == PA_LD_BNRELU) v = fmaxf(fmaf(a0[j], v, a1[j]), 0.f);
+                    l[j] = v;
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    bf16x8 o;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        float v = (float)hi[k][j];
+                        if (MB == PA_LD_BNRELU) v = fmaxf(fmaf(b0[j], v, b1[j]), 0.f);
+                        o[j] = (bf16)(l[j] + v);
+                    }
+                    *reinterpret_cast<bf16x8*>(out + off[k]) = o;
+                }
+            }
+        }
+    }
+}
+
+// returns false when the configuration is not covered (caller uses the generic kernel)
+template <int OP>
+static bool launch_pool_up_fwd_s(const PaOperand& a, const PaOperand& b, bf16* out, int B, int H, int W, int C, hipStream_t st) {
+    static int old = -1;
+    if (old < 0) old = getenv("PA_ELTWISE_OLD") ? 1 : 0;
+    const int threads = 256;
+    const size_t row_items = (size_t)(W / 2) * (C / 8);
+    const bool ma = a.mode == PA_LD_PLAIN || a.mode == PA_LD_BNRELU, mb = OP == 0 || b.mode == PA_LD_PLAIN || b.mode == PA_LD_BNRELU;
+    if (old || !ma || !mb || C % 8 || H % 2 || W % 2 || threads % (C / 8) != 0 || !(row_items % threads == 0 || threads % row_items == 0) ||
+        (size_t)B * H * W * C >= ((size_t)1 << 31)) return false;
+    const int rows = B * (H / 2);
+    const size_t total = (size_t)rows * row_items;
+    int blocks = (int)((total + threads - 1) / threads);
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    const bool A = a.mode == PA_LD_BNRELU, Bm = OP == 1 && b.mode == PA_LD_BNRELU;
+    if (A && Bm) hipLaunchKernelGGL((pool_up_fwd_s_kernel<OP, PA_LD_BNRELU, PA_LD_BNRELU>), dim3(blocks), dim3(threads), 0, st, a, b, out, rows, W, C);
+    else if (A) hipLaunchKernelGGL((pool_up_fwd_s_kernel<OP, PA_LD_BNRELU, PA_LD_PLAIN>), dim3(blocks), dim3(threads), 0, st, a, b, out, rows, W, C);
+    else if (Bm) hipLaunchKernelGGL((pool_up_fwd_s_kernel<OP, PA_LD_PLAIN, PA_LD_BNRELU>), dim3(blocks), dim3(threads), 0, st, a, b, out, rows, W, C);
+    else hipLaunchKernelGGL((pool_up_fwd_s_kernel<OP, PA_LD_PLAIN, PA_LD_PLAIN>), dim3(blocks), dim3(threads), 0, st, a, b, out, rows, W, C);
+    return true;
+}
+
 int pa_launch_maxpool_fwd(const PaOperand& in, bf16* out, int B, int H, int W, int C, hipStream_t st) {
+    if (launch_pool_up_fwd_s<0>(in, in, out, B, H, W, C, st)) return (int)hipGetLastError();
     size_t total = (size_t)B * (H / 2) * (W / 2) * (C / 8);
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
@@ -449,6 +545,7 @@ __global__ void upadd_fwd_kernel(PaOperand low, PaOperand skip, bf16* out, int B
 }
 
 int pa_launch_upadd_fwd(const PaOperand& low, const PaOperand& skip, bf16* out, int B, int H, int W, int C, hipStream_t st) {
+    if (launch_pool_up_fwd_s<1>(low, skip, out, B, H, W, C, st)) return (int)hipGetLastError();
     size_t total = (size_t)B * H * W * (C / 8);
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
