@@ -225,13 +225,15 @@ __device__ __forceinline__ void pa_conv_epilogue_lds(const PaConvArgs& a, f32x4 
 // (2) a thread owns the same 8 channels for all its pixels, so the constants live in registers; (3) the second reduction
 // is accumulated as sum(dz * x) and turned into sum(dz * xhat) = invstd * (sum(dz*x) - mean * sum(dz)) once per
 // workgroup row, which removes mean / invstd from the per-element work.
-template <int BN, int NI, int MI, class PixFn>
+template <int BN, int NI, int MI, bool TAB, class PixFn>
 __device__ __forceinline__ void pa_conv_epilogue_lds_bwd(const PaConvArgs& a, f32x4 (&acc)[NI][MI], int n0, int wm, int wn,
-                                                         PixFn pix, float* T, int stat_row) {
+                                                         PixFn pix, float* T, int stat_row, float4* ctab = nullptr) {
+    // ctab (optional, 2 * BN float4 of LDS outside T): the per-channel constants live there instead of in 40 registers
+    // (entry j * CPR + chunk: conflict-free for the 16 chunks of a wave) -- for the kernels that run 3 workgroups per CU
     constexpr int CPR = BN / 8;
     constexpr int RPS = 256 / CPR;
     constexpr int SW = 32 / RPS;
-    constexpr int G = MI >= 2 ? 2 : 1;               // passes per operand request
+    constexpr int G = (MI >= 2 && !TAB) ? 2 : 1;    // passes per operand request (1 for the 168-register kernels)
     constexpr int IT = G * SW;
     const int tid = threadIdx.x, lane = tid & 63;
     const int N = a.Cout;
@@ -263,10 +265,18 @@ __device__ __forceinline__ void pa_conv_epilogue_lds_bwd(const PaConvArgs& a, f3
                 if (m2 != PA_LD_NONE) p2[it] = *reinterpret_cast<const bf16x8*>(a.add2.p + idx[it]);
             }
         if (g == 0) {
+            if (TAB) {
+                for (int i = tid; i < BN; i += 256) {
+                    const int e = (i & 7) * CPR + (i >> 3);
+                    ctab[e] = make_float4(a.ep.scale[n0 + i], a.ep.shift[n0 + i], 0.f, 0.f);
+                    ctab[BN + e] = m1 == PA_LD_LIN2 ? make_float4(a.add1.k0[n0 + i], a.add1.k1[n0 + i], a.add1.k2[n0 + i], 0.f) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }                                    // (visible after the first pass barrier below)
+            } else {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                es[j] = a.ep.scale[n + j]; et[j] = a.ep.shift[n + j];
-                if (m1 == PA_LD_LIN2) { ka[j] = a.add1.k0[n + j]; kb[j] = a.add1.k1[n + j]; kc[j] = a.add1.k2[n + j]; }
+                for (int j = 0; j < 8; ++j) {
+                    es[j] = a.ep.scale[n + j]; et[j] = a.ep.shift[n + j];
+                    if (m1 == PA_LD_LIN2) { ka[j] = a.add1.k0[n + j]; kb[j] = a.add1.k1[n + j]; kc[j] = a.add1.k2[n + j]; }
+                }
             }
         }
 #pragma unroll
@@ -287,11 +297,16 @@ __device__ __forceinline__ void pa_conv_epilogue_lds_bwd(const PaConvArgs& a, f3
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     float v = (j < 4 ? v0[j & 3] : v1[j & 3]);
+                    float ej = TAB ? 0.f : es[j], tj = TAB ? 0.f : et[j];
+                    if (TAB) { const float4 e = ctab[j * CPR + chunk]; ej = e.x; tj = e.y; }
                     if (m1 == PA_LD_PLAIN) v += (float)p1[it][j];
-                    else if (m1 == PA_LD_LIN2) v += fmaf(ka[j], (float)p1[it][j], fmaf(kb[j], (float)q1[it][j], kc[j]));
+                    else if (m1 == PA_LD_LIN2) {
+                        if (TAB) { const float4 k = ctab[BN + j * CPR + chunk]; v += fmaf(k.x, (float)p1[it][j], fmaf(k.y, (float)q1[it][j], k.z)); }
+                        else v += fmaf(ka[j], (float)p1[it][j], fmaf(kb[j], (float)q1[it][j], kc[j]));
+                    }
                     if (m2 != PA_LD_NONE) v += (float)p2[it][j];
                     const float x = (float)xr[it][j];
-                    const float dz = (fmaf(es[j], x, et[j]) > 0.f) ? v : 0.f;
+                    const float dz = (fmaf(ej, x, tj) > 0.f) ? v : 0.f;
                     o[j] = (bf16)dz;
                     const float dzr = (float)o[j];
                     s1[j] += dzr;
@@ -323,16 +338,16 @@ __device__ __forceinline__ void pa_conv_epilogue_lds_bwd(const PaConvArgs& a, f3
 }
 
 // forward epilogues through LDS (coalesced rows), backward epilogue direct; pix(wm, mi, p) as above
-template <int BN, int NI, int MI, bool BWD_LDS = true, class PixFn>
+template <int BN, int NI, int MI, bool BWD_LDS = true, bool TAB = false, class PixFn>
 __device__ __forceinline__ void pa_conv_epilogue_auto(const PaConvArgs& a, f32x4 (&acc)[NI][MI], int n0, int wm, int wn,
-                                                      PixFn pix, float* T, int stat_row) {
+                                                      PixFn pix, float* T, int stat_row, float4* ctab = nullptr) {
     if (a.ep.mode == PA_OUT_BWD) {
         // supported operand modes of the LDS variant: addend 1 plain / LIN2, addend 2 plain, no bias (every data gradient of
         // the networks); anything else takes the direct epilogue
         const bool lds_ok = BWD_LDS && a.xcd < 2 && a.bias == nullptr && (a.add1.mode == PA_LD_NONE || a.add1.mode == PA_LD_PLAIN || a.add1.mode == PA_LD_LIN2) &&
                             (a.add2.mode == PA_LD_NONE || a.add2.mode == PA_LD_PLAIN);
         if (lds_ok) {
-            pa_conv_epilogue_lds_bwd<BN, NI, MI>(a, acc, n0, wm, wn, pix, T, stat_row);
+            pa_conv_epilogue_lds_bwd<BN, NI, MI, TAB>(a, acc, n0, wm, wn, pix, T, stat_row, ctab);
         } else {
             const int p = threadIdx.x & 15;
             pa_conv_epilogue<BN, NI, MI>(a, acc, n0, wm, wn, [&](int mi) { return pix(wm, mi, p); }, T, stat_row);
