@@ -102,6 +102,8 @@ __global__ __launch_bounds__(256, (CIN == 128 && BM == 64) ? 3 : 2) void conv1x1
                 }
                 const int sw = CPP >= 16 ? (row & 15) : ((row >> 1) & 7);
                 *reinterpret_cast<bf16x8*>(As + row * CIN + ((chunk ^ sw) << 3)) = o;
+                if (LDMODE == PA_LD_LIN2 && a.dz_out && blockIdx.y == 0 && m0 + row < M)
+                    *reinterpret_cast<bf16x8*>(a.dz_out + (size_t)(m0 + row) * CIN + c) = o;
             }
         }
     }

@@ -11,6 +11,8 @@ struct PaConvArgs {
     PaEpilogue ep;
     bf16* out;           // [M][Cout]
     int B, H, W, Cin, Cout, taps;
+    bf16* dz_out;        // optional (1x1 row-tile kernel, LIN2 input): the transformed input tile is also stored here [M][Cin] --
+                         // later consumers of the same BatchNorm-backward gradient read ONE tensor instead of recomputing it from two
     int xcd;             // set by the launchers: workgroup i works on tile (i % 8) * (tiles / 8) + i / 8 (one contiguous range per XCD)
 };
 // stat_rows (optional) receives the number of partial-statistics rows the launch writes (= grid.x)

@@ -84,6 +84,8 @@ struct Residual {
     Act x1, x2, x3;          // raw conv outputs (x3 includes the shortcut)
     bf16* adout = nullptr;   // adapter(x)
     bf16* adgrad = nullptr;  // scratch for the adapter's data gradient
+    bf16* dz3 = nullptr;     // BatchNorm-backward gradient of x3, materialised by conv3's data gradient for its later consumers
+    bool dz3_valid = false;
     void declare(Net& n, const std::string& prefix, int cin, int cout, bool adapter);
     void layout(Net& n, Arena& a, int B, int H, int W, bool need_grad);
     int fwd(Net& n, const Act& in);
@@ -206,7 +208,7 @@ struct Net {
     int conv_fwd(ConvLayer& c, const PaOperand& in, int B, int H, int W, const PaOperand& add1, const PaOperand& add2,
                  bf16* out, BNLayer* bn_after);
     int conv_dgrad(ConvLayer& c, const PaOperand& dy, int B, int H, int W, const PaOperand& add1, const PaOperand& add2,
-                   const PaEpilogue& ep, bf16* out);
+                   const PaEpilogue& ep, bf16* out, bf16* dz_out = nullptr, bool* dz_done = nullptr);
     int conv_wgrad(ConvLayer& c, const PaOperand& dy, const PaOperand& x, int B, int H, int W);
 
     int prepare_weights();

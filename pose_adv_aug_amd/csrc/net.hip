@@ -150,6 +150,7 @@ void Residual::layout(Net& n, Arena& a, int B, int H, int W, bool need_grad) {
     x1 = n.new_act(a, B, H, W, mid, &b1, need_grad);
     x2 = n.new_act(a, B, H, W, mid, &b2, need_grad);
     x3 = n.new_act(a, B, H, W, cout, &b3, need_grad);
+    dz3 = need_grad ? a.get<bf16>(x3.numel()) : nullptr;
     if (has_adapter) {
         n.layout_conv(ad, a, M);
         adout = a.get<bf16>((size_t)M * cout);
@@ -344,10 +345,16 @@ int Net::conv_fwd(ConvLayer& c, const PaOperand& in, int B_, int H, int W, const
 }
 
 int Net::conv_dgrad(ConvLayer& c, const PaOperand& dy, int B_, int H, int W, const PaOperand& add1, const PaOperand& add2,
-                    const PaEpilogue& ep, bf16* out) {
+                    const PaEpilogue& ep, bf16* out, bf16* dz_out, bool* dz_done) {
     PaConvArgs a; memset(&a, 0, sizeof a);
     a.in = dy; a.w = c.wb; a.bias = nullptr; a.add1 = add1; a.add2 = add2; a.out = out; a.ep = ep;
     a.B = B_; a.H = H; a.W = W; a.Cin = c.pcout; a.Cout = c.pcin; a.taps = c.taps();
+    if (dz_done) *dz_done = false;
+    if (dz_out && dy.mode == PA_LD_LIN2) {         // only the 1x1 row-tile kernel stores its transformed input
+        static int off = -1;
+        if (off < 0) off = (getenv("PA_CONV1_OLD") || getenv("PA_NO_DZ3")) ? 1 : 0;
+        if (!off && pa_conv1x1_tile_supported(a)) { a.dz_out = dz_out; if (dz_done) *dz_done = true; }
+    }
     double wb, wf; conv_work(B_ * H * W, c.Cin, c.Cout, c.taps(), false, wb, wf);
     ProfEntry* pe = prof.begin(c.k == 3 ? PA_PROF_DGRAD3 : PA_PROF_DGRAD1, wb, wf, st);
     int rc = pa_launch_conv(a, st);
@@ -448,9 +455,13 @@ int Residual::fwd(Net& n, const Act& in) {
 // part that needs `extra`, the gradient arriving at the input from its other consumers)
 int Residual::bwd_a(Net& n, const Act& in) {
     const int B = in.B, H = in.H, W = in.W;
-    const PaOperand g3 = n.gradop(x3);
+    // conv3's data gradient goes first: its kernel also stores dz3 = BatchNorm-backward(x3.grad, x3.raw), and the weight
+    // gradients / the shortcut addend after it read that one tensor instead of recomputing it from two
+    PaOperand g3 = n.gradop(x3);
+    dz3_valid = false;
+    TRY(n.conv_dgrad(c3, g3, B, H, W, pa_none(), pa_none(), n.final_ep(x2), x2.grad, dz3, &dz3_valid));
+    if (dz3_valid) g3 = pa_plain(dz3);
     TRY(n.conv_wgrad(c3, g3, n.op(x2), B, H, W));
-    TRY(n.conv_dgrad(c3, g3, B, H, W, pa_none(), pa_none(), n.final_ep(x2), x2.grad));
     TRY(n.finish_grad(x2));
     const PaOperand g2 = n.gradop(x2);
     TRY(n.conv_wgrad(c2, g2, n.op(x1), B, H, W));
@@ -465,7 +476,7 @@ int Residual::bwd_a(Net& n, const Act& in) {
 
 int Residual::bwd_b(Net& n, const Act& in, const PaOperand& extra) {
     const int B = in.B, H = in.H, W = in.W;
-    const PaOperand g3 = n.gradop(x3), g1 = n.gradop(x1);
+    const PaOperand g3 = dz3_valid ? pa_plain(dz3) : n.gradop(x3), g1 = n.gradop(x1);
     if (has_adapter) {
         TRY(n.conv_dgrad(ad, g3, B, H, W, extra, pa_none(), ep_plain(), adgrad));
         TRY(n.conv_dgrad(c1, g1, B, H, W, pa_plain(adgrad), pa_none(), n.final_ep(in), in.grad));
