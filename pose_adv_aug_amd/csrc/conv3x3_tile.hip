@@ -138,6 +138,13 @@ __global__ __launch_bounds__(256, (TW == 16 ? (TH == 4 ? 3 : 2) : 1)) void conv3
                         for (int j = 0; j < 8; ++j) o[j] = (bf16)0.f;
                     }
                     *reinterpret_cast<bf16x8*>(halo + hp[u] * CIN + ((chunk ^ halo_sw<CPP>(hp[u])) << 3)) = o;
+                    if (LDMODE == PA_LD_LIN2 && a.dz_out && blockIdx.y == 0 && ok[u]) {       // interior pixels: this tile owns them
+                        const int im = IMG == 1 ? 0 : hp[u] / (PHh * PW);
+                        const int hr = hp[u] - im * (PHh * PW);
+                        const int hy = hr / PW, hx = hr - hy * PW;
+                        if (hy >= 1 && hy < PHh - 1 && hx >= 1 && hx < PW - 1)
+                            *reinterpret_cast<bf16x8*>(a.dz_out + (img + ((size_t)im * a.H + y0 + hy - 1) * a.W + x0 + hx - 1) * CIN + c) = o;
+                    }
                 }
             }
         }

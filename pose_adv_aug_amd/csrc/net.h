@@ -86,6 +86,7 @@ struct Residual {
     bf16* adgrad = nullptr;  // scratch for the adapter's data gradient
     bf16* dz3 = nullptr;     // BatchNorm-backward gradient of x3, materialised by conv3's data gradient for its later consumers
     bool dz3_valid = false;
+    bf16* dz2 = nullptr;     // the same for x2 (stored by conv2's data gradient, read by conv2's weight gradient)
     void declare(Net& n, const std::string& prefix, int cin, int cout, bool adapter);
     void layout(Net& n, Arena& a, int B, int H, int W, bool need_grad);
     int fwd(Net& n, const Act& in);

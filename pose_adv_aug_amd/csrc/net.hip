@@ -151,6 +151,7 @@ void Residual::layout(Net& n, Arena& a, int B, int H, int W, bool need_grad) {
     x2 = n.new_act(a, B, H, W, mid, &b2, need_grad);
     x3 = n.new_act(a, B, H, W, cout, &b3, need_grad);
     dz3 = need_grad ? a.get<bf16>(x3.numel()) : nullptr;
+    dz2 = need_grad ? a.get<bf16>(x2.numel()) : nullptr;
     if (has_adapter) {
         n.layout_conv(ad, a, M);
         adout = a.get<bf16>((size_t)M * cout);
@@ -353,7 +354,9 @@ int Net::conv_dgrad(ConvLayer& c, const PaOperand& dy, int B_, int H, int W, con
     if (dz_out && dy.mode == PA_LD_LIN2) {         // only the 1x1 row-tile kernel stores its transformed input
         static int off = -1;
         if (off < 0) off = (getenv("PA_CONV1_OLD") || getenv("PA_NO_DZ3")) ? 1 : 0;
-        if (!off && pa_conv1x1_tile_supported(a)) { a.dz_out = dz_out; if (dz_done) *dz_done = true; }
+        static int off3 = -1;
+        if (off3 < 0) off3 = (getenv("PA_CONV3_OLD") || getenv("PA_NO_DZ2")) ? 1 : 0;
+        if ((!off && a.taps == 1 && pa_conv1x1_tile_supported(a)) || (!off3 && a.taps == 9 && pa_conv3x3_tile_supported(a))) { a.dz_out = dz_out; if (dz_done) *dz_done = true; }
     }
     double wb, wf; conv_work(B_ * H * W, c.Cin, c.Cout, c.taps(), false, wb, wf);
     ProfEntry* pe = prof.begin(c.k == 3 ? PA_PROF_DGRAD3 : PA_PROF_DGRAD1, wb, wf, st);
@@ -463,9 +466,11 @@ int Residual::bwd_a(Net& n, const Act& in) {
     if (dz3_valid) g3 = pa_plain(dz3);
     TRY(n.conv_wgrad(c3, g3, n.op(x2), B, H, W));
     TRY(n.finish_grad(x2));
-    const PaOperand g2 = n.gradop(x2);
+    PaOperand g2 = n.gradop(x2);
+    bool dz2_valid = false;
+    TRY(n.conv_dgrad(c2, g2, B, H, W, pa_none(), pa_none(), n.final_ep(x1), x1.grad, dz2, &dz2_valid));
+    if (dz2_valid) g2 = pa_plain(dz2);
     TRY(n.conv_wgrad(c2, g2, n.op(x1), B, H, W));
-    TRY(n.conv_dgrad(c2, g2, B, H, W, pa_none(), pa_none(), n.final_ep(x1), x1.grad));
     TRY(n.finish_grad(x1));
     const PaOperand g1 = n.gradop(x1);
     TRY(n.conv_wgrad(c1, g1, n.op(in), B, H, W));
