@@ -702,9 +702,11 @@ int Net::backward_pose() {
             TRY(conv_dgrad(outc[i], gh, B, Hh, Hh, pa_none(), pa_none(), final_ep(lin_out[i]), lin_out[i].grad));
         }
         TRY(finish_grad(lin_out[i]));
-        const PaOperand gl = gradop(lin_out[i]);
+        PaOperand gl = gradop(lin_out[i]);
+        bool gl_stored = false;                  // lgrad_tmp[i] is free again: the data gradient stores dz there for the weight gradient
+        TRY(conv_dgrad(lin[i], gl, B, Hh, Hh, pa_none(), pa_none(), final_ep(post[i].x3), post[i].x3.grad, lgrad_tmp[i], &gl_stored));
+        if (gl_stored) gl = pa_plain(lgrad_tmp[i]);
         TRY(conv_wgrad(lin[i], gl, op(post[i].x3), B, Hh, Hh));
-        TRY(conv_dgrad(lin[i], gl, B, Hh, Hh, pa_none(), pa_none(), final_ep(post[i].x3), post[i].x3.grad));
         TRY(finish_grad(post[i].x3));
         TRY(post[i].bwd(*this, hg[i].out(), pa_none(), true));
         TRY(hg[i].bwd(*this, xin[i], inner ? pa_plain(xin[i + 1].grad) : pa_none()));
