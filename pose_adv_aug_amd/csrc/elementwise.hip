@@ -713,7 +713,7 @@ int pa_launch_rmsprop(float* p, const float* g, float* v, size_t n, float lr, fl
 //   wf[n][tap][c]            forward / wgrad layout, zero padded to pad_cout x pad_cin
 //   wb[c][taps-1-tap][n]     dgrad layout (transposed, taps flipped)
 // taps == 49 marks the 7x7 stem: wf[n][ky*32 + kx*4 + c] (K padded to 256), no wb.
-__global__ void weight_prep_kernel(const PaPrepJob* jobs) {
+__global__ __launch_bounds__(1024) void weight_prep_kernel(const PaPrepJob* jobs) {
     const PaPrepJob j = jobs[blockIdx.y];
     if (j.taps == 49) {
         const int total = j.pad_cout * 256;
@@ -726,32 +726,35 @@ __global__ void weight_prep_kernel(const PaPrepJob* jobs) {
         }
         return;
     }
-    const int per = j.pad_cout * j.pad_cin * j.taps;
-    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < 2 * per; e += gridDim.x * blockDim.x) {
-        if (e < per) {
-            int n = e / (j.taps * j.pad_cin);
-            int r = e - n * j.taps * j.pad_cin;
-            int tap = r / j.pad_cin, c = r - tap * j.pad_cin;
-            float v = (n < j.Cout && c < j.Cin) ? j.w[((size_t)n * j.Cin + c) * j.taps + tap] : 0.f;
-            j.wf[e] = (bf16)v;
-        } else if (j.wb) {
-            int f = e - per;
-            int c = f / (j.taps * j.pad_cout);
-            int r = f - c * j.taps * j.pad_cout;
-            int tapb = r / j.pad_cout, n = r - tapb * j.pad_cout;
-            int tap = j.taps - 1 - tapb;
-            float v = (n < j.Cout && c < j.Cin) ? j.w[((size_t)n * j.Cin + c) * j.taps + tap] : 0.f;
-            j.wb[f] = (bf16)v;
+    // 32 x 32 (n, c) tiles: the fp32 source is read once, in contiguous runs (taps floats per thread); wf is written along c,
+    // wb along n through an LDS transpose (read element-wise per output the strided source fetched 10-20x its bytes)
+    __shared__ bf16 tile[9][32][33];
+    const int tn = threadIdx.x >> 5, tc = threadIdx.x & 31;
+    const int tiles_c = j.pad_cin / 32, ntiles = (j.pad_cout / 32) * tiles_c;
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int n0 = (t / tiles_c) * 32, c0 = (t % tiles_c) * 32;
+        const int n = n0 + tn, c = c0 + tc;
+        const bool ok = n < j.Cout && c < j.Cin;
+        const float* src = j.w + ((size_t)n * j.Cin + c) * j.taps;
+        for (int tap = 0; tap < j.taps; ++tap) {
+            const bf16 v = (bf16)(ok ? src[tap] : 0.f);
+            j.wf[((size_t)n * j.taps + tap) * j.pad_cin + c] = v;
+            tile[tap][tn][tc] = v;
         }
+        __syncthreads();
+        if (j.wb) {
+            // thread (tn, tc) now writes channel c0 + tn, output channel n0 + tc
+            for (int tap = 0; tap < j.taps; ++tap)
+                j.wb[((size_t)(c0 + tn) * j.taps + (j.taps - 1 - tap)) * j.pad_cout + n0 + tc] = tile[tap][tc][tn];
+        }
+        __syncthreads();
     }
 }
 
 int pa_launch_weight_prep(const PaPrepJob* jobs_dev, int njobs, int max_elems, hipStream_t st) {
     if (njobs <= 0) return 0;
-    int bx = (2 * max_elems + 255) / 256;
-    if (bx > 64) bx = 64;
-    if (bx < 1) bx = 1;
-    hipLaunchKernelGGL(weight_prep_kernel, dim3(bx, njobs), dim3(256), 0, st, jobs_dev);
+    (void)max_elems;
+    hipLaunchKernelGGL(weight_prep_kernel, dim3(32, njobs), dim3(1024), 0, st, jobs_dev);
     return (int)hipGetLastError();
 }
 
