@@ -452,11 +452,11 @@ int pa_hg_accuracy(pa_net* net, int stack, const int32_t* idxs, int nidx, float*
     Net& n = net->n;
     const int H = n.res / 4, J = 16, B = n.B;
     float* tgt = scratch;                         // [B][16][H][H]
-    float* pp = tgt + (size_t)B * J * H * H;      // [B][16][2]
-    float* gp = pp + (size_t)B * J * 2;
+    float* gp = tgt + (size_t)B * J * H * H + (size_t)B * J * 2;      // [B][16][2]
     float* norm = gp + (size_t)B * J * 2;         // [B]
+    const float* pp = nullptr;                    // [B][16][2] arg-max of the heat maps (shared with pa_hg_pckh)
+    TRY(n.heat_argmax(stack, &pp));
     TRY(pa_launch_gaussian_heatmap(n.pts_dev, tgt, B, J, H, H, n.st));
-    TRY(pa_launch_argmax(n.heat[stack], (long)H * H * 16, 1, 16, B, J, H, H, pp, nullptr, n.st));
     TRY(pa_launch_argmax(tgt, (long)J * H * H, (long)H * H, 1, B, J, H, H, gp, nullptr, n.st));
     TRY(pa_launch_fill(norm, (float)H / 10.f, B, n.st));
     TRY(pa_launch_pck(pp, gp, norm, 1.f, idxs, nidx, 0.5f, nullptr, B, J, acc, nullptr, nullptr, n.st));
@@ -471,11 +471,11 @@ int pa_hg_pckh(pa_net* net, int stack, const float* center, const float* scale, 
     g_err[0] = 0;
     Net& n = net->n;
     const int H = n.res / 4, J = 16, B = n.B;
-    float* pp = scratch;                          // [B][16][2] arg-max
-    float* fp = pp + (size_t)B * J * 2;           // [B][16][2] back-projected predictions
+    const float* pp = nullptr;                    // [B][16][2] arg-max (computed once per forward, shared with pa_hg_accuracy)
+    TRY(n.heat_argmax(stack, &pp));
+    float* fp = scratch + (size_t)B * J * 2;      // [B][16][2] back-projected predictions
     float* vis = fp + (size_t)B * J * 2;          // [B][16][2] arg-max of the augmented target
     float* tgt = vis + (size_t)B * J * 2;         // [B][16][H][H] (only when person != NULL)
-    TRY(pa_launch_argmax(n.heat[stack], (long)H * H * 16, 1, 16, B, J, H, H, pp, nullptr, n.st));
     TRY(pa_launch_final_preds(n.heat[stack], (long)H * H * 16, 1, 16, pp, center, scale, rot, B, J, H, H, fp, n.st));
     if (person) {
         TRY(pa_launch_gaussian_heatmap(n.pts_dev, tgt, B, J, H, H, n.st));

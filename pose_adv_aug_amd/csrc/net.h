@@ -183,6 +183,9 @@ struct Net {
     std::vector<Act> lin_out, xin;                 // xin[i] = input of stack i
     std::vector<float*> heat; std::vector<bf16*> heat64, dheat64, dheat_in, forth_tmp, lgrad_tmp;
     double* pts_dev = nullptr;                     // [B][16][2] heat-map coords (caller provided per step)
+    std::vector<float*> heat_peak;                 // [B][16][2] arg-max of heat[i], computed once per forward on demand (accuracy AND PCKh use it)
+    std::vector<char> heat_peak_valid;
+    int heat_argmax(int stack, const float** out); // launches the arg-max unless this forward's result exists
     // occlusion (dropout) branch, reference :172-190: [B][16] cell masks (caller-owned device memory) applied to the neck and the
     // four skip tensors of every stack in forward_pose / backward_pose; nullptr = off
     const float* drop_mask = nullptr;

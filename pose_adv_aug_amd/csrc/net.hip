@@ -199,7 +199,7 @@ size_t Net::layout_all(char* base) {
     pool0 = new_act(a, B, H4, H4, 128, nullptr, true);
     res2.layout(*this, a, B, H4, H4, true);
     res3.layout(*this, a, B, H4, H4, true);
-    lin_out.resize(stacks); xin.resize(stacks); heat.resize(stacks); heat64.resize(stacks); dheat64.resize(stacks);
+    lin_out.resize(stacks); xin.resize(stacks); heat.resize(stacks); heat_peak.resize(stacks); heat_peak_valid.assign(stacks, 0); heat64.resize(stacks); dheat64.resize(stacks);
     dheat_in.resize(stacks); forth_tmp.resize(stacks); lgrad_tmp.resize(stacks);
     const int M = B * H4 * H4;
     for (int i = 0; i < stacks; ++i) {
@@ -209,6 +209,7 @@ size_t Net::layout_all(char* base) {
         lin_out[i] = new_act(a, B, H4, H4, chan, &lin_bn[i], true);
         layout_conv(outc[i], a, M);
         heat[i] = a.get<float>((size_t)M * 16);
+        heat_peak[i] = a.get<float>((size_t)B * 16 * 2);
         heat64[i] = a.get<bf16>((size_t)M * 64);        // channels 16..63 stay zero (workspace is zero-filled once)
         dheat64[i] = a.get<bf16>((size_t)M * 64);
         dheat_in[i] = a.get<bf16>((size_t)M * 64);
@@ -647,8 +648,19 @@ int Net::begin_step() {
 }
 
 // reference :282-342 (stem :283-289, stacks :292-334) + loss of stack-hg.py:156-159
+int Net::heat_argmax(int stack, const float** out) {
+    const int H = res / 4;
+    if (!heat_peak_valid[stack]) {
+        TRY(pa_launch_argmax(heat[stack], (long)H * H * 16, 1, 16, B, 16, H, H, heat_peak[stack], nullptr, st));
+        heat_peak_valid[stack] = 1;
+    }
+    *out = heat_peak[stack];
+    return 0;
+}
+
 int Net::forward_pose(const float* img_nchw, const bf16* img4_in, const double* pts, bool train, float* loss_out_dev) {
     train_bn = train;
+    heat_peak_valid.assign(stacks, 0);
     TRY(ensure_streams());
     TRY(begin_step());
     if (!train) TRY(pa_launch_bn_eval(bneval_jobs, n_bneval, eps, st));
