@@ -116,6 +116,38 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* bsta
     if (dbeta) dbeta[c] = S1;
 }
 
+// two BatchNorm-backward finalizes in one launch (blockIdx.y picks the layer): the upsample-add backward feeds two layers at once
+struct BwdFinArgs { const float* bstats; int rows; const float* scale; const float* mean; const float* invstd; float *kA, *kB, *kC, *dgamma, *dbeta; int C; float count; };
+__global__ __launch_bounds__(1024) void bn_bwd_finalize2_kernel(BwdFinArgs a0, BwdFinArgs a1) {
+    const BwdFinArgs& a = blockIdx.y == 0 ? a0 : a1;
+    __shared__ float sums[FC][2];
+    const int c0 = blockIdx.x * FC;
+    if (c0 >= a.C) return;
+    reduce_partial_rows(a.bstats, a.rows, a.C, c0, sums);
+    if (threadIdx.x >= FC) return;
+    const int c = c0 + threadIdx.x;
+    if (c >= a.C) return;
+    float S1 = sums[threadIdx.x][0], S2 = sums[threadIdx.x][1];
+    float s = a.scale[c], is = a.invstd[c], mu = a.mean[c];
+    a.kA[c] = s;
+    float b = -s * is * S2 / a.count;
+    a.kB[c] = b;
+    a.kC[c] = -s * S1 / a.count - b * mu;
+    if (a.dgamma) a.dgamma[c] = S2;
+    if (a.dbeta) a.dbeta[c] = S1;
+}
+
+int pa_launch_bn_bwd_finalize2(const float* bs0, int rows0, const float* sc0, const float* mu0, const float* is0, float* kA0, float* kB0, float* kC0,
+                               float* dg0, float* db0, int C0, float cnt0,
+                               const float* bs1, int rows1, const float* sc1, const float* mu1, const float* is1, float* kA1, float* kB1, float* kC1,
+                               float* dg1, float* db1, int C1, float cnt1, hipStream_t st) {
+    BwdFinArgs a0 = {bs0, rows0, sc0, mu0, is0, kA0, kB0, kC0, dg0, db0, C0, cnt0};
+    BwdFinArgs a1 = {bs1, rows1, sc1, mu1, is1, kA1, kB1, kC1, dg1, db1, C1, cnt1};
+    const int cm = C0 > C1 ? C0 : C1;
+    hipLaunchKernelGGL(bn_bwd_finalize2_kernel, dim3((cm + FC - 1) / FC, 2), dim3(1024), 0, st, a0, a1);
+    return (int)hipGetLastError();
+}
+
 int pa_launch_bn_bwd_finalize(const float* bstats, int rows, const float* scale, const float* mean, const float* invstd,
                               float* kA, float* kB, float* kC, float* dgamma, float* dbeta, int C, float count,
                               hipStream_t st) {

@@ -61,6 +61,10 @@ int pa_launch_bn_finalize(const float* stats, int rows, const float* gamma, cons
 struct PaBnEvalJob { const float* gamma; const float* beta; const float* rmean; const float* rvar; float* scale; float* shift; int C; };
 int pa_launch_bn_eval(const PaBnEvalJob* jobs_dev, int njobs, float eps, hipStream_t st);
 // backward: partial rows bstats[rows][C][2] (sum dz, sum dz*xhat) -> LIN2 coefficients (A,B,C), dgamma, dbeta
+int pa_launch_bn_bwd_finalize2(const float* bs0, int rows0, const float* sc0, const float* mu0, const float* is0, float* kA0, float* kB0, float* kC0,
+                               float* dg0, float* db0, int C0, float cnt0,
+                               const float* bs1, int rows1, const float* sc1, const float* mu1, const float* is1, float* kA1, float* kB1, float* kC1,
+                               float* dg1, float* db1, int C1, float cnt1, hipStream_t st);
 int pa_launch_bn_bwd_finalize(const float* bstats, int rows, const float* scale, const float* mean, const float* invstd,
                               float* kA, float* kB, float* kC, float* dgamma, float* dbeta, int C, float count,
                               hipStream_t st);

@@ -209,6 +209,7 @@ struct Net {
     PaOperand gradop(const Act& a) const;           // gradient w.r.t. the raw tensor (LIN2 or PLAIN)
     PaEpilogue final_ep(const Act& a) const;        // epilogue that finishes a gradient for `a`
     int finish_grad(const Act& a);                  // BatchNorm backward finalize (if pending BN)
+    int finish_grad2(const Act& a, const Act& b);   // two of them in one launch
     int conv_fwd(ConvLayer& c, const PaOperand& in, int B, int H, int W, const PaOperand& add1, const PaOperand& add2,
                  bf16* out, BNLayer* bn_after);
     int conv_dgrad(ConvLayer& c, const PaOperand& dy, int B, int H, int W, const PaOperand& add1, const PaOperand& add2,

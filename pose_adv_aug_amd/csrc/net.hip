@@ -326,6 +326,15 @@ int Net::finish_grad(const Act& a) {
                                      grads + b->p_beta, b->C, (float)a.M(), st);
 }
 
+int Net::finish_grad2(const Act& a, const Act& b) {
+    if (!a.bn || !b.bn) { TRY(finish_grad(a)); return finish_grad(b); }
+    BNLayer *x = a.bn, *y = b.bn;
+    return pa_launch_bn_bwd_finalize2(x->bstats, x->bstat_rows, x->scale, x->mean, x->invstd, x->kA, x->kB, x->kC, grads + x->p_gamma, grads + x->p_beta,
+                                      x->C, (float)a.M(),
+                                      y->bstats, y->bstat_rows, y->scale, y->mean, y->invstd, y->kA, y->kB, y->kC, grads + y->p_gamma, grads + y->p_beta,
+                                      y->C, (float)b.M(), st);
+}
+
 int Net::conv_fwd(ConvLayer& c, const PaOperand& in, int B_, int H, int W, const PaOperand& add1, const PaOperand& add2,
                   bf16* out, BNLayer* bn_after) {
     PaConvArgs a; memset(&a, 0, sizeof a);
@@ -558,8 +567,7 @@ int Hourglass::bwd(Net& n, const Act& in, const PaOperand& extra0) {
             TRY(pa_launch_upadd_bwd(m.grad, n.final_ep(up[k].x3), up[k].x3.grad, n.final_ep(skip[k].x3), skip[k].x3.grad,
                                     m.B, m.H, m.W, m.C, n.st));
         }
-        TRY(n.finish_grad(up[k].x3));
-        TRY(n.finish_grad(skip[k].x3));
+        TRY(n.finish_grad2(up[k].x3, skip[k].x3));
         if (n.forks(k)) {          // parameter / inner gradients of the skip block next to the deeper levels
             const Act& x = (k == 0) ? in : down[k - 1].x3;
             TRY(n.fork_to(k));
