@@ -242,7 +242,7 @@ class HourglassNet(_HipModule):
         h = self._net(B)
         self._last_B = B
         p = pts.to(torch.float64).contiguous() if pts is not None else None
-        losses = torch.zeros(self.num_stacks, dtype=torch.float32, device=self.flat_params.device) if pts is not None else None
+        losses = torch.empty(self.num_stacks, dtype=torch.float32, device=self.flat_params.device) if pts is not None else None   # (fully overwritten)
         keep = self._set_masks(h, dropout_masks)
         try:
             check(lib().pa_hg_forward(h, ptr(x.contiguous().float()) if x is not None else None, ptr(img4), ptr(p),
@@ -274,7 +274,7 @@ class HourglassNet(_HipModule):
         h = self._net(B)
         self._last_B = B
         p = pts.to(torch.float64).contiguous()
-        losses = torch.zeros(self.num_stacks, dtype=torch.float32, device=self.flat_params.device)
+        losses = torch.empty(self.num_stacks, dtype=torch.float32, device=self.flat_params.device)      # the engine copies every entry
         keep = self._set_masks(h, dropout_masks)
         try:
             check(lib().pa_hg_forward(h, ptr(x.contiguous().float()) if x is not None else None, ptr(img4), ptr(p),
@@ -303,7 +303,7 @@ class HourglassNet(_HipModule):
         ix = cache.get(key)
         if ix is None:
             ix = cache[key] = torch.as_tensor(key, dtype=torch.int32, device=dev)
-        acc = torch.zeros(len(idxs) + 1, dtype=torch.float32, device=dev)
+        acc = torch.empty(len(idxs) + 1, dtype=torch.float32, device=dev)          # pck_kernel writes every entry
         check(lib().pa_hg_accuracy(h, stack, ptr(ix), len(idxs), ptr(acc), ptr(scratch)), 'pa_hg_accuracy')
         return acc
 
@@ -320,8 +320,8 @@ class HourglassNet(_HipModule):
         if not hasattr(self, '_pckh_idx'):
             self._pckh_idx = torch.as_tensor(PCKH_JOINTS, dtype=torch.int32, device=dev)
         scratch = torch.empty(6 * B * 16 + (B * 16 * Hh * Hh if per_person else 0) + 16, dtype=torch.float32, device=dev)
-        acc = torch.zeros(len(PCKH_JOINTS) + 1, dtype=torch.float32, device=dev)
-        person = torch.zeros(B, dtype=torch.float32, device=dev) if per_person else None
+        acc = torch.empty(len(PCKH_JOINTS) + 1, dtype=torch.float32, device=dev)
+        person = torch.empty(B, dtype=torch.float32, device=dev) if per_person else None
         c = center.float().contiguous(); s = scale.float().contiguous(); r = rot.float().contiguous()
         g = grnd_pts.float().contiguous(); nm = normalizers.float().contiguous()
         check(lib().pa_hg_pckh(h, stack, ptr(c), ptr(s), ptr(r), ptr(g), ptr(nm), ptr(self._pckh_idx), len(PCKH_JOINTS),
