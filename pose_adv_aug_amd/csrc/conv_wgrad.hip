@@ -279,6 +279,7 @@ int pa_launch_stem_wgrad(const PaWgradArgs& a, hipStream_t st) {
         pa_set_error_msg("pa_launch_stem_wgrad: bad arguments");
         return 1;
     }
+    { const int rc = pa_launch_stem_wgrad_tile(a, st); if (rc >= 0) return rc; }
     dim3 grid(a.splits, 2, 1);
     if (a.dy.mode == PA_LD_LIN2)
         hipLaunchKernelGGL((conv_wgrad_kernel<64, 128, PA_LD_LIN2, PA_LD_PLAIN, 1, true>), grid, dim3(256), 0, st, a);

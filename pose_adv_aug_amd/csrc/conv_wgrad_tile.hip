@@ -20,12 +20,13 @@
 #include "kernels.h"
 #include <stdlib.h>
 
+#define PA_WG_STEM 3          // QMODE of the stem: x is the 4-channel image, gathered as 7x7/2 patches (K = 256)
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 
 template <int CH>
 __device__ __forceinline__ int wg_sw(int p) {
-    return CH == 128 ? ((p & 3) | ((p >> 1) & 4)) : (((p >> 1) & 1) | ((p >> 2) & 2));
+    return CH >= 128 ? ((p & 3) | ((p >> 1) & 4)) : (((p >> 1) & 1) | ((p >> 2) & 2));
 }
 
 // fragment: lane l receives 8 consecutive pixels (p0 .. p0+7, p0 = base + 8*(l>>4)) of channel 16*gran + (l&15)
@@ -161,6 +162,26 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile_kernel(PaWgradArgs a, int n
                     ok[u] = hp < HP && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
                     m = (b * a.H + y) * a.W + x;
                 } else { m = tile * 128 + hp; ok[u] = m < M; }
+                if (QMODE == PA_WG_STEM) {
+                    // 7x7 stride-2 stem: the 'channels' are the 256 patch elements ky*32 + kx*4 + c of the 4-channel image; one
+                    // 16-byte chunk = input pixels (2x + 2q - 3, +1) of input row 2y + ky - 3; a.H / a.W are the OUTPUT dims
+                    const int chunk = c0 / 8 + cchunk, ky = chunk >> 2, q = chunk & 3;
+                    const int HWo = a.H * a.W, Hin = 2 * a.H, Win = 2 * a.W;
+                    const int mm = ok[u] ? m : 0;
+                    const int bb = mm / HWo, rem = mm - bb * HWo, y = rem / a.W, x = rem - y * a.W;
+                    const int yi = 2 * y + ky - 3, xi = 2 * x + 2 * q - 3;
+                    const bool rowok = ok[u] && ky < 7 && (unsigned)yi < (unsigned)Hin;
+                    const bool lok = rowok && (unsigned)xi < (unsigned)Win, hok = rowok && (unsigned)(xi + 1) < (unsigned)Win;
+                    const bf16* rowp = a.x.p + ((size_t)bb * Hin + (rowok ? yi : 0)) * Win * 4;
+                    bf16x4 lo = *reinterpret_cast<const bf16x4*>(rowp + (size_t)(lok ? xi : 0) * 4);          // clamped, unconditional
+                    bf16x4 hi = *reinterpret_cast<const bf16x4*>(rowp + (size_t)(hok ? xi + 1 : 0) * 4);
+                    const bf16x4 z = {(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
+                    if (!lok) lo = z;
+                    if (!hok) hi = z;
+                    rx[u] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    ok[u] = true;              // (zero padding already applied)
+                    continue;
+                }
                 const size_t idx = ok[u] ? (size_t)m * a.Cin + c0 + cchunk * 8 : 0;
                 rx[u] = *reinterpret_cast<const bf16x8*>(a.x.p + idx);
             }
@@ -309,6 +330,18 @@ static void launch_wt_modes(const PaWgradArgs& a, dim3 grid, int ntiles, hipStre
     else if (lin2) hipLaunchKernelGGL((wgrad_tile_kernel<TAPS, NF, CF, WNW, PA_LD_LIN2, PA_LD_PLAIN, DB>), grid, dim3(256), 0, st, a, ntiles);
     else if (bnrelu) hipLaunchKernelGGL((wgrad_tile_kernel<TAPS, NF, CF, WNW, PA_LD_PLAIN, PA_LD_BNRELU, DB>), grid, dim3(256), 0, st, a, ntiles);
     else hipLaunchKernelGGL((wgrad_tile_kernel<TAPS, NF, CF, WNW, PA_LD_PLAIN, PA_LD_PLAIN, DB>), grid, dim3(256), 0, st, a, ntiles);
+}
+
+// 7x7/2 stem weight gradient on the tile kernel: NB = 64 output channels x CB = 256 patch elements per workgroup, dy read once
+int pa_launch_stem_wgrad_tile(const PaWgradArgs& a, hipStream_t st) {
+    static int off = -1;
+    if (off < 0) off = (getenv("PA_WGRAD_OLD") || getenv("PA_STEM_WGRAD_OLD")) ? 1 : 0;
+    const int M = a.B * a.H * a.W, ntiles = (M + 127) / 128;
+    if (off || a.Cin != 256 || a.Cout != 64 || a.splits > ntiles) return -1;
+    dim3 grid(a.splits, 1, 1);
+    if (a.dy.mode == PA_LD_LIN2) hipLaunchKernelGGL((wgrad_tile_kernel<1, 2, 8, 2, PA_LD_LIN2, PA_WG_STEM, false>), grid, dim3(256), 0, st, a, ntiles);
+    else hipLaunchKernelGGL((wgrad_tile_kernel<1, 2, 8, 2, PA_LD_PLAIN, PA_WG_STEM, false>), grid, dim3(256), 0, st, a, ntiles);
+    return (int)hipGetLastError();
 }
 
 // returns -1 when the shape is not handled here (caller falls back to conv_wgrad.hip)

@@ -41,6 +41,7 @@ int pa_launch_wgrad(const PaWgradArgs& a, hipStream_t st);
 int pa_wgrad_splits(int M, int H, int W, int Cin, int Cout, int taps);
 // tile kernels (conv_wgrad_tile.hip): 0 / -1 = shape not handled there
 int pa_wgrad_tile_splits(int B, int H, int W, int Cin, int Cout, int taps);
+int pa_launch_stem_wgrad_tile(const PaWgradArgs& a, hipStream_t st);   // -1: not handled
 int pa_launch_wgrad_tile(const PaWgradArgs& a, hipStream_t st);
 
 // reduce partial slabs into the fp32 gradient in PyTorch layout  dst[n][c][tap]  (real_cin/real_cout
