@@ -110,6 +110,11 @@ void Net::layout_conv(ConvLayer& c, Arena& a, int M, int H, int W) {
     c.wf = a.get<bf16>(wn);
     c.wb = (c.k == 7) ? nullptr : a.get<bf16>(wn);
     c.splits = c.k == 7 ? pa_wgrad_splits(M, 0, 0, c.pcin, c.pcout, 1) : pa_wgrad_splits(M, H, W, c.pcin, c.pcout, c.taps());
+    if (c.k == 7) {                              // stem: 64 KB slabs, so two workgroups per CU (their load / MFMA phases overlap)
+        static int ss = -1;
+        if (ss < 0) { const char* e = getenv("PA_STEM_SPLITS"); ss = e ? atoi(e) : 512; }       // 6.96 vs 7.00 ms (256)
+        if (ss > 0 && ss <= (M + 127) / 128) c.splits = ss;
+    }
     c.part_floats = (size_t)c.splits * wn;
     c.db_floats = c.has_bn_after ? 0 : (size_t)c.splits * c.pcout;
     if (immediate_reduce) {                   // shared slab: remember the largest request, bind after the layout pass
