@@ -118,7 +118,7 @@ struct ResidualOp {
 };
 
 size_t pa_residual_workspace_bytes(int B, int H, int W, int C) {
-    ResidualOp op; op.n.is_agent = true; op.r.declare(op.n, "", C, C, false);
+    ResidualOp op; op.n.is_agent = true; op.n.B = B; op.r.declare(op.n, "", C, C, false);      // (same state as pa_residual_fwd_bwd: the layout depends on it)
     return op.build(B, H, W, C, nullptr);
 }
 

@@ -306,7 +306,9 @@ static bool wg_tile_cfg(int B, int H, int W, int Cin, int Cout, int taps, WgTile
     } else if (taps == 1) {
         if (Cin % 64 || Cout % 64) return false;
         c.nb = Cout % 128 == 0 ? 128 : 64; c.cb = Cin % 128 == 0 ? 128 : 64; c.ntiles = (M + 127) / 128;
-        if (c.ntiles < 96) return false;
+        static int min1 = -1;
+        if (min1 < 0) min1 = getenv("PA_WGRAD_MIN1") ? atoi(getenv("PA_WGRAD_MIN1")) : 3;      // also the 16x16 ... 4x4 levels: 6.90 vs 6.97 ms (96)
+        if (c.ntiles < min1) return false;
     } else return false;
     const int types = (Cout / c.nb) * (Cin / c.cb);
     int s = (taps == 9 ? target9 : target1) / types;

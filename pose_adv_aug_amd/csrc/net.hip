@@ -150,7 +150,7 @@ Act Net::new_act(Arena& a, int B_, int H, int W, int C, BNLayer* bn, bool need_g
 
 void Residual::layout(Net& n, Arena& a, int B, int H, int W, bool need_grad) {
     const int M = B * H * W, mid = cout / 2;
-    n.layout_conv(c1, a, M); n.layout_conv(c2, a, M); n.layout_conv(c3, a, M);
+    n.layout_conv(c1, a, M, H, W); n.layout_conv(c2, a, M, H, W); n.layout_conv(c3, a, M, H, W);      // explicit map size: the split counts depend on it
     n.layout_bn(b1, a, M); n.layout_bn(b2, a, M); n.layout_bn(b3, a, M);
     x1 = n.new_act(a, B, H, W, mid, &b1, need_grad);
     x2 = n.new_act(a, B, H, W, mid, &b2, need_grad);
@@ -158,7 +158,7 @@ void Residual::layout(Net& n, Arena& a, int B, int H, int W, bool need_grad) {
     dz3 = need_grad ? a.get<bf16>(x3.numel()) : nullptr;
     dz2 = need_grad ? a.get<bf16>(x2.numel()) : nullptr;
     if (has_adapter) {
-        n.layout_conv(ad, a, M);
+        n.layout_conv(ad, a, M, H, W);
         adout = a.get<bf16>((size_t)M * cout);
         adgrad = need_grad ? a.get<bf16>((size_t)M * cin) : nullptr;
     }
@@ -210,9 +210,9 @@ size_t Net::layout_all(char* base) {
     for (int i = 0; i < stacks; ++i) {
         hg[i].layout(*this, a, B, H4, H4, true);
         post[i].layout(*this, a, B, H4, H4, true);
-        layout_conv(lin[i], a, M); layout_bn(lin_bn[i], a, M);
+        layout_conv(lin[i], a, M, H4, H4); layout_bn(lin_bn[i], a, M);
         lin_out[i] = new_act(a, B, H4, H4, chan, &lin_bn[i], true);
-        layout_conv(outc[i], a, M);
+        layout_conv(outc[i], a, M, H4, H4);
         heat[i] = a.get<float>((size_t)M * 16);
         heat_peak[i] = a.get<float>((size_t)B * 16 * 2);
         heat64[i] = a.get<bf16>((size_t)M * 64);        // channels 16..63 stay zero (workspace is zero-filled once)
@@ -220,7 +220,7 @@ size_t Net::layout_all(char* base) {
         dheat_in[i] = a.get<bf16>((size_t)M * 64);
         lgrad_tmp[i] = a.get<bf16>((size_t)M * chan);
         if (i + 1 < stacks) {
-            layout_conv(forth[i], a, M); layout_conv(inc[i], a, M);
+            layout_conv(forth[i], a, M, H4, H4); layout_conv(inc[i], a, M, H4, H4);
             forth_tmp[i] = a.get<bf16>((size_t)M * chan);
         }
         if (i == 0) xin[0] = res3.x3;

@@ -250,3 +250,26 @@ def test_training_is_bitwise_reproducible_across_runs_and_stream_modes():
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]), 'run-to-run mismatch (race?)'
     assert torch.equal(a[0], c[0]) and torch.equal(a[1], c[1]), 'side streams change the result (missing dependency?)'
     assert bool(torch.isfinite(a[0]).all())
+
+
+@pytest.mark.parametrize('C_,H,B', [(128, 16, 2), (128, 64, 8), (256, 32, 8), (256, 8, 3)])
+def test_residual_op_stays_inside_its_workspace(C_, H, B):
+    """pa_residual_workspace_bytes must cover everything pa_residual_fwd_bwd lays out (the split counts of the weight
+    gradients depend on the map size: an under-estimate once let the op write 3 MB past its workspace).  Guard regions of
+    64 MB on both sides of the workspace stay untouched."""
+    from pose_adv_aug_amd._lib import lib, check, ptr, stream
+    L = lib()
+    nws = L.pa_residual_workspace_bytes(B, H, H, C_)
+    SL = 64 << 20
+    big = torch.zeros(nws + 2 * SL, dtype=torch.uint8, device='cuda')
+    big[:SL] = 0x5A; big[SL + nws:] = 0x5A
+    blk = om.Residual(C_, C_); om.deterministic_fill_(blk, seed=3)
+    params = torch.cat([p.detach().flatten() for p in blk.parameters()]).cuda()
+    bufs = torch.cat([b.flatten().float() for n, b in blk.named_buffers() if 'num_batches' not in n]).cuda()
+    x = torch.rand(B, C_, H, H, device='cuda'); dy = torch.randn(B, C_, H, H, device='cuda')
+    yd = torch.empty_like(x); dxd = torch.empty_like(x); gd = torch.zeros_like(params)
+    check(L.pa_residual_fwd_bwd(ptr(x), ptr(dy), ptr(params), ptr(yd), ptr(dxd), ptr(gd), ptr(bufs), B, C_, H, H,
+                                C.c_void_p(big.data_ptr() + SL), stream()), 'pa_residual_fwd_bwd')
+    torch.cuda.synchronize()
+    assert bool((big[:SL] == 0x5A).all()) and bool((big[SL + nws:] == 0x5A).all())
+    assert bool(torch.isfinite(dxd).all()) and bool(torch.isfinite(gd).all())
