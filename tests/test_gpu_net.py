@@ -273,3 +273,43 @@ def test_residual_op_stays_inside_its_workspace(C_, H, B):
     torch.cuda.synchronize()
     assert bool((big[:SL] == 0x5A).all()) and bool((big[SL + nws:] == 0x5A).all())
     assert bool(torch.isfinite(dxd).all()) and bool(torch.isfinite(gd).all())
+
+
+def test_network_step_stays_inside_its_workspace():
+    """pa_net_workspace_bytes vs what pa_hg_forward / pa_hg_backward and the agent touch: 64 MB guard regions around the
+    workspaces of a 2-stack pose net (chan 128, 256x256, B = 2) and of its agent stay untouched."""
+    from pose_adv_aug_amd._lib import lib, check, ptr, stream
+    L = lib()
+    B, res, chan = 2, 256, 128
+    SL = 64 << 20
+
+    def bound(h):
+        nws = L.pa_net_workspace_bytes(h)
+        big = torch.zeros(nws + 2 * SL, dtype=torch.uint8, device='cuda')
+        big[:SL] = 0x5A; big[SL + nws:] = 0x5A
+        P = torch.rand(L.pa_net_param_floats(h), device='cuda') * 0.1
+        G = torch.zeros_like(P)
+        Bf = torch.ones(max(1, L.pa_net_buffer_floats(h)), device='cuda')
+        check(L.pa_net_bind(h, ptr(P), ptr(G), ptr(Bf), C.c_void_p(big.data_ptr() + SL), stream()), 'pa_net_bind')
+        return big, nws, (P, G, Bf)
+
+    hp = L.pa_hg_create(2, 16, chan, B, res)
+    ha = L.pa_asn_create(chan, 7, 7, B, res)
+    bp, np_, keep_p = bound(hp)
+    ba, na, keep_a = bound(ha)
+    img = torch.rand(B, 3, res, res, device='cuda')
+    pts = (torch.rand(B, 16, 2, device='cuda', dtype=torch.float64) * 60 + 2)
+    loss = torch.empty(2, device='cuda')
+    check(L.pa_hg_forward(hp, ptr(img), None, ptr(pts), 1, ptr(loss)), 'pa_hg_forward')
+    check(L.pa_hg_backward(hp), 'pa_hg_backward')
+    check(L.pa_hg_forward_half(hp, ptr(img), None, 1), 'pa_hg_forward_half')
+    ls = torch.empty(B, 7, device='cuda'); lr = torch.empty(B, 7, device='cuda')
+    check(L.pa_asn_forward(ha, hp, 1, ptr(ls), ptr(lr)), 'pa_asn_forward')
+    t7 = torch.full((B, 7), 1.0 / 7, device='cuda')
+    al = torch.zeros(1, device='cuda')
+    check(L.pa_asn_backward(ha, hp, ptr(t7), ptr(t7), ptr(al)), 'pa_asn_backward')
+    torch.cuda.synchronize()
+    for big, nws in ((bp, np_), (ba, na)):
+        assert bool((big[:SL] == 0x5A).all()) and bool((big[SL + nws:] == 0x5A).all())
+    assert bool(torch.isfinite(loss).all()) and bool(torch.isfinite(keep_p[1]).all()) and bool(torch.isfinite(keep_a[1]).all())
+    L.pa_net_destroy(hp); L.pa_net_destroy(ha)
