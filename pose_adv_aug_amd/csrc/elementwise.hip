@@ -521,11 +521,21 @@ static void launch_maxpool_bwd_s(const bf16* dout, const PaOperand& in, const bf
         hipLaunchKernelGGL((maxpool_bwd_s_kernel<INMODE, HASADD, PA_OUT_PLAIN>), dim3(blocks), dim3(threads), lds, st, dout, in, add, ep, din, rows, W, C);
 }
 
+// the streaming variants need blockDim and the items of a map row (W/2 * C/8) to divide one another: pick 512 / 256 threads
+// where 1024 do not (96 x 96 maps of the 384 x 384 configuration: 1536 items per row)
+static inline void fit_threads_to_rows(int& threads, int W, int C) {
+    const size_t row_items = (size_t)(W / 2) * (C / 8);
+    auto fit = [&](int t) { return t % (C / 8) == 0 && (row_items % t == 0 || t % row_items == 0); };
+    if (fit(threads)) return;
+    if (fit(512)) threads = 512; else if (fit(256)) threads = 256;
+}
+
 int pa_launch_maxpool_bwd(const bf16* dout, const PaOperand& in, const PaOperand& add, const PaEpilogue& ep, bf16* din,
                           int B, int H, int W, int C, hipStream_t st, int* stat_rows) {
     size_t total = (size_t)B * (H / 2) * (W / 2) * (C / 8);
     int blocks, threads;
     stream_launch_dims(total, blocks, threads);
+    fit_threads_to_rows(threads, W, C);
     if (stat_rows) *stat_rows = blocks;
     if (ep.rows_out) *ep.rows_out = blocks;
     {
@@ -689,6 +699,7 @@ int pa_launch_upadd_bwd(const bf16* dout, const PaEpilogue& ep_low, bf16* dlow, 
     size_t total = (size_t)B * (H / 2) * (W / 2) * (C / 8);
     int blocks, threads;
     stream_launch_dims(total, blocks, threads);
+    fit_threads_to_rows(threads, W, C);
     if (stat_rows) *stat_rows = blocks;
     if (ep_low.rows_out) *ep_low.rows_out = blocks;
     if (ep_skip.rows_out) *ep_skip.rows_out = blocks;
