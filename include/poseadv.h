@@ -65,8 +65,9 @@ int pa_affine_params(const double* params, int B, int res_in, int res_out, doubl
 int pa_transform_pts(const float* pts, const double* params, const double* t, int B, int J, float width,
                      double* out, float* pts_img, void* stream);
 
-/* HumanAug.crop (pylib/HumanAug.py:117-176) + flip / colour gain of data/mpii_for_mpii.py:126-135 as
- * one inverse-affine bilinear gather.  src: uint8 [B][Hs][Ws][3]; out4: bf16 [B][res][res][4]
+/* The PURE inverse-affine bilinear sampler (2 x 2 taps, no pre-filter): the geometry of HumanAug.crop
+ * (pylib/HumanAug.py:117-176) + flip / colour gain of data/mpii_for_mpii.py:126-135 as one gather.  NOT the reference's
+ * pixels (those are pa_crop below, which the training / validation paths use); kept as an operator.  src: uint8 [B][Hs][Ws][3]; out4: bf16 [B][res][res][4]
  * (network input layout, 4th channel 0) and/or outf: fp32 [B][3][res][res]; either may be NULL. */
 int pa_affine_warp_bilinear(const uint8_t* src, int Hs, int Ws, const double* tinv, const double* params,
                             int B, int res, void* out4, float* outf, void* stream);
@@ -78,6 +79,21 @@ int pa_affine_warp_bilinear_sized(const uint8_t* src, int Hs, int Ws, const int3
                                   const double* params, int B, int res, void* out4, float* outf, void* stream);
 int pa_transform_pts_sized(const float* pts, const double* params, const double* t, int B, int J, const int32_t* sizes,
                            double* out, float* pts_img, void* stream);
+
+/* HumanAug.crop (pylib/HumanAug.py:117-176) behind the dataset's pre-processing (data/mpii_for_mpii.py:114-135,
+ * utils/imutils.py:31-40), stage for stage with the arithmetic of the libraries the reference delegates its pixels to
+ * (scipy.misc.pilutil over Pillow): source bytes = fp32 frame / 255, mirrored, times gain, clamped; for
+ * scale * 200 / res >= 2 the antialiased whole-frame pre-downscale (:121-133); the int-truncated, rotation-padded,
+ * zero-filled window (:136-164); PIL's bilinear rotate about the window centre (:166-170); PIL's bilinear (triangle
+ * filter) resize to res x res (:175); uint8 / 255.  Byte-exact against the reference's crop over Pillow 12 for crops
+ * that hold a black and a white pixel (scipy's per-image min/max stretching is not applied).
+ * src: uint8 [B][Hs][Ws][3]; sizes: int32 [B][2] = (width, height) of each sample's own frame inside the padded
+ * buffer, or NULL (all Ws x Hs); params: [B][8] as for pa_affine_params (centre AFTER the mirror);
+ * workspace: pa_crop_workspace_bytes() bytes (scratch, no initialisation needed);
+ * out4: bf16 [B][res][res][4] network input, outf: fp32 [B][3][res][res], out8: uint8 [B][res][res][3]; any may be NULL. */
+size_t pa_crop_workspace_bytes(int B, int Hs, int Ws, int res);
+int pa_crop(const uint8_t* src, int Hs, int Ws, const int32_t* sizes, const double* params, int B, int res, void* workspace,
+            void* out4, float* outf, uint8_t* out8, void* stream);
 
 /* Validation with flip test-time augmentation (stack-hg.py:222-230).
  * pa_flip_lr_nhwc4: mirror the bf16 NHWC4 network input along W (img.numpy()[:, :, :, ::-1], :223).
@@ -91,6 +107,11 @@ int pa_flip_tta_merge(const float* out, const float* out_flipped, float* merged,
  * meta [B][4] = {objpos_x, objpos_y, scale, frame_width}; params [B][8] as above. */
 int pa_sample_aug(const float* meta, const int32_t* scale_idx, const int32_t* rot_idx, int mode,
                   uint64_t seed, uint64_t step, int B, double* params, void* stream);
+/* the same laws with CALLER-GIVEN draws instead of the engine's counter-based stream: draws [B][7] float64 =
+ * {N(0,1) scale, N(0,1) rotation, U "rotation forced to 0", U flip, U gain_r, U gain_g, U gain_b} -- with the draws of
+ * np.random in the reference's call order the result equals the reference's parameters value for value. */
+int pa_sample_aug_given(const float* meta, const int32_t* scale_idx, const int32_t* rot_idx, int mode,
+                        const double* draws, int B, double* params, void* stream);
 
 /* softmax + np.random.choice(K, p) of joint-train-pose-s-r-agent.py:252-271.  logits [B][K];
  * probs [B][K] and idx int32 [B] may be NULL. */

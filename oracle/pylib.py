@@ -432,3 +432,34 @@ def bounded_gaussian(x, z):
 def small_gaussian(mean, var, z):
     """data/joint_train_s_r_agent.py:15-16 with the normal draw z passed in."""
     return max(mean - var + 1e-3, min(mean + var, mean + z * var))
+
+
+def regular_aug(c, s, width, z_scale, z_rot, u_rot, u_flip, u_gain):
+    """data/mpii_for_mpii.py:119-135 with every np.random draw passed in (call order of the reference: randn for the scale,
+    randn for the rotation, uniform for "no rotation", random for the flip, three uniforms for the gains).  c, s are the
+    torch.FloatTensor quantities of :95-104.  Returns (c', s' (fp32), r, flip, gains)."""
+    c = torch.tensor([float(c[0]), float(c[1])], dtype=torch.float32)
+    s = torch.tensor([float(s)], dtype=torch.float32)
+    s = s * (2 ** bounded_gaussian(0.25, z_scale))
+    r = bounded_gaussian(30, z_rot)
+    if u_rot <= 0.6:
+        r = 0
+    flip = u_flip <= 0.5
+    if flip:
+        c[0] = width - c[0]
+    gains = [0.6 + (1.4 - 0.6) * u for u in u_gain]          # np.random.uniform(low, high) = low + (high - low) * random_sample()
+    return c.numpy().astype(np.float64), float(s[0]), float(r), bool(flip), gains
+
+
+def agent_aug(c, s, width, scale_idx, rot_idx, z_scale, z_rot, u_flip, u_gain):
+    """data/joint_train_s_r_agent.py:134-139,161-169 (separate_s_r False) with the draws passed in."""
+    c = torch.tensor([float(c[0]), float(c[1])], dtype=torch.float32)
+    s = torch.tensor([float(s)], dtype=torch.float32)
+    f = small_gaussian(SCALE_MEANS[scale_idx], 0.05, z_scale)
+    r = small_gaussian(ROT_MEANS[rot_idx], 5, z_rot)
+    s = s * (2 ** f)
+    flip = u_flip <= 0.5
+    if flip:
+        c[0] = width - c[0]
+    gains = [0.6 + (1.4 - 0.6) * u for u in u_gain]
+    return c.numpy().astype(np.float64), float(s[0]), float(r), bool(flip), gains

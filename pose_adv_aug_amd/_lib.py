@@ -44,9 +44,12 @@ _PROTOS = {
     'pa_affine_warp_bilinear': (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _vp]),
     'pa_affine_warp_bilinear_sized': (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
     'pa_transform_pts_sized': (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
+    'pa_crop_workspace_bytes': (_sz, [_i, _i, _i, _i]),
+    'pa_crop': (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     'pa_flip_lr_nhwc4': (_i, [_vp, _vp, _i, _i, _i, _vp]),
     'pa_flip_tta_merge': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'pa_sample_aug': (_i, [_vp, _vp, _vp, _i, _u64, _u64, _i, _vp, _vp]),
+    'pa_sample_aug_given': (_i, [_vp, _vp, _vp, _i, _vp, _i, _vp, _vp]),
     'pa_sample_categorical': (_i, [_vp, _i, _i, _u64, _u64, C.c_uint, _vp, _vp, _vp]),
     'pa_rmsprop_step': (_i, [_vp, _vp, _vp, _sz, _f, _f, _f, _f, _vp]),
     'pa_residual_workspace_bytes': (_sz, [_i, _i, _i, _i]),

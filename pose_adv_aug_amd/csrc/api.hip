@@ -61,6 +61,12 @@ int pa_affine_warp_bilinear_sized(const uint8_t* src, int Hs, int Ws, const int3
     if (!sizes) { pa_set_error_msg("pa_affine_warp_bilinear_sized: sizes is NULL"); return 1; }
     TRY(pa_launch_warp(src, Hs, Ws, sizes, tinv, params, B, res, reinterpret_cast<bf16*>(out4), outf, ST(s))); return 0;
 }
+size_t pa_crop_workspace_bytes(int B, int Hs, int Ws, int res) { return pa_crop_workspace_size(B, Hs, Ws, res); }
+int pa_crop(const uint8_t* src, int Hs, int Ws, const int32_t* sizes, const double* params, int B, int res, void* workspace,
+            void* out4, float* outf, uint8_t* out8, void* s) {
+    if (!src || !params || !workspace || B <= 0 || res <= 0) { pa_set_error_msg("pa_crop: bad arguments"); return 1; }
+    TRY(pa_launch_crop(src, Hs, Ws, sizes, params, B, res, workspace, reinterpret_cast<bf16*>(out4), outf, out8, ST(s))); return 0;
+}
 int pa_flip_lr_nhwc4(const void* src, void* dst, int B, int H, int W, void* s) {
     TRY(pa_launch_flip_lr_nhwc4(reinterpret_cast<const bf16*>(src), reinterpret_cast<bf16*>(dst), B, H, W, ST(s))); return 0;
 }
@@ -70,7 +76,14 @@ int pa_flip_tta_merge(const float* out, const float* out_flipped, float* merged,
 }
 int pa_sample_aug(const float* meta, const int32_t* scale_idx, const int32_t* rot_idx, int mode, uint64_t seed, uint64_t step,
                   int B, double* params, void* s) {
-    TRY(pa_launch_sample_aug(meta, scale_idx, rot_idx, mode, seed, step, B, params, ST(s))); return 0;
+    if (mode != 0 && ((mode != 3 && !scale_idx) || (mode != 2 && !rot_idx))) { pa_set_error_msg("pa_sample_aug: the agent laws need bin indices"); return 1; }
+    TRY(pa_launch_sample_aug(meta, scale_idx, rot_idx, mode, seed, step, nullptr, B, params, ST(s))); return 0;
+}
+int pa_sample_aug_given(const float* meta, const int32_t* scale_idx, const int32_t* rot_idx, int mode, const double* draws,
+                        int B, double* params, void* s) {
+    if (!draws) { pa_set_error_msg("pa_sample_aug_given: draws is NULL"); return 1; }
+    if (mode != 0 && ((mode != 3 && !scale_idx) || (mode != 2 && !rot_idx))) { pa_set_error_msg("pa_sample_aug_given: the agent laws need bin indices"); return 1; }
+    TRY(pa_launch_sample_aug(meta, scale_idx, rot_idx, mode, 0, 0, draws, B, params, ST(s))); return 0;
 }
 int pa_sample_categorical(const float* logits, int B, int K, uint64_t seed, uint64_t step, unsigned slot, float* probs,
                           int32_t* idx, void* s) {

@@ -20,10 +20,13 @@ int pa_launch_transform_pts(const float* pts, const double* params, const double
 int pa_launch_warp(const unsigned char* src, int Hs, int Ws, const int* sizes, const double* tinv, const double* params, int B, int res,
                    bf16* out4, float* outf, hipStream_t st);
 int pa_launch_sample_aug(const float* meta, const int* scale_idx, const int* rot_idx, int mode, unsigned long long seed,
-                         unsigned long long step, int B, double* params, hipStream_t st);
+                         unsigned long long step, const double* draws, int B, double* params, hipStream_t st);
 int pa_launch_sample_categorical(const float* logits, int B, int K, unsigned long long seed, unsigned long long step, unsigned slot,
                                  float* probs, int* idx, hipStream_t st);
 int pa_launch_flip_lr_nhwc4(const bf16* src, bf16* dst, int B, int H, int W, hipStream_t st);
 int pa_launch_flip_tta_merge(const float* a, const float* b, float* out, int B, int H, int W, hipStream_t st);
 int pa_launch_sample_dropout_masks(const float* logits, int B, int K, int k, unsigned long long seed, unsigned long long step,
                                    const double* uniforms, float* probs, float* masks, int* indexes, hipStream_t st);
+size_t pa_crop_workspace_size(int B, int Hs, int Ws, int res);
+int pa_launch_crop(const unsigned char* src, int Hs, int Ws, const int* sizes, const double* params, int B, int res, void* workspace,
+                   bf16* out4, float* outf, unsigned char* out8, hipStream_t st);

@@ -566,44 +566,53 @@ __device__ __forceinline__ double pa_normal(unsigned long long seed, unsigned lo
 
 // mode 0: regular law; mode 1: agent law with bins (scale_idx, rot_idx); mode 2/3: agent law, scale only / rotation only
 // meta[b] = {objpos_x, objpos_y, scale (already MPII-normalised), frame_width}
+// draws (optional, [B][7] float64 = {N(0,1) for the scale, N(0,1) for the rotation, U for "rotation forced to 0", U for the
+// flip, U x 3 for the colour gains}) replaces the engine's own counter-based stream: with the draws of a numpy generator the
+// kernel reproduces the reference's laws value for value (parity tests).
 __global__ void sample_aug_kernel(const float* meta, const int* scale_idx, const int* rot_idx, int mode, unsigned long long seed,
-                                  unsigned long long step, int B, double* params) {
+                                  unsigned long long step, const double* draws, int B, double* params) {
+#pragma clang fp contract(off)        // numpy evaluates mu + z * var and low + (high - low) * u with two roundings each
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     const float* m = meta + (size_t)b * 4;
-    double s = (double)m[2], r = 0.0;
+    const double* d = draws ? draws + (size_t)b * 7 : nullptr;
+    const double zs = d ? d[0] : pa_normal(seed, step, b, 0), zr = d ? d[1] : pa_normal(seed, step, b, 2);
+    float s = m[2];                       // torch.FloatTensor in the reference: s * (2 ** x) is an fp32 product
+    double r = 0.0;
     double cx = (double)m[0];
     double flip = 0.0, g0 = 1.0, g1 = 1.0, g2 = 1.0;
     if (mode == 0) {
-        const double zs = pa_normal(seed, step, b, 0), zr = pa_normal(seed, step, b, 2);
-        s *= exp2(fmax(-0.5, fmin(0.5, zs * 0.25)));
+        // data/mpii_for_mpii.py:12-13,119-123: s *= 2 ** clip(N(0, .25), +-.5); r = clip(N(0, 30), +-60), 0 with probability .6
+        s = s * (float)exp2(fmax(-0.5, fmin(0.5, zs * 0.25)));
         r = fmax(-60.0, fmin(60.0, zr * 30.0));
-        if (pa_uniform(seed, step, b, 4) <= 0.6) r = 0.0;
+        if ((d ? d[2] : pa_uniform(seed, step, b, 4)) <= 0.6) r = 0.0;
     } else {
+        // data/joint_train_s_r_agent.py:15-16,33-36,134-139: bin means arange(-.6, .61, .2) / arange(-60, 61, 20)
         if (mode == 1 || mode == 2) {
-            const double mu = -0.6 + 0.2 * (double)scale_idx[b];
-            const double f = fmax(mu - 0.05 + 1e-3, fmin(mu + 0.05, mu + pa_normal(seed, step, b, 0) * 0.05));
-            s *= exp2(f);
+            const double mu = -0.6 + (double)scale_idx[b] * 0.2;
+            const double f = fmax(mu - 0.05 + 1e-3, fmin(mu + 0.05, mu + zs * 0.05));
+            s = s * (float)exp2(f);
         }
         if (mode == 1 || mode == 3) {
             const double mu = -60.0 + 20.0 * (double)rot_idx[b];
-            r = fmax(mu - 5.0 + 1e-3, fmin(mu + 5.0, mu + pa_normal(seed, step, b, 2) * 5.0));
+            r = fmax(mu - 5.0 + 1e-3, fmin(mu + 5.0, mu + zr * 5.0));
         }
     }
     if (mode == 0 || mode == 1) {
-        if (pa_uniform(seed, step, b, 5) <= 0.5) { flip = 1.0; cx = (double)m[3] - cx; }
-        g0 = 0.6 + 0.8 * pa_uniform(seed, step, b, 6);
-        g1 = 0.6 + 0.8 * pa_uniform(seed, step, b, 7);
-        g2 = 0.6 + 0.8 * pa_uniform(seed, step, b, 8);
+        // data/mpii_for_mpii.py:126-135: flip with probability .5 (c.x <- W - c.x), per-channel gain U(.6, 1.4)
+        if ((d ? d[3] : pa_uniform(seed, step, b, 5)) <= 0.5) { flip = 1.0; cx = (double)m[3] - cx; }
+        g0 = 0.6 + (1.4 - 0.6) * (d ? d[4] : pa_uniform(seed, step, b, 6));
+        g1 = 0.6 + (1.4 - 0.6) * (d ? d[5] : pa_uniform(seed, step, b, 7));
+        g2 = 0.6 + (1.4 - 0.6) * (d ? d[6] : pa_uniform(seed, step, b, 8));
     }
     // centre and scale are fp32 quantities in the reference (torch tensors), the rotation a float64
     double* p = params + (size_t)b * 8;
-    p[0] = (double)(float)cx; p[1] = (double)m[1]; p[2] = (double)(float)s; p[3] = r; p[4] = flip; p[5] = g0; p[6] = g1; p[7] = g2;
+    p[0] = (double)(float)cx; p[1] = (double)m[1]; p[2] = (double)s; p[3] = r; p[4] = flip; p[5] = g0; p[6] = g1; p[7] = g2;
 }
 
 int pa_launch_sample_aug(const float* meta, const int* scale_idx, const int* rot_idx, int mode, unsigned long long seed,
-                         unsigned long long step, int B, double* params, hipStream_t st) {
-    hipLaunchKernelGGL(sample_aug_kernel, dim3((B + 63) / 64), dim3(64), 0, st, meta, scale_idx, rot_idx, mode, seed, step, B, params);
+                         unsigned long long step, const double* draws, int B, double* params, hipStream_t st) {
+    hipLaunchKernelGGL(sample_aug_kernel, dim3((B + 63) / 64), dim3(64), 0, st, meta, scale_idx, rot_idx, mode, seed, step, draws, B, params);
     return (int)hipGetLastError();
 }
 

@@ -63,8 +63,8 @@ class Augmenter(object):
         self.step = 0
 
     def _finish(self, batch, want_nchw=False):
-        t_out, tinv = HumanAug.affine_params(batch.params, self.inp_res, self.out_res)
-        img4, imgf = HumanAug.warp_batch(batch.frames, tinv, batch.params, res=self.inp_res, want_nchw=want_nchw, sizes=batch.sizes)
+        t_out, _ = HumanAug.affine_params(batch.params, self.inp_res, self.out_res)
+        img4, imgf, _ = HumanAug.crop_batch(batch.frames, batch.params, res=self.inp_res, want_nchw=want_nchw, sizes=batch.sizes)
         pts_heat, pts_img = HumanAug.transform_pts_batch(batch.joints, batch.params, t_out, batch.Ws, sizes=batch.sizes)
         return {'img4': img4, 'img': imgf, 'pts': pts_heat, 'grnd_pts': pts_img,
                 'c': batch.params[:, 0:2].float().contiguous(), 's': batch.params[:, 2].float().contiguous(),

@@ -1,5 +1,5 @@
 """pylib/HumanAug.py of the reference, on the GPU: similarity transforms, joint transforms and the
-scale/rotation crop as one on-device bilinear warp."""
+scale/rotation crop (pre-downscale, window, rotate, resize: the reference's own pixel pipeline) on the device."""
 from ._dev import lib, check, ptr, stream, dev, to_dev, np, torch
 
 FLIP_PAIRS = ((0, 5), (1, 4), (2, 3), (10, 15), (11, 14), (12, 13))          # pylib/HumanAug.py:241-244
@@ -69,9 +69,35 @@ def transform_pts_batch(pts, params, t, width, sizes=None):
     return out, img
 
 
+_CROP_WS = {}
+
+
+def _crop_workspace(B, Hs, Ws, res):
+    """scratch of pa_crop (intermediate images of the staged crop), cached per shape and device"""
+    key = (B, Hs, Ws, res, torch.cuda.current_device())
+    ws = _CROP_WS.get(key)
+    if ws is None:
+        ws = _CROP_WS[key] = torch.empty(lib().pa_crop_workspace_bytes(B, Hs, Ws, res), dtype=torch.uint8, device=dev())
+    return ws
+
+
+def crop_batch(frames, params, res=256, want_nchw=False, want_nhwc4=True, want_u8=False, sizes=None):
+    """device: uint8 frames [B][Hs][Ws][3] + params [B][8] -> network input (bf16 NHWC4) and/or fp32 NCHW and/or the uint8
+    crop [B][res][res][3].  crop (pylib/HumanAug.py:117-176: pre-downscale, int-truncated window, PIL rotate, PIL resize)
+    behind flip + colour gain (data/mpii_for_mpii.py:126-135), byte-exact against the reference over Pillow."""
+    f = frames if (isinstance(frames, torch.Tensor) and frames.is_cuda) else to_dev(frames, torch.uint8)
+    B, Hs, Ws, _ = f.shape
+    out4 = torch.empty((B, res, res, 4), dtype=torch.bfloat16, device=dev()) if want_nhwc4 else None
+    outf = torch.empty((B, 3, res, res), dtype=torch.float32, device=dev()) if want_nchw else None
+    out8 = torch.empty((B, res, res, 3), dtype=torch.uint8, device=dev()) if want_u8 else None
+    check(lib().pa_crop(ptr(f), Hs, Ws, ptr(sizes), ptr(params), B, res, ptr(_crop_workspace(B, Hs, Ws, res)), ptr(out4), ptr(outf),
+                        ptr(out8), stream()), 'pa_crop')
+    return out4, outf, out8
+
+
 def warp_batch(frames, tinv, params, res=256, want_nchw=False, want_nhwc4=True, sizes=None):
-    """device: uint8 frames [B][Hs][Ws][3] -> network input (bf16 NHWC4 as a uint16-viewed tensor) and/or
-    fp32 NCHW.  Replaces crop (pylib/HumanAug.py:117-176) + flip + colour gain (data/mpii_for_mpii.py:126-135)."""
+    """device: the PURE inverse-affine bilinear sampler (2 x 2 taps at T^-1(u, v), no pre-filter) -- an operator, not the
+    reference's crop pixels (crop_batch is what the loops use)."""
     f = frames if (isinstance(frames, torch.Tensor) and frames.is_cuda) else to_dev(frames, torch.uint8)
     B, Hs, Ws, _ = f.shape
     out4 = torch.empty((B, res, res, 4), dtype=torch.bfloat16, device=dev()) if want_nhwc4 else None
@@ -86,17 +112,16 @@ def warp_batch(frames, tinv, params, res=256, want_nchw=False, want_nhwc4=True, 
 
 
 def crop(img, center, scale, rot, res, size):
-    """Reference signature (pylib/HumanAug.py:117): H x W x 3 image (float [0,1] or uint8) ->
-    res x res x 3 uint8.  Pixels come from the inverse-affine bilinear sampler, not from PIL."""
+    """Reference signature (pylib/HumanAug.py:117): H x W x 3 image (float [0,1] or uint8) -> res x res x 3 uint8, with the
+    reference's pixels (its PIL arithmetic restated on the device) except scipy's per-image min/max byte stretching."""
     if size != 200:
         raise ValueError('the reference always uses size == 200')
     a = np.asarray(img)
     if a.dtype != np.uint8:
-        a = np.clip(np.rint(a * 255.0), 0, 255).astype(np.uint8)
+        a = (np.clip(a.astype(np.float64) * 255.0, 0, 255) + 0.5).astype(np.uint8)      # toimage() with the full range
     p = make_params(np.asarray(center, dtype=np.float64).reshape(1, 2), [_scalar(scale)], [_scalar(rot)])
-    _, ti = affine_params(p, res_in=int(res), res_out=64)
-    _, outf = warp_batch(a[None], ti, p, res=int(res), want_nchw=True, want_nhwc4=False)
-    return np.clip(np.rint(outf[0].permute(1, 2, 0).cpu().numpy() * 255.0), 0, 255).astype(np.uint8)
+    _, _, out8 = crop_batch(np.ascontiguousarray(a)[None], p, res=int(res), want_nhwc4=False, want_u8=True)
+    return out8[0].cpu().numpy()
 
 
 def shufflelr(x, width, dataset='mpii'):

@@ -61,7 +61,7 @@ def transliterate():
 
 def load_ref():
     transliterate()
-    import scipy.misc  # noqa: F401  (module exists; imresize/imrotate are not used here)
+    install_scipy_misc_shim()
     from pylib import HumanPts, HumanAug, Evaluation, HumanAcc, Criterion
     from models import asn_stacked_hg
     from utils import util
@@ -78,6 +78,57 @@ def load_ref():
 
 def t(x):
     return torch.from_numpy(np.ascontiguousarray(x))
+
+
+def install_scipy_misc_shim():
+    """scipy.misc.{bytescale, toimage, fromimage, imresize, imrotate} were removed in scipy 1.3 (this image has 1.15); the
+    reference's crop calls them (pylib/HumanAug.py:130,169,175).  Restated here from scipy 0.19..1.2 `misc/pilutil.py`
+    (3-D RGB arrays only) on top of the REAL Pillow of this container, which does all the pixel work."""
+    import scipy.misc
+    from PIL import Image
+
+    def bytescale(data, cmin=None, cmax=None, high=255, low=0):
+        if data.dtype == np.uint8:
+            return data
+        if cmin is None:
+            cmin = data.min()
+        if cmax is None:
+            cmax = data.max()
+        cscale = cmax - cmin
+        if cscale == 0:
+            cscale = 1
+        scale = float(high - low) / cscale
+        bytedata = (data - cmin) * scale + low
+        return (bytedata.clip(low, high) + 0.5).astype(np.uint8)
+
+    def toimage(arr, high=255, low=0, cmin=None, cmax=None, pal=None, mode=None, channel_axis=None):
+        data = np.asarray(arr)
+        assert data.ndim == 3 and data.shape[2] == 3 and data.shape[0] != 3 and data.shape[1] != 3
+        bytedata = bytescale(data, high=high, low=low, cmin=cmin, cmax=cmax)
+        return Image.frombytes('RGB', (data.shape[1], data.shape[0]), bytedata.tobytes())
+
+    def fromimage(im):
+        return np.array(im)
+
+    func = {'nearest': 0, 'lanczos': 1, 'bilinear': 2, 'bicubic': 3, 'cubic': 3}
+
+    def imresize(arr, size, interp='bilinear', mode=None):
+        im = toimage(arr, mode=mode)
+        ts = type(size)
+        if np.issubdtype(ts, np.signedinteger):
+            size = tuple((np.array(im.size) * (size / 100.0)).astype(int))
+        elif np.issubdtype(ts, np.floating):
+            size = tuple((np.array(im.size) * size).astype(int))
+        else:
+            size = (size[1], size[0])
+        return fromimage(im.resize(tuple(int(v) for v in size), resample=func[interp]))
+
+    def imrotate(arr, angle, interp='bilinear'):
+        im = toimage(np.asarray(arr))
+        return fromimage(im.rotate(angle, resample=func[interp]))
+
+    scipy.misc.bytescale, scipy.misc.toimage, scipy.misc.fromimage = bytescale, toimage, fromimage
+    scipy.misc.imresize, scipy.misc.imrotate = imresize, imrotate
 
 
 def gen_pylib(R):
@@ -307,8 +358,46 @@ def gen_dropout(R):
     print('dropout', float(loss), indexes.tolist())
 
 
+def gen_crop(R):
+    """Row a9: the reference's own crop (pylib/HumanAug.py:117-176) behind the reference's own pre-processing
+    (data/mpii_for_mpii.py:114-135: load as fp32 / 255, mirror, colour gain + clamp) on 720x1280 frames at res 256, over
+    the scipy.misc shim above and the real Pillow.  Stored per case: every 4th pixel of the crop (rows 1::4, columns 2::4), per-channel byte sums of the
+    full crop, and the full crop for three of the cases."""
+    from tests import inputs
+    sys.path.insert(0, TMP)
+    from utils import imutils
+    HumanAug = R['HumanAug']
+    out = {}
+    frames = {}
+    for i, (kind, c0, s0, r0, flip, gain, neutral) in enumerate(inputs.WARP_CASES):
+        if kind not in frames:
+            frames[kind] = inputs.warp_frame(kind)
+        img = imutils.im_to_torch(frames[kind].copy())                    # load_image: uint8 HWC -> fp32 CHW / 255
+        c = torch.Tensor(list(c0))
+        s = torch.Tensor([s0])
+        if flip:
+            img = torch.from_numpy(HumanAug.fliplr(img.numpy())).float()
+            c[0] = img.size(2) - c[0]
+        for k in range(3):
+            img[k, :, :].mul_(gain[k]).clamp_(0, 1)
+        inp = HumanAug.crop(imutils.im_to_numpy(img), c.numpy(), s.numpy(), r0, 256, 200)
+        assert inp.dtype == np.uint8 and inp.shape == (256, 256, 3)
+        out['crop%02d_sub' % i] = inp[1::4, 2::4].copy()
+        out['crop%02d_sums' % i] = np.array([inp[..., k].astype(np.int64).sum() for k in range(3)]
+                                            + [(inp[..., k].astype(np.int64) ** 2).sum() for k in range(3)])
+        if i in (0, 5, 13):
+            out['crop%02d_full' % i] = inp
+    out['frame_sums'] = np.array([[int(frames[k].astype(np.int64).sum())] for k in sorted(frames)])
+    np.savez_compressed(os.path.join(OUT, 'crop.npz'), **out)
+    print('crop.npz', len(out), 'arrays', os.path.getsize(os.path.join(OUT, 'crop.npz')) // 1024, 'KB')
+
+
 if __name__ == '__main__':
     R = load_ref()
+    if len(sys.argv) > 1 and sys.argv[1] == 'crop':
+        gen_crop(R)
+        sys.exit(0)
     gen_pylib(R)
     gen_nets(R)
     gen_dropout(R)
+    gen_crop(R)

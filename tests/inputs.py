@@ -55,3 +55,52 @@ def person_meta(seed, n, joints=16):
     pts[bad] = 0.0
     norm = g.uniform(40, 120, n) * 0.6
     return c, s, r, pts, norm
+
+
+# ------------------------------------------------------------------ frames and cases for the crop / warp parity (row a9)
+def _mark_squares(img, x0, y0):
+    """a 28x28 pure-black and a 28x28 pure-white square side by side: a crop that contains both makes scipy's per-image
+    min/max byte scaling the identity, even after the >=2x pre-downscale"""
+    img[y0:y0 + 28, x0:x0 + 28] = 0
+    img[y0:y0 + 28, x0 + 52:x0 + 80] = 255
+
+
+def warp_frame(kind, H=720, W=1280):
+    """uint8 H x W x 3 'MPII-shape' frame: 'smooth' (low-frequency sinusoids), 'noise' (the bench's U{0..255} pixels),
+    'checker' (period-3 checkerboard with a diagonal ramp: the aliasing worst case for a point sampler)."""
+    yy, xx = np.meshgrid(np.arange(H, dtype=np.float64), np.arange(W, dtype=np.float64), indexing='ij')
+    if kind == 'smooth':
+        ch = [127.5 + 100 * np.sin(xx / (37.0 + 11 * k) + 0.3 * k) * np.cos(yy / (29.0 + 7 * k)) + 20 * np.sin((xx + yy) / 9.0 + k)
+              for k in range(3)]
+        img = np.clip(np.rint(np.stack(ch, -1)), 0, 255).astype(np.uint8)
+    elif kind == 'noise':
+        img = rng(77, 5).integers(0, 256, (H, W, 3), dtype=np.uint8)
+    elif kind == 'checker':
+        base = (((xx // 3).astype(np.int64) + (yy // 3).astype(np.int64)) % 2) * 200.0
+        ch = [np.clip(base + 0.04 * (k + 1) * (xx + yy) % 56, 0, 255) for k in range(3)]
+        img = np.rint(np.stack(ch, -1)).astype(np.uint8)
+    else:
+        raise ValueError(kind)
+    _mark_squares(img, 600, 346)
+    _mark_squares(img, 70, 76)
+    return img
+
+
+# (frame kind, centre BEFORE the mirror, scale (final, fp32), rotation deg, flip, colour gains, neutral byte scaling?)
+WARP_CASES = [
+    ('smooth',  (655.3, 371.8), 2.013, 0.0, 0, (1.0, 1.0, 1.0), True),     # resize 402 -> 256 only
+    ('smooth',  (655.3, 371.8), 2.013, 25.0, 0, (1.0, 1.0, 1.0), True),    # + rotation
+    ('smooth',  (629.5, 350.2), 3.47, 0.0, 0, (1.0, 1.0, 1.0), True),      # scale_factor 2.71: pre-downscale
+    ('smooth',  (640.0, 360.0), 1.2, -40.0, 0, (1.0, 1.0, 1.0), True),     # 240 -> 256 upscale + rotation
+    ('noise',   (641.7, 362.4), 2.3, 0.0, 0, (1.0, 1.0, 1.0), True),
+    ('noise',   (648.2, 355.9), 2.9, -17.5, 0, (1.0, 1.0, 1.0), True),     # pre-downscale + rotation
+    ('noise',   (633.1, 366.6), 5.7, 33.0, 0, (1.0, 1.0, 1.0), True),      # scale_factor 4.45
+    ('checker', (640.0, 360.0), 0.9, 0.0, 0, (1.0, 1.0, 1.0), True),       # 180 -> 256 upscale
+    ('checker', (644.4, 357.3), 2.5625, 0.0, 0, (1.0, 1.0, 1.0), True),    # scale_factor 2.002: just above the threshold
+    ('checker', (644.4, 357.3), 2.55, 8.0, 0, (1.0, 1.0, 1.0), True),      # scale_factor 1.992: just below (widest resize filter)
+    ('noise',   (632.0, 352.0), 2.55, 0.0, 1, (0.7, 1.0, 1.35), True),     # mirror + colour gain
+    ('smooth',  (651.0, 349.0), 3.1, 58.0, 1, (1.4, 0.6, 1.1), True),
+    ('checker', (110.5, 90.25), 2.2, 12.0, 0, (1.0, 1.0, 1.0), True),      # window reaches outside the frame (zero padding)
+    ('smooth',  (300.0, 500.0), 2.0, 0.0, 0, (1.0, 1.0, 1.0), False),      # no pure black / white in the crop: the byte-scaling quirk
+    ('smooth',  (300.0, 500.0), 3.3, -20.0, 0, (1.0, 1.0, 1.0), False),    # the quirk after the pre-downscale
+]

@@ -144,6 +144,7 @@ def test_losses(P):
 
 
 def test_warp_matches_oracle_sampler(P):
+    """the pure inverse-affine sampler (an operator; the loops' crop is pa_crop: tests/test_gpu_crop.py)"""
     from oracle import pylib as opl
     rng = inputs.rng(90)
     frames = rng.integers(0, 256, size=(3, 90, 120, 3), dtype=np.uint8)
@@ -160,11 +161,6 @@ def test_warp_matches_oracle_sampler(P):
         assert np.allclose(outf[i].cpu().numpy(), ref, atol=2e-6)
         nhwc = out4[i].float().cpu().numpy()
         assert np.allclose(nhwc[..., :3].transpose(2, 0, 1), ref, atol=4e-3) and np.all(nhwc[..., 3] == 0)
-    # the reference-signature wrapper
-    img = frames[0].astype(np.float64) / 255.0
-    cr = P.HumanAug.crop(img, c[0], s[0], 0, 64, 200)
-    assert cr.shape == (64, 64, 3) and cr.dtype == np.uint8
-    assert np.abs(cr.astype(np.float64) / 255 - opl.warp_bilinear(frames[0], c[0], s[0], 0.0, 64).transpose(1, 2, 0)).max() < 3e-3
 
 
 def test_rmsprop_matches_torch():

@@ -255,3 +255,51 @@ def test_occlusion_sampler_law():
             f_ref = np.mean((ref[:, 0] == a) & (ref[:, 1] == b))
             f_mine = np.mean((mine[:, 0] == a) & (mine[:, 1] == b))
             assert abs(f_ref - want) < 0.01 and abs(f_mine - want) < 0.01, (a, b, want, f_ref, f_mine)
+
+
+# ------------------------------------------------------------------ crop (row a9)
+def test_crop_restatement_reproduces_the_reference_crop():
+    """oracle.crop (numpy restatement of scipy.misc.pilutil + Pillow's resize / rotate arithmetic) == the reference's own
+    crop() over the real Pillow (tests/golden/crop.npz), byte for byte, for all 15 cases; quirk=False (the device
+    specification) equals it wherever the crop holds a black and a white pixel."""
+    from oracle import crop as oc
+    g = load('crop.npz')
+    frames = {}
+    for i, (kind, c0, s0, r0, flip, gain, neutral) in enumerate(inputs.WARP_CASES):
+        if kind not in frames:
+            frames[kind] = inputs.warp_frame(kind)
+        c = np.array(c0, dtype=np.float32)
+        if flip:
+            c[0] = np.float32(1280) - c[0]
+        for quirk in ((True, False) if neutral else (True,)):
+            out = oc.crop(oc.source_image(frames[kind], flip, gain), c, np.float32(s0), r0, 256, 200, quirk=quirk)
+            assert out.dtype == np.uint8 and out.shape == (256, 256, 3)
+            assert np.array_equal(out[1::4, 2::4], g['crop%02d_sub' % i]), (i, quirk)
+            sums = [int(out[..., k].astype(np.int64).sum()) for k in range(3)] + [int((out[..., k].astype(np.int64) ** 2).sum()) for k in range(3)]
+            assert sums == [int(v) for v in g['crop%02d_sums' % i]], (i, quirk)
+            if 'crop%02d_full' % i in g.files:
+                assert np.array_equal(out, g['crop%02d_full' % i])
+    assert [int(frames[k].astype(np.int64).sum()) for k in sorted(frames)] == [int(v) for v in g['frame_sums'].reshape(-1)]
+
+
+def test_pillow_restatements_equal_pillow():
+    """the two PIL restatements against the real library on random images (skipped where Pillow is absent)"""
+    Image = pytest.importorskip('PIL.Image')
+    from oracle import crop as oc
+    rng = inputs.rng(97)
+    for h, w, ang in [(37, 53, 25.0), (64, 64, -40.0), (101, 77, 58.0), (50, 50, 90.0), (50, 60, 90.0), (40, 40, 180.0), (33, 47, -17.5), (64, 64, 270.0)]:
+        a = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        assert np.array_equal(oc.pil_rotate_bilinear(a, ang), np.array(Image.fromarray(a).rotate(ang, resample=Image.BILINEAR)))
+    for h, w, oh, ow in [(37, 53, 20, 30), (360, 640, 112, 200), (402, 402, 256, 256), (180, 180, 256, 256), (511, 509, 256, 256), (300, 256, 256, 256), (256, 300, 256, 256)]:
+        a = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        assert np.array_equal(oc.pil_resize_bilinear(a, ow, oh), np.array(Image.fromarray(a).resize((ow, oh), resample=Image.BILINEAR)))
+
+
+def test_augmentation_law_restatements():
+    """oracle.regular_aug / agent_aug: clips, the 0.6 / 0.5 thresholds (<=), fp32 scale product, the mirror of the centre"""
+    c, s, r, flip, gains = opl.regular_aug([640.25, 360.5], 2.5, 1280.0, 3.0, -3.0, 0.7, 0.5, [0.0, 0.5, 1.0])
+    assert s == float(np.float32(2.5) * np.float32(2 ** 0.5)) and r == -60.0 and flip and c[0] == 1280 - 640.25
+    assert np.allclose(gains, [0.6, 1.0, 1.4])
+    assert opl.regular_aug([1, 1], 1.0, 10.0, 0.0, 1.0, 0.6, 0.51, [0, 0, 0])[2:4] == (0.0, False)
+    c, s, r, flip, _ = opl.agent_aug([100.0, 50.0], 2.0, 1280.0, 0, 6, -5.0, 5.0, 0.9, [0, 0, 0])
+    assert abs(np.log2(s / 2.0) - (-0.6 - 0.05 + 1e-3)) < 1e-6 and r == 65.0 and not flip
