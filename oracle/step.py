@@ -87,3 +87,49 @@ def pretrain_kl_loss(scale_logits, rot_logits, scale_distri, rot_distri):
     ls = F.kl_div(F.log_softmax(scale_logits, 1), scale_distri, reduction='mean') * scale_distri.size(1)
     lr = F.kl_div(F.log_softmax(rot_logits, 1), rot_distri, reduction='mean') * rot_distri.size(1)
     return ls + lr
+
+
+def separated_s_r_pckh(hg, img_list, c_list, s_list, r_list, grnd_pts_list, heatmap_list, normalizer_list):
+    """compute_separated_s_r_pckh, joint-train-pose-s-r-agent.py:452-467: full forward on the scale-only and the
+    rotation-only crops, per-person PCKh of each."""
+    assert len(img_list) == 2
+    out = []
+    for k in range(2):
+        with torch.no_grad():
+            o = hg(img_list[k])
+        out.append(pylib.per_person_pckh(o[-1], heatmap_list[k], c_list[k], s_list[k], [64, 64], grnd_pts_list[k],
+                                         normalizer_list[k], r_list[k]))
+    return out
+
+
+def train_agent_sr(hg, agent_sr, optimizer_sr, img_std, regular, agent_crops, scale_index_list, rotation_index_list,
+                   pckh_override=None):
+    """train_agent_sr, joint-train-pose-s-r-agent.py:317-422, ONE batch, with everything the reference draws at random
+    passed in: `regular` = what the AGENT loader yields with separate_s_r (img_list, heatmap_list, c_list, s_list, r_list,
+    grnd_pts_list, normalizer_list -- :326-328), the sampled bins (:352-362), and `agent_crops` = what load_batch_data
+    returns for those bins (:364-369).  pckh_override = (regular_pckh_list, sr_pckh_list) replaces the four PCKh vectors
+    (an untrained pose net scores ~0 everywhere; the override exercises both branches of the reward shaping).
+    Returns a dict of every intermediate; the agent's parameters have taken one RMSprop step."""
+    hg.eval()                                                                # :323-324
+    agent_sr.train()
+    keys = ('img', 'heatmap', 'c', 's', 'r', 'grnd_pts', 'normalizer')
+    reg = [[d[k] for d in regular] for k in keys]
+    regular_pckh_list = separated_s_r_pckh(hg, reg[0], reg[2], reg[3], reg[4], reg[5], reg[1], reg[6])      # :331-336
+    ls, lr = hg(img_std, agent_sr, is_half_hg=True, is_aug=True)             # :340-342
+    ps, pr = F.softmax(ls, dim=1), F.softmax(lr, dim=1)                      # :343-344
+    ag = [[d[k] for d in agent_crops] for k in keys]
+    sr_pckh_list = separated_s_r_pckh(hg, ag[0], ag[2], ag[3], ag[4], ag[5], ag[1], ag[6])                  # :372-374
+    if pckh_override is not None:
+        regular_pckh_list, sr_pckh_list = pckh_override
+    idx_s = torch.as_tensor(scale_index_list).long().view(-1, 1)             # :376-377
+    idx_r = torch.as_tensor(rotation_index_list).long().view(-1, 1)
+    gs = pylib.gen_groundtruth(ps.detach(), idx_s, regular_pckh_list[0], sr_pckh_list[0])                   # :379-389
+    gr = pylib.gen_groundtruth(pr.detach(), idx_r, regular_pckh_list[1], sr_pckh_list[1])
+    loss_scale = F.kl_div(torch.log(ps + 1e-7), gs, reduction='mean') * gs.size(1)                          # :399-404
+    loss_rot = F.kl_div(torch.log(pr + 1e-7), gr, reduction='mean') * gr.size(1)
+    loss = loss_scale + loss_rot
+    optimizer_sr.zero_grad()
+    loss.backward()
+    optimizer_sr.step()                                                      # :408-410
+    return dict(pckh_regular=regular_pckh_list, pckh_agent=sr_pckh_list, logits=(ls.detach(), lr.detach()),
+                probs=(ps.detach(), pr.detach()), targets=(gs, gr), loss=loss.detach())

@@ -77,6 +77,16 @@ __device__ __forceinline__ int tap_coeff(const Taps& t, int x) {
 }
 __device__ __forceinline__ int clip8(int ss) { ss >>= CW_PREC; return ss < 0 ? 0 : (ss > 255 ? 255 : ss); }
 
+// Coefficients are computed ONCE per output index of an axis (the double divisions are the expensive part) into a table the
+// passes read: per sample 4 axes (pre-downscale x / y over the window's part of the downscaled frame, final resize x / y),
+// CW_AXIS_MAX entries each, entry = {xmin, n, coeff[CW_KMAX]}.  n > CW_KMAX (scale factors above 11): n is stored negated and
+// the pass computes its taps inline.
+#define CW_KMAX 24
+#define CW_ENTRY (2 + CW_KMAX)
+__device__ __forceinline__ const int* tap_entry(const int* table, int b, int axis, int axis_max, int i) {
+    return table + (((size_t)b * 4 + axis) * axis_max + i) * CW_ENTRY;
+}
+
 // ------------------------------------------------------------------------------------------------ plan
 __global__ void crop_plan_kernel(const double* params, const int* sizes, int Hs, int Ws, int B, int res, CropPlan* plans) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -144,9 +154,28 @@ __global__ void crop_plan_kernel(const double* params, const int* sizes, int Hs,
     plans[b] = P;
 }
 
+__global__ void crop_coeff_kernel(const CropPlan* plans, int res, int* table, int axis_max) {
+    const CropPlan& P = plans[blockIdx.y];
+    const int axis = blockIdx.z;
+    int count, first, in_size; double scale;
+    if (axis == 0) { if (!P.case_b) return; count = P.dx1 - P.dx0; first = P.dx0; in_size = P.wb; scale = P.sx; }
+    else if (axis == 1) { if (!P.case_b) return; count = P.dy1 - P.dy0; first = P.dy0; in_size = P.hb; scale = P.sy; }
+    else if (axis == 2) { if (P.cw == res) return; count = res; first = 0; in_size = P.cw; scale = (double)P.cw / (double)res; }
+    else { if (P.ch == res) return; count = res; first = 0; in_size = P.ch; scale = (double)P.ch / (double)res; }
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count || i >= axis_max) return;
+    const Taps t = taps_of(first + i, in_size, scale);
+    int* e = table + (((size_t)blockIdx.y * 4 + axis) * axis_max + i) * CW_ENTRY;
+    e[0] = t.xmin;
+    if (t.n > CW_KMAX) { e[1] = -t.n; return; }
+    e[1] = t.n;
+    for (int k = 0; k < t.n; ++k) e[2 + k] = tap_coeff(t, k);
+}
+
 // ------------------------------------------------------------------------------------------------ pre-downscale
 // horizontal pass: T1[r - sy0][x - dx0] for source rows r in [sy0, sy1), downscaled columns x in [dx0, dx1)
-__global__ void crop_down_h_kernel(const unsigned char* src, int Hs, int Ws, const CropPlan* plans, uchar4* t1, size_t t1_stride, int t1_pitch) {
+__global__ void crop_down_h_kernel(const unsigned char* src, int Hs, int Ws, const CropPlan* plans, const int* table, int axis_max,
+                                   uchar4* t1, size_t t1_stride, int t1_pitch) {
     const CropPlan& P = plans[blockIdx.y];
     if (!P.case_b) return;
     const int ncol = P.dx1 - P.dx0, nrow = P.sy1 - P.sy0;
@@ -155,21 +184,33 @@ __global__ void crop_down_h_kernel(const unsigned char* src, int Hs, int Ws, con
     uchar4* out = t1 + (size_t)blockIdx.y * t1_stride;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int r = (int)(i / ncol), xc = (int)(i - (long)r * ncol);
-        const Taps t = taps_of(P.dx0 + xc, P.wb, P.sx);
+        const int* e = tap_entry(table, blockIdx.y, 0, axis_max, xc);
         int a0 = 1 << (CW_PREC - 1), a1 = a0, a2 = a0;
         const unsigned char* row = img + (size_t)(P.sy0 + r) * Ws * 3;
-        for (int k = 0; k < t.n; ++k) {
-            const int xs = t.xmin + k;
-            const unsigned char* px = row + (size_t)(P.flip ? P.wb - 1 - xs : xs) * 3;
-            const int w = tap_coeff(t, k);
-            a0 += src_byte(px[0], P.gain[0], true) * w; a1 += src_byte(px[1], P.gain[1], true) * w; a2 += src_byte(px[2], P.gain[2], true) * w;
+        const int xmin = e[0], n = e[1];
+        if (n >= 0) {
+            for (int k = 0; k < n; ++k) {
+                const int xs = xmin + k;
+                const unsigned char* px = row + (size_t)(P.flip ? P.wb - 1 - xs : xs) * 3;
+                const int w = e[2 + k];
+                a0 += src_byte(px[0], P.gain[0], true) * w; a1 += src_byte(px[1], P.gain[1], true) * w; a2 += src_byte(px[2], P.gain[2], true) * w;
+            }
+        } else {
+            const Taps t = taps_of(P.dx0 + xc, P.wb, P.sx);
+            for (int k = 0; k < t.n; ++k) {
+                const int xs = t.xmin + k;
+                const unsigned char* px = row + (size_t)(P.flip ? P.wb - 1 - xs : xs) * 3;
+                const int w = tap_coeff(t, k);
+                a0 += src_byte(px[0], P.gain[0], true) * w; a1 += src_byte(px[1], P.gain[1], true) * w; a2 += src_byte(px[2], P.gain[2], true) * w;
+            }
         }
         out[(size_t)r * t1_pitch + xc] = make_uchar4((unsigned char)clip8(a0), (unsigned char)clip8(a1), (unsigned char)clip8(a2), 0);
     }
 }
 
 // vertical pass: D[y - dy0][x - dx0]
-__global__ void crop_down_v_kernel(const CropPlan* plans, const uchar4* t1, size_t t1_stride, int t1_pitch, uchar4* d, size_t d_stride, int d_pitch) {
+__global__ void crop_down_v_kernel(const CropPlan* plans, const int* table, int axis_max, const uchar4* t1, size_t t1_stride, int t1_pitch,
+                                   uchar4* d, size_t d_stride, int d_pitch) {
     const CropPlan& P = plans[blockIdx.y];
     if (!P.case_b) return;
     const int ncol = P.dx1 - P.dx0, nrow = P.dy1 - P.dy0;
@@ -178,12 +219,22 @@ __global__ void crop_down_v_kernel(const CropPlan* plans, const uchar4* t1, size
     uchar4* out = d + (size_t)blockIdx.y * d_stride;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int yr = (int)(i / ncol), xc = (int)(i - (long)yr * ncol);
-        const Taps t = taps_of(P.dy0 + yr, P.hb, P.sy);
+        const int* e = tap_entry(table, blockIdx.y, 1, axis_max, yr);
         int a0 = 1 << (CW_PREC - 1), a1 = a0, a2 = a0;
-        for (int k = 0; k < t.n; ++k) {
-            const uchar4 px = in[(size_t)(t.xmin + k - P.sy0) * t1_pitch + xc];
-            const int w = tap_coeff(t, k);
-            a0 += (int)px.x * w; a1 += (int)px.y * w; a2 += (int)px.z * w;
+        if (e[1] >= 0) {
+            const int ymin = e[0], n = e[1];
+            for (int k = 0; k < n; ++k) {
+                const uchar4 px = in[(size_t)(ymin + k - P.sy0) * t1_pitch + xc];
+                const int w = e[2 + k];
+                a0 += (int)px.x * w; a1 += (int)px.y * w; a2 += (int)px.z * w;
+            }
+        } else {
+            const Taps t = taps_of(P.dy0 + yr, P.hb, P.sy);
+            for (int k = 0; k < t.n; ++k) {
+                const uchar4 px = in[(size_t)(t.xmin + k - P.sy0) * t1_pitch + xc];
+                const int w = tap_coeff(t, k);
+                a0 += (int)px.x * w; a1 += (int)px.y * w; a2 += (int)px.z * w;
+            }
         }
         out[(size_t)yr * d_pitch + xc] = make_uchar4((unsigned char)clip8(a0), (unsigned char)clip8(a1), (unsigned char)clip8(a2), 0);
     }
@@ -256,7 +307,7 @@ __device__ __forceinline__ void crop_px(const CropPlan& P, const unsigned char* 
 // ------------------------------------------------------------------------------------------------ final resize
 // horizontal pass: T2[y][uo], y < ch, uo < res (a copy when cw == res)
 __global__ void crop_resize_h_kernel(const unsigned char* src, int Hs, int Ws, const CropPlan* plans, const uchar4* d, size_t d_stride, int d_pitch,
-                                     const uchar4* u, size_t u_stride, int u_pitch, int res, uchar4* t2, size_t t2_stride) {
+                                     const uchar4* u, size_t u_stride, int u_pitch, int res, const int* table, int axis_max, uchar4* t2, size_t t2_stride) {
     const CropPlan& P = plans[blockIdx.y];
     if (P.cw == res && P.ch == res) return;                      // Image.resize to the same size: a copy (done by the last kernel)
     const long total = (long)P.ch * res;
@@ -271,13 +322,24 @@ __global__ void crop_resize_h_kernel(const unsigned char* src, int Hs, int Ws, c
         if (P.cw == res) {
             crop_px(P, img, Ws, dd, d_pitch, uu, u_pitch, y, uo, v);
         } else {
-            const Taps t = taps_of(uo, P.cw, scale);
+            const int* e = tap_entry(table, blockIdx.y, 2, axis_max, uo);
             int a0 = 1 << (CW_PREC - 1), a1 = a0, a2 = a0;
-            for (int k = 0; k < t.n; ++k) {
-                int px[3];
-                crop_px(P, img, Ws, dd, d_pitch, uu, u_pitch, y, t.xmin + k, px);
-                const int w = tap_coeff(t, k);
-                a0 += px[0] * w; a1 += px[1] * w; a2 += px[2] * w;
+            if (e[1] >= 0) {
+                const int xmin = e[0], n = e[1];
+                for (int k = 0; k < n; ++k) {
+                    int px[3];
+                    crop_px(P, img, Ws, dd, d_pitch, uu, u_pitch, y, xmin + k, px);
+                    const int w = e[2 + k];
+                    a0 += px[0] * w; a1 += px[1] * w; a2 += px[2] * w;
+                }
+            } else {
+                const Taps t = taps_of(uo, P.cw, scale);
+                for (int k = 0; k < t.n; ++k) {
+                    int px[3];
+                    crop_px(P, img, Ws, dd, d_pitch, uu, u_pitch, y, t.xmin + k, px);
+                    const int w = tap_coeff(t, k);
+                    a0 += px[0] * w; a1 += px[1] * w; a2 += px[2] * w;
+                }
             }
             v[0] = clip8(a0); v[1] = clip8(a1); v[2] = clip8(a2);
         }
@@ -288,7 +350,7 @@ __global__ void crop_resize_h_kernel(const unsigned char* src, int Hs, int Ws, c
 // vertical pass + im_to_torch (uint8 / 255, utils/imutils.py:31-36) + network layouts
 __global__ void crop_resize_v_kernel(const unsigned char* src, int Hs, int Ws, const CropPlan* plans, const uchar4* d, size_t d_stride, int d_pitch,
                                      const uchar4* u, size_t u_stride, int u_pitch, const uchar4* t2, size_t t2_stride, int res,
-                                     bf16* out4, float* outf, unsigned char* out8) {
+                                     const int* table, int axis_max, bf16* out4, float* outf, unsigned char* out8) {
     const CropPlan& P = plans[blockIdx.y];
     const int b = blockIdx.y;
     const long total = (long)res * res;
@@ -305,12 +367,22 @@ __global__ void crop_resize_v_kernel(const unsigned char* src, int Hs, int Ws, c
         } else if (P.ch == res) {
             const uchar4 px = tt[(size_t)vo * res + uo]; v[0] = px.x; v[1] = px.y; v[2] = px.z;
         } else {
-            const Taps t = taps_of(vo, P.ch, scale);
+            const int* e = tap_entry(table, b, 3, axis_max, vo);
             int a0 = 1 << (CW_PREC - 1), a1 = a0, a2 = a0;
-            for (int k = 0; k < t.n; ++k) {
-                const uchar4 px = tt[(size_t)(t.xmin + k) * res + uo];
-                const int w = tap_coeff(t, k);
-                a0 += (int)px.x * w; a1 += (int)px.y * w; a2 += (int)px.z * w;
+            if (e[1] >= 0) {
+                const int ymin = e[0], n = e[1];
+                for (int k = 0; k < n; ++k) {
+                    const uchar4 px = tt[(size_t)(ymin + k) * res + uo];
+                    const int w = e[2 + k];
+                    a0 += (int)px.x * w; a1 += (int)px.y * w; a2 += (int)px.z * w;
+                }
+            } else {
+                const Taps t = taps_of(vo, P.ch, scale);
+                for (int k = 0; k < t.n; ++k) {
+                    const uchar4 px = tt[(size_t)(t.xmin + k) * res + uo];
+                    const int w = tap_coeff(t, k);
+                    a0 += (int)px.x * w; a1 += (int)px.y * w; a2 += (int)px.z * w;
+                }
             }
             v[0] = clip8(a0); v[1] = clip8(a1); v[2] = clip8(a2);
         }
@@ -327,7 +399,8 @@ __global__ void crop_resize_v_kernel(const unsigned char* src, int Hs, int Ws, c
 // ------------------------------------------------------------------------------------------------ host
 struct CropLayout {
     int pad_b, nw_b, cw_max;           // worst-case padded window of the pre-downscale case, worst-case un-padded window
-    size_t plans, t1, d, u, t2, total; // byte offsets
+    size_t plans, table, t1, d, u, t2, total; // byte offsets
+    int axis_max;
     size_t t1_stride, d_stride, u_stride, t2_stride;   // per-sample strides in pixels
     int t1_pitch, d_pitch, u_pitch;
 };
@@ -341,6 +414,8 @@ static CropLayout crop_layout(int B, int Hs, int Ws, int res) {
     auto align = [](size_t v) { return (v + 255) & ~(size_t)255; };
     size_t off = 0;
     L.plans = off; off = align(off + (size_t)B * sizeof(CropPlan));
+    L.axis_max = L.nw_b > res ? L.nw_b : res;
+    L.table = off; off = align(off + (size_t)B * 4 * L.axis_max * CW_ENTRY * sizeof(int));
     L.t1_pitch = L.nw_b; L.t1_stride = (size_t)Hs * L.t1_pitch;
     L.t1 = off; off = align(off + (size_t)B * L.t1_stride * 4);
     L.d_pitch = L.nw_b; L.d_stride = (size_t)L.nw_b * L.d_pitch;
@@ -360,6 +435,7 @@ int pa_launch_crop(const unsigned char* src, int Hs, int Ws, const int* sizes, c
     const CropLayout L = crop_layout(B, Hs, Ws, res);
     char* ws = reinterpret_cast<char*>(workspace);
     CropPlan* plans = reinterpret_cast<CropPlan*>(ws + L.plans);
+    int* table = reinterpret_cast<int*>(ws + L.table);
     uchar4* t1 = reinterpret_cast<uchar4*>(ws + L.t1);
     uchar4* d = reinterpret_cast<uchar4*>(ws + L.d);
     uchar4* u = reinterpret_cast<uchar4*>(ws + L.u);
@@ -367,13 +443,15 @@ int pa_launch_crop(const unsigned char* src, int Hs, int Ws, const int* sizes, c
     hipLaunchKernelGGL(crop_plan_kernel, dim3((B + 63) / 64), dim3(64), 0, st, params, sizes, Hs, Ws, B, res, plans);
     const int T = 256;
     auto blocks = [&](long n) { long g = (n + T - 1) / T; return (unsigned)(g < 1 ? 1 : (g > 1024 ? 1024 : g)); };
-    hipLaunchKernelGGL(crop_down_h_kernel, dim3(blocks((long)Hs * L.nw_b), B), dim3(T), 0, st, src, Hs, Ws, plans, t1, L.t1_stride, L.t1_pitch);
-    hipLaunchKernelGGL(crop_down_v_kernel, dim3(blocks((long)L.nw_b * L.nw_b), B), dim3(T), 0, st, plans, t1, L.t1_stride, L.t1_pitch, d, L.d_stride, L.d_pitch);
+    hipLaunchKernelGGL(crop_coeff_kernel, dim3((L.axis_max + 63) / 64, B, 4), dim3(64), 0, st, plans, res, table, L.axis_max);
+    hipLaunchKernelGGL(crop_down_h_kernel, dim3(blocks((long)Hs * L.nw_b), B), dim3(T), 0, st, src, Hs, Ws, plans, table, L.axis_max, t1, L.t1_stride, L.t1_pitch);
+    hipLaunchKernelGGL(crop_down_v_kernel, dim3(blocks((long)L.nw_b * L.nw_b), B), dim3(T), 0, st, plans, table, L.axis_max, t1, L.t1_stride, L.t1_pitch,
+                       d, L.d_stride, L.d_pitch);
     hipLaunchKernelGGL(crop_rotate_kernel, dim3(blocks((long)L.cw_max * L.cw_max / 2), B), dim3(T), 0, st, src, Hs, Ws, plans, d, L.d_stride, L.d_pitch,
                        u, L.u_stride, L.u_pitch);
     hipLaunchKernelGGL(crop_resize_h_kernel, dim3(blocks((long)L.cw_max * res / 2), B), dim3(T), 0, st, src, Hs, Ws, plans, d, L.d_stride, L.d_pitch,
-                       u, L.u_stride, L.u_pitch, res, t2, L.t2_stride);
+                       u, L.u_stride, L.u_pitch, res, table, L.axis_max, t2, L.t2_stride);
     hipLaunchKernelGGL(crop_resize_v_kernel, dim3(blocks((long)res * res), B), dim3(T), 0, st, src, Hs, Ws, plans, d, L.d_stride, L.d_pitch,
-                       u, L.u_stride, L.u_pitch, t2, L.t2_stride, res, out4, outf, out8);
+                       u, L.u_stride, L.u_pitch, t2, L.t2_stride, res, table, L.axis_max, out4, outf, out8);
     return (int)hipGetLastError();
 }

@@ -55,6 +55,32 @@ class DeviceBatch(object):
         return DeviceBatch(frames, objpos, scale, joints, normalizer)
 
 
+class BatchFeed(object):
+    """A SIZED, re-iterable source of DeviceBatches (what `len(train_loader)` / `enumerate(train_loader)` are to the
+    reference's loops, stack-hg.py:133,183): len() = number of batches, .num_samples = number of people, iter() starts a
+    fresh pass (`make_iter` is called once per pass)."""
+
+    def __init__(self, num_batches, num_samples, make_iter):
+        self._n, self.num_samples, self._make_iter = int(num_batches), int(num_samples), make_iter
+
+    def __len__(self):
+        return self._n
+
+    def __iter__(self):
+        return iter(self._make_iter())
+
+    @staticmethod
+    def of(batches):
+        """a list of resident batches (the synthetic benchmark input)"""
+        batches = list(batches)
+        return BatchFeed(len(batches), sum(b.B for b in batches), lambda: batches)
+
+
+def num_samples(batches):
+    """people in a feed WITHOUT consuming it"""
+    return batches.num_samples if hasattr(batches, 'num_samples') else sum(b.B for b in batches)
+
+
 class Augmenter(object):
     """Draw augmentation parameters by the reference's laws and produce the network input + targets."""
 

@@ -64,8 +64,9 @@ class _HipModule(object):
             ws = torch.zeros(L.pa_net_workspace_bytes(h), dtype=torch.uint8, device=dev)
             check(L.pa_net_bind(h, ptr(self.flat_params), ptr(self.flat_grads), ptr(self.flat_buffers), ptr(ws), stream()),
                   'pa_net_bind')
-            self._nets[B] = (h, ws)
-            self._weights_dirty = False
+            self._nets[B] = (h, ws)               # (binding packs THIS handle's bf16 weights; a pending change still has to reach
+            if len(self._nets) == 1:              #  the handles of the other batch sizes, so the flag survives unless this is the only one)
+                self._weights_dirty = False
         h, _ = self._nets[B]
         if self._weights_dirty:
             for hh, _ in self._nets.values():

@@ -77,19 +77,30 @@ class MPII(object):
         return DeviceBatch(frames, np.stack([r[2] for r in recs]), np.asarray([r[3] for r in recs]),
                            np.stack([r[1] for r in recs]), np.asarray([r[4] for r in recs]), sizes=sizes, index=list(indices))
 
-    def batches(self, batch_size, shuffle=None, seed=0, drop_last=False, workers=8):
-        """Iterate DeviceBatches over the split (shuffle defaults to is_train, stack-hg.py:73-83); the next batch is decoded
-        by a thread pool while the caller trains on the current one."""
+    def batches(self, batch_size, shuffle=None, seed=0, drop_last=False, workers=8, rank=0, world=1):
+        """A sized BatchFeed over the split (shuffle defaults to is_train, stack-hg.py:73-83): len() = number of batches,
+        every iter() is one pass in a fresh order (seed + pass number); the next batch is decoded by a thread pool
+        (PIL releases the GIL while decoding) while the caller trains on the current one.  Data parallel: all ranks draw
+        the SAME order and rank r takes batches r, r + world, ... (equal counts on every rank)."""
+        from .data import BatchFeed
         n = len(self)
-        order = np.arange(n)
-        if self.is_train if shuffle is None else shuffle:
-            np.random.default_rng(seed).shuffle(order)
-        chunks = [order[i:i + batch_size].tolist() for i in range(0, n, batch_size)]
-        if drop_last and chunks and len(chunks[-1]) < batch_size:
-            chunks.pop()
-        with ThreadPoolExecutor(max_workers=max(1, workers)) as pool, ThreadPoolExecutor(max_workers=1) as ahead:
-            fut = ahead.submit(self.load_batch, chunks[0], pool) if chunks else None
-            for k in range(len(chunks)):
-                batch = fut.result()
-                fut = ahead.submit(self.load_batch, chunks[k + 1], pool) if k + 1 < len(chunks) else None
-                yield batch
+        nb_all = n // batch_size if drop_last else (n + batch_size - 1) // batch_size
+        nb = nb_all // world if world > 1 else nb_all
+        passes = [0]
+
+        def one_pass():
+            order = np.arange(n)
+            if self.is_train if shuffle is None else shuffle:
+                np.random.default_rng(seed + passes[0]).shuffle(order)
+            passes[0] += 1
+            chunks = [order[i:i + batch_size].tolist() for i in range(0, n, batch_size)][:nb_all]
+            chunks = chunks[rank::world][:nb] if world > 1 else chunks
+            with ThreadPoolExecutor(max_workers=max(1, workers)) as pool, ThreadPoolExecutor(max_workers=1) as ahead:
+                fut = ahead.submit(self.load_batch, chunks[0], pool) if chunks else None
+                for k in range(len(chunks)):
+                    batch = fut.result()
+                    fut = ahead.submit(self.load_batch, chunks[k + 1], pool) if k + 1 < len(chunks) else None
+                    yield batch
+
+        total = sum(min(batch_size, n - k * batch_size) for k in (range(rank, nb_all, world) if world > 1 else range(nb_all)))
+        return BatchFeed(nb, total if world == 1 else min(total, nb * batch_size), one_pass)

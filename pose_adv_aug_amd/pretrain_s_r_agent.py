@@ -13,7 +13,7 @@ import numpy as np
 import torch
 
 from .data import Augmenter, DeviceBatch
-from .utils.util import AverageMeter
+from .utils.util import DeviceMeters
 
 SCALE_MEANS = np.arange(-0.6, 0.61, 0.2)        # data/collect_scale_distri.py (scale_means): s * 2**mean
 ROT_MEANS = np.arange(-60, 61, 20)              # data/collect_rotation_distri.py (rotation_means): degrees
@@ -70,7 +70,7 @@ def _targets(distri_list, first, B, dev):
 
 
 def _run(batches, scale_distri, rotation_distri, hg, agent, optimizer, augmenter, epoch, opt, log):
-    losses = AverageMeter()
+    losses = None
     hg.eval()
     first, n = 0, len(batches)
     for i, batch in enumerate(batches):
@@ -84,10 +84,13 @@ def _run(batches, scale_distri, rotation_distri, hg, agent, optimizer, augmenter
             optimizer.step()                                                            # :192-194
         else:
             loss = agent.kl_loss(ls, lr, ts, tr, log_eps=0.0)
-        losses.update(float(loss))
+        if losses is None:
+            losses = DeviceMeters(('loss',), loss.device)
+        losses.update({'loss': loss})                                                   # every iteration, no host sync
         if i % opt.print_freq == 0 or i == n - 1:
-            log('%s epoch:%d, iters:%d/%d loss: %.4f' % ('sr-pretrain' if optimizer is not None else 'sr-val', epoch, i, n, losses.avg))
-    return losses.avg
+            log('%s epoch:%d, iters:%d/%d loss: %.4f' % ('sr-pretrain' if optimizer is not None else 'sr-val', epoch, i, n,
+                                                          losses.averages()['loss']))
+    return losses.averages()['loss']
 
 
 def train(batches, scale_distri, rotation_distri, hg, agent, optimizer, augmenter, epoch, opt, log=print):
@@ -103,25 +106,35 @@ def validate(batches, scale_distri, rotation_distri, hg, agent, augmenter, epoch
 
 
 def main(argv=None):
-    """collect (if the text files are missing) + pre-train, on synthetic MPII-shape people."""
+    """pretrain-s-r-agent.py:34-146: collect (if the text files are missing) + pre-train.  The agent checkpoints carry an
+    ASNTrainHistory (lowest_loss / is_best by train loss, :52,:131-135) so that stage 3 loads them
+    (joint-train-pose-s-r-agent.py:97-106), live in <exp>/<sr_dir>-<pose checkpoint>/ (:40-42) and resume with
+    --load_prefix_sr (:64-70)."""
     from .options.train_options import TrainOptions
+    from .stack_hg import make_feeds
     from .utils.checkpoint import Checkpoint
     from .utils.optim import RMSprop
-    from .utils.util import PoseTrainHistory
+    from .utils.util import ASNTrainHistory, adjust_lr
     from .models.asn_stacked_hg import create_hg, create_asn
     opt = TrainOptions().parse(argv)
-    sr_dir = os.path.join(opt.exp_dir, opt.exp_id, 'sr-pretrain')
+    exp = os.path.join(opt.exp_dir, opt.exp_id)
+    sr_dir = os.path.join(exp, opt.sr_dir + '-' + opt.load_prefix_pose[0:-1]) if opt.load_prefix_pose != '' else os.path.join(exp, opt.sr_dir)
     os.makedirs(sr_dir, exist_ok=True)
     hg = create_hg(num_stacks=2, num_modules=1, num_classes=16, chan=256, default_batch=opt.bs)
     if opt.load_prefix_pose != '':
-        ck = Checkpoint(); ck.load_prefix = os.path.join(opt.exp_dir, opt.exp_id, opt.load_prefix_pose)[0:-1]
+        ck = Checkpoint(); ck.load_prefix = os.path.join(exp, opt.load_prefix_pose)[0:-1]
         ck.load_checkpoint(hg)
     agent = create_asn(chan_in=256, chan_out=256, scale_num=len(SCALE_MEANS), rotation_num=len(ROT_MEANS), is_aug=True,
                        default_batch=opt.bs)
-    optimizer = RMSprop(agent, lr=opt.lr, alpha=0.99, eps=1e-8)
+    optimizer = RMSprop(agent, lr=opt.lr, alpha=0.99, eps=1e-8)                              # :93-94 (opt.lr, not agent_lr)
+    history, ckpt = ASNTrainHistory(), Checkpoint()
+    if opt.load_prefix_sr != '':                                                              # resume (:64-70)
+        ckpt.load_prefix = sr_dir + '/' + opt.load_prefix_sr[0:-1]
+        ckpt.load_checkpoint(agent, optimizer, history)
+    ckpt.save_prefix = sr_dir + '/'
     aug = Augmenter(seed=4321)
-    sets = {'train': [DeviceBatch.synthetic(opt.bs, seed=k) for k in range(4)],
-            'val': [DeviceBatch.synthetic(opt.bs, seed=700000 + k) for k in range(2)]}
+    train_feed, val_feed = make_feeds(opt)
+    sets = {'train': list(train_feed), 'val': list(val_feed)}                                 # the distributions are per person, in feed order
     distri = {}
     for split, batches in sets.items():
         for kind, fname in (('scale', '%s_scales.txt' % split), ('rotation', '%s_rotations.txt' % split)):
@@ -129,13 +142,13 @@ def main(argv=None):
             if not os.path.isfile(path):
                 collect_data(batches, hg, aug, kind, path)
             distri[(split, kind)] = read_grnd_distri_from_txt(path)
-    history, ckpt = PoseTrainHistory(), Checkpoint()
-    ckpt.save_prefix = sr_dir + '/'
-    for epoch in range(opt.nEpochs):
+    start = history.epoch[-1]['epoch'] + 1 if history.epoch else 0
+    for epoch in range(start, opt.nEpochs):
+        adjust_lr(opt, optimizer, epoch)
         tl = train(sets['train'], distri[('train', 'scale')], distri[('train', 'rotation')], hg, agent, optimizer, aug, epoch, opt)
         vl = validate(sets['val'], distri[('val', 'scale')], distri[('val', 'rotation')], hg, agent, aug, epoch, opt)
         history.update(OrderedDict([('epoch', epoch)]), OrderedDict([('lr', optimizer.param_groups[0]['lr'])]),
-                       OrderedDict([('train_loss', tl), ('val_loss', vl)]), OrderedDict([('train_pckh', 0.0), ('val_pckh', 0.0)]))
+                       OrderedDict([('train_loss', tl), ('val_loss', vl)]))
         ckpt.save_checkpoint(agent, optimizer, history, is_asn=True)
 
 

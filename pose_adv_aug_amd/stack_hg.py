@@ -10,10 +10,10 @@ from collections import OrderedDict
 import torch
 import torch.distributed as dist
 
-from .data import Augmenter, DeviceBatch
+from .data import Augmenter, BatchFeed, DeviceBatch, num_samples
 from .models.asn_stacked_hg import create_hg
 from .utils.optim import RMSprop
-from .utils.util import AverageMeter, PoseTrainHistory, adjust_lr
+from .utils.util import AverageMeter, DeviceMeters, PoseTrainHistory, adjust_lr
 
 PCK_IDX = [0, 1, 2, 3, 4, 5, 10, 11, 14, 15]            # stack-hg.py:89
 
@@ -54,17 +54,20 @@ def train_step(net, optimizer, augmenter, batch, want_pckh=True):
 
 
 def train(batches, net, optimizer, augmenter, epoch, opt, log=print):
-    """stack-hg.py:124-189 over an iterable of DeviceBatch objects."""
-    losses, pckhs, pckhs_o = AverageMeter(), AverageMeter(), AverageMeter()
+    """stack-hg.py:124-189 over a sized feed of DeviceBatches (a list, data.BatchFeed, MPII.batches()).  The meters see
+    EVERY iteration (:171-180) through device-side sums; the host synchronises only every print_freq steps."""
     net.train()
     n = len(batches)
+    meters = None
     for i, batch in enumerate(batches):
         loss, pckh, pckh_o = train_step(net, optimizer, augmenter, batch)
-        if i % opt.print_freq == 0 or i == n - 1:          # the only host sync: every print_freq steps
-            losses.update(float(loss)); pckhs.update(float(pckh)); pckhs_o.update(float(pckh_o))
-            d = OrderedDict([('loss', losses.avg), ('pckh', pckhs.avg), ('pckh_origin_res', pckhs_o.avg)])
-            log('epoch:%d, iters:%d/%d ' % (epoch, i, n) + ''.join('%s: %.4f ' % kv for kv in d.items()))      # utils/visualizer.py:70-72
-    return losses.avg, pckhs_o.avg
+        if meters is None:
+            meters = DeviceMeters(('loss', 'pckh', 'pckh_origin_res'), loss.device)
+        meters.update({'loss': loss, 'pckh': pckh, 'pckh_origin_res': pckh_o})
+        if i % opt.print_freq == 0 or i == n - 1:          # the only host sync
+            log('epoch:%d, iters:%d/%d ' % (epoch, i, n) + ''.join('%s: %.4f ' % kv for kv in meters.averages().items()))   # utils/visualizer.py:70-72
+    d = meters.averages()
+    return d['loss'], d['pckh_origin_res']
 
 
 def validate_step(net, augmenter, batch):
@@ -89,7 +92,7 @@ def validate_step(net, augmenter, batch):
 def validate(batches, net, augmenter, epoch, opt, num_classes=16, log=print):
     """stack-hg.py:191-260: returns (losses.avg, pckhs_origin_res.avg, predictions [N][num_classes][2])."""
     losses, pckhs, pckhs_o = AverageMeter(), AverageMeter(), AverageMeter()
-    n_total = sum(b.B for b in batches)
+    n_total = num_samples(batches)                    # (a feed is not consumed by asking for its size)
     predictions = torch.zeros(n_total, num_classes, 2)
     net.eval()
     n = len(batches)
@@ -107,9 +110,29 @@ def validate(batches, net, augmenter, epoch, opt, num_classes=16, log=print):
     return losses.avg, pckhs_o.avg, predictions
 
 
+MPII_JSON = 'mpii-hr-lsp-normalizer.json'                # stack-hg.py:73 ('dataset/mpii-hr-lsp-normalizer.json')
+
+
+def make_feeds(opt, rank=0, world=1, log=print):
+    """stack-hg.py:73-83: the MPII train / validation loaders.  With <data_dir>/mpii-hr-lsp-normalizer.json present the
+    feeds are MPII.batches() (JSON + image decode on the host, everything else on the device; rank r trains on batches
+    r, r + world, ... of one common order); otherwise synthetic MPII-shape people resident in HBM (the benchmark input)."""
+    path = os.path.join(opt.data_dir, MPII_JSON)
+    if os.path.isfile(path):
+        from .mpii_for_mpii import MPII
+        tr = MPII(path, opt.data_dir, is_train=True, log=log)
+        va = MPII(path, opt.data_dir, is_train=False, log=log)
+        return (tr.batches(opt.bs, shuffle=True, seed=0, drop_last=True, workers=opt.nThreads, rank=rank, world=world),
+                va.batches(opt.bs, shuffle=False, workers=opt.nThreads))
+    log('no %s: synthetic MPII-shape people' % path)
+    return (BatchFeed.of(DeviceBatch.synthetic(opt.bs, seed=rank * 1000 + k) for k in range(4)),
+            BatchFeed.of(DeviceBatch.synthetic(opt.bs, seed=500000 + k) for k in range(2)))
+
+
 def main(argv=None):
     from .options.train_options import TrainOptions
     from .utils.checkpoint import Checkpoint
+    from .utils.visualizer import Visualizer
     opt = TrainOptions().parse(argv)
     rank, world, _ = init_distributed()
     net = create_hg(num_stacks=2, num_modules=1, num_classes=16, chan=256, default_batch=opt.bs)     # stack-hg.py:40-41
@@ -124,14 +147,20 @@ def main(argv=None):
         ckpt.save_prefix = exp_dir + '/'
     broadcast_parameters(net)
     augmenter = Augmenter(seed=1234 + rank)
-    # synthetic MPII-shape people (the dataset JSON / images are not part of the checkout)
-    batches = [DeviceBatch.synthetic(opt.bs, seed=rank * 1000 + k) for k in range(4)]
-    val_batches = [DeviceBatch.synthetic(opt.bs, seed=500000 + k) for k in range(2)]
+    vis = Visualizer(opt, log_path=os.path.join(exp_dir, 'train-log.txt' if opt.is_train else 'val-log.txt') if rank == 0 else None)
+    log = (lambda m: (print(m), vis.write_log(m))) if rank == 0 else (lambda m: None)
+    batches, val_batches = make_feeds(opt, rank, world, log)
+    if not opt.is_train:                                                                     # stack-hg.py:90-96
+        epoch = history.epoch[-1]['epoch'] if history.epoch else 0
+        _, _, predictions = validate(val_batches, net, augmenter, epoch, opt, log=log)
+        if rank == 0:
+            ckpt.save_preds(predictions)
+        return
     start = history.epoch[-1]['epoch'] + 1 if history.epoch else 0
     for epoch in range(start, opt.nEpochs):
         adjust_lr(opt, optimizer, epoch)
-        tl, tp = train(batches, net, optimizer, augmenter, epoch, opt)
-        vl, vp, predictions = validate(val_batches, net, augmenter, epoch, opt)               # stack-hg.py:98-99
+        tl, tp = train(batches, net, optimizer, augmenter, epoch, opt, log=log)
+        vl, vp, predictions = validate(val_batches, net, augmenter, epoch, opt, log=log)      # stack-hg.py:98-99
         history.update(OrderedDict([('epoch', epoch)]), OrderedDict([('lr', optimizer.param_groups[0]['lr'])]),
                        OrderedDict([('train_loss', tl), ('val_loss', vl)]), OrderedDict([('train_pckh', tp), ('val_pckh', vp)]))
         if rank == 0:

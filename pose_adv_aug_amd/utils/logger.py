@@ -1,46 +1,42 @@
-"""utils/logger.py of the reference: the tab-separated training-summary file (plotting helpers left out)."""
+"""Training-summary table of the reference's scripts (utils/logger.py:24-74, used by joint-train-pose-s-r-agent.py:131-133,
+164-165,192): a text file whose first line holds the column names and every later line one epoch's numbers, fields
+terminated by a tab, numbers printed with six decimals.  The matplotlib plotting half of the reference's class is outside
+the hot path and not provided."""
 
 
 class Logger(object):
-    """Names header (tab-terminated fields) followed by one row of `{:.6f}` numbers per epoch (utils/logger.py:24-74)."""
-
     def __init__(self, fpath, title=None, resume=False):
+        self.title = title or ''
+        self.names = []
+        self.numbers = {}
         self.file = None
-        self.resume = resume
-        self.title = '' if title is None else title
-        self.names, self.numbers = [], {}
-        if fpath is not None:
-            if resume:
-                with open(fpath, 'r') as f:
-                    self.names = f.readline().rstrip().split('\t')
-                    self.numbers = {n: [] for n in self.names}
-                    for line in f:
-                        vals = line.rstrip().split('\t')
-                        for i in range(len(vals)):
-                            self.numbers[self.names[i]].append(vals[i])
-                self.file = open(fpath, 'a')
-            else:
-                self.file = open(fpath, 'w')
+        if fpath is None:
+            return
+        if resume:                                   # continue an existing table: read it back, then append
+            with open(fpath) as existing:
+                rows = [line.rstrip('\n').rstrip('\t').split('\t') for line in existing if line.strip()]
+            if rows:
+                self.names = rows[0]
+                self.numbers = {name: [row[k] for row in rows[1:] if k < len(row)] for k, name in enumerate(self.names)}
+        self.file = open(fpath, 'a' if resume else 'w')
+
+    def _write_row(self, fields):
+        self.file.write(''.join(f + '\t' for f in fields) + '\n')
+        self.file.flush()
 
     def set_names(self, names):
-        self.numbers = {}
-        self.names = list(names)
-        for name in self.names:
-            self.file.write(name)
-            self.file.write('\t')
-            self.numbers[name] = []
-        self.file.write('\n')
-        self.file.flush()
+        self.names = [str(n) for n in names]
+        self.numbers = {n: [] for n in self.names}
+        self._write_row(self.names)
 
     def append(self, numbers):
-        assert len(self.names) == len(numbers), 'Numbers do not match names'
-        for index, num in enumerate(numbers):
-            self.file.write("{0:.6f}".format(num))
-            self.file.write('\t')
-            self.numbers[self.names[index]].append(num)
-        self.file.write('\n')
-        self.file.flush()
+        if len(numbers) != len(self.names):
+            raise ValueError('%d numbers for %d columns' % (len(numbers), len(self.names)))
+        for name, value in zip(self.names, numbers):
+            self.numbers[name].append(value)
+        self._write_row(['%.6f' % float(v) for v in numbers])
 
     def close(self):
         if self.file is not None:
             self.file.close()
+            self.file = None

@@ -49,12 +49,31 @@ class RMSprop(object):
         return {'state': state, 'param_groups': [pg]}
 
     def load_state_dict(self, sd):
+        """Accepts this class's own files and torch.optim.RMSprop's: `state` is keyed by the entries of
+        param_groups[0]['params'] (positions 0..n-1 in current torch, object ids in the reference's torch 0.3), in
+        parameters() order either way.  A missing or mis-shaped entry is reported, never silently dropped."""
+        import warnings
         params = [t for t in self.net._table if t[4] == 0]
-        for i, (name, shape, off, numel, kind) in enumerate(params):
-            st = sd['state'].get(i)
-            if st is not None:
-                self.square_avg[off:off + numel] = torch.as_tensor(st['square_avg']).reshape(-1).to(self.square_avg.device)
-                self.steps = int(st.get('step', self.steps))
+        state = sd.get('state', {})
+        keys = list(sd['param_groups'][0].get('params', range(len(params))))
+        if len(keys) != len(params):
+            warnings.warn('optimizer state has %d parameters, the network %d: square_avg not loaded' % (len(keys), len(params)))
+            keys = []
+        missing = 0
+        for key, (name, shape, off, numel, kind) in zip(keys, params):
+            st = state.get(key)
+            if st is None or 'square_avg' not in st:
+                missing += 1
+                continue
+            v = torch.as_tensor(st['square_avg'])
+            if v.numel() != numel:
+                warnings.warn('optimizer state of %s has %d elements, expected %d: skipped' % (name, v.numel(), numel))
+                missing += 1
+                continue
+            self.square_avg[off:off + numel] = v.reshape(-1).to(self.square_avg.device, torch.float32)
+            self.steps = int(st.get('step', self.steps))
+        if missing and state:
+            warnings.warn('optimizer state: %d of %d parameters had no square_avg entry (left at their current value)' % (missing, len(params)))
         for k, v in sd['param_groups'][0].items():
             if k != 'params':
                 self.param_groups[0][k] = v

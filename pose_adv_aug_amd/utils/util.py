@@ -67,6 +67,46 @@ class AverageMeter(object):
         self.avg = self.sum / self.count
 
 
+class DeviceMeters(object):
+    """The AverageMeters of the training loops (stack-hg.py:126-131, joint-train-pose-s-r-agent.py:197-205) for values that
+    live on the GPU: every update is ONE tiny device add into a [names][2] (sum, count) tensor -- every iteration
+    contributes, as in the reference, without a host synchronisation per step; .averages() reads the table back (the
+    print_freq / end-of-epoch sync)."""
+
+    def __init__(self, names, device):
+        self.names = list(names)
+        self.index = {n: i for i, n in enumerate(self.names)}
+        self.table = torch.zeros(len(self.names), 2, dtype=torch.float64, device=device)
+        self._masks = {}
+
+    def update(self, values):
+        """values: {name: 0-d device tensor}; names not given keep their sums"""
+        key = tuple(sorted(values))
+        m = self._masks.get(key)
+        if m is None:
+            m = torch.zeros(len(self.names), 2, dtype=torch.float64)
+            for n in key:
+                m[self.index[n], 1] = 1.0
+            idx = torch.tensor([self.index[n] for n in key], dtype=torch.long)
+            m = self._masks[key] = (m.to(self.table.device), idx.to(self.table.device))
+        mask, idx = m
+        vals = torch.stack([values[n].detach().reshape(()).double() for n in key])
+        self.table.add_(mask)
+        self.table[:, 0].index_add_(0, idx, vals)
+
+    def averages(self, all_ranks=True):
+        """Read the table back.  all_ranks: sum the (sum, count) tables of all data-parallel ranks first (a clone is
+        reduced, the running sums stay local): the logged averages cover the GLOBAL batch, like the reference's single
+        process that sees every DataParallel shard.  len(names) * 2 numbers, only at print time."""
+        import torch.distributed as dist
+        t = self.table
+        if all_ranks and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            t = t.clone()
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        t = t.cpu()
+        return OrderedDict((n, float(t[i, 0] / t[i, 1]) if float(t[i, 1]) > 0 else 0.0) for i, n in enumerate(self.names))
+
+
 def adjust_lr(opt, optimizer, epoch):
     """utils/util.py:105-117: x0.2 at epoch 100, x0.5 at epoch 140."""
     if epoch < 100:

@@ -167,3 +167,95 @@ def test_text_log_formats(tmp_path, capsys):
     lg2 = Logger(path, resume=True)
     assert lg2.names == ['Epoch', 'LR', 'Train Loss', 'Val Loss'] and lg2.numbers['Train Loss'] == ['0.500000', '0.125000']
     lg2.close()
+
+
+def test_device_meters_see_every_iteration_split_by_kind():
+    """utils.util.DeviceMeters (CPU tensors here): the six meters of train_hg (joint-train-pose-s-r-agent.py:197-305) get
+    every step's value, regular and agent-augmented steps separately -- not a print_freq subsample."""
+    from pose_adv_aug_amd.utils.util import DeviceMeters
+    from pose_adv_aug_amd.joint_train_pose_s_r_agent import METER_NAMES
+    m = DeviceMeters(METER_NAMES, torch.device('cpu'))
+    for i in range(7):
+        loss, pckh = torch.tensor(float(i)), torch.tensor(i / 10.0)
+        tag = ('loss_hg_regular', 'pckhs_regular') if i % 2 == 0 else ('loss_hg_sr', 'pckhs_sr')
+        m.update({'loss_hg': loss, 'pckh': pckh, tag[0]: loss, tag[1]: pckh})
+    d = m.averages()
+    assert list(d) == list(METER_NAMES)
+    assert d['loss_hg'] == 3.0 and d['loss_hg_regular'] == 3.0 and d['loss_hg_sr'] == 3.0           # (0+2+4+6)/4, (1+3+5)/3
+    assert abs(d["pckhs_sr"] - 0.3) < 1e-7 and abs(d["pckh"] - 0.3) < 1e-7
+    assert DeviceMeters(('a',), torch.device('cpu')).averages() == {'a': 0.0}
+
+
+def test_batch_feed_is_sized_and_reiterable(tmp_path):
+    """what len(train_loader) / enumerate(train_loader) need (stack-hg.py:133,183): MPII.batches() is a sized feed"""
+    from pose_adv_aug_amd.data import BatchFeed, num_samples
+    calls = []
+
+    def gen():
+        calls.append(1)
+        for k in range(3):
+            yield types.SimpleNamespace(B=2, k=k)
+    f = BatchFeed(3, 6, gen)
+    assert len(f) == 3 and num_samples(f) == 6 and not calls           # asking for sizes consumes nothing
+    assert [b.k for b in f] == [0, 1, 2] and [b.k for b in f] == [0, 1, 2] and len(calls) == 2
+    assert num_samples([types.SimpleNamespace(B=4), types.SimpleNamespace(B=3)]) == 7
+
+
+def test_mpii_feed_sizes_and_rank_shards(tmp_path):
+    import json
+    from pose_adv_aug_amd.mpii_for_mpii import MPII
+    anno = [dict(dataset='MPII', isValidation=float(i % 5 == 0), img_paths='i%d.jpg' % i, joint_self=[[1.0, 2.0, 1.0]] * 16,
+                 objpos=[100.0, 80.0], scale_provided=1.0, normalizer=10.0) for i in range(53)]
+    p = tmp_path / 'a.json'
+    p.write_text(json.dumps(anno))
+    ds = MPII(str(p), str(tmp_path), is_train=True, log=lambda m: None)
+    n = len(ds)
+    assert n == 42
+    f = ds.batches(8, drop_last=True)
+    assert len(f) == 5 and f.num_samples == 40
+    f = ds.batches(8, drop_last=False, shuffle=False)
+    assert len(f) == 6 and f.num_samples == 42
+    f0, f1 = ds.batches(8, drop_last=True, rank=0, world=2), ds.batches(8, drop_last=True, rank=1, world=2)
+    assert len(f0) == len(f1) == 2 and f0.num_samples == f1.num_samples == 16       # equal counts on every rank
+
+
+def test_optimizer_state_loads_torch_files_and_warns(tmp_path):
+    """utils/optim.RMSprop.load_state_dict: torch.optim.RMSprop files keyed by position OR by arbitrary ids (torch 0.3), a
+    missing / mis-shaped entry is reported"""
+    import warnings
+    from pose_adv_aug_amd.utils.optim import RMSprop
+    table = [('a.weight', (2, 3), 0, 6, 0), ('a.bias', (3,), 8, 3, 0), ('bn.running_mean', (3,), 0, 3, 1)]
+    net = types.SimpleNamespace(flat_params=torch.zeros(12), flat_grads=torch.zeros(12), _table=table, _ensure_table=lambda: None)
+    ps = [torch.nn.Parameter(torch.randn(2, 3)), torch.nn.Parameter(torch.randn(3))]
+    topt = torch.optim.RMSprop(ps, lr=1e-3, alpha=0.99, eps=1e-8)
+    for q in ps:
+        q.grad = torch.randn_like(q)
+    topt.step()
+    sd = topt.state_dict()
+    o = RMSprop(net); o.load_state_dict(sd)
+    assert torch.equal(o.square_avg[0:6].view(2, 3), sd['state'][0]['square_avg']) and torch.equal(o.square_avg[8:11], sd['state'][1]['square_avg'])
+    assert o.param_groups[0]['lr'] == 1e-3
+    sd_ids = {'state': {140001: sd['state'][0], 140777: sd['state'][1]}, 'param_groups': [dict(sd['param_groups'][0], params=[140001, 140777])]}
+    o2 = RMSprop(net); o2.load_state_dict(sd_ids)
+    assert torch.equal(o2.square_avg, o.square_avg)
+    bad = {'state': {0: sd['state'][0]}, 'param_groups': sd['param_groups']}
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        RMSprop(net).load_state_dict(bad)
+    assert any('no square_avg' in str(x.message) for x in w)
+    own = RMSprop(net); own.load_state_dict(o.state_dict())
+    assert torch.equal(own.square_avg[0:6], o.square_avg[0:6]) and torch.equal(own.square_avg[8:11], o.square_avg[8:11])
+
+
+def test_summary_logger_format_and_resume(tmp_path):
+    """the pose-training-summary.txt table (joint-train-pose-s-r-agent.py:145-147,175): tab-terminated names, %.6f rows"""
+    from pose_adv_aug_amd.utils.logger import Logger
+    p = str(tmp_path / 's.txt')
+    lg = Logger(p, title='t'); lg.set_names(['Epoch', 'LR']); lg.append([0, 2.5e-4]); lg.close()
+    assert open(p).read() == 'Epoch\tLR\t\n0.000000\t0.000250\t\n'
+    lg = Logger(p, resume=True)
+    assert lg.names == ['Epoch', 'LR'] and lg.numbers['LR'] == ['0.000250']
+    lg.append([1, 5e-5]); lg.close()
+    assert open(p).read().count('\n') == 3
+    with pytest.raises(ValueError):
+        l2 = Logger(str(tmp_path / 'x.txt')); l2.set_names(['a']); l2.append([1, 2])
