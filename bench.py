@@ -33,13 +33,21 @@ HBM_PEAK = 8.0e12          # B/s   (MI355X_MICROARCH.md)
 MFMA_PEAK = 2.5e15         # FLOP/s dense bf16
 
 
-def cpu_baseline(stacks, chan, B, res, budget_s=25.0):
-    """The CPU oracle's train step (forward, sum-over-stacks MSE, backward, RMSprop, heat-map PCK) on the host."""
+def cpu_model():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.lower().startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
+def _time_oracle(stacks, chan, B, res, steps, budget_s):
+    """`steps` timed train steps (after 1 warm-up) of the CPU oracle: forward, sum-over-stacks MSE, backward, RMSprop,
+    heat-map PCK -- the scope of stack-hg.py:153-180.  The batch shrinks (never the network) if one step would blow the budget."""
     from oracle import model as om, step as ostep
     from tests import inputs
-    # PyTorch's CPU convolutions stop scaling (and collapse when oversubscribed) well before the core
-    # count of a GPU host: 32 threads is the measured sweet spot region; the count used is reported.
-    torch.set_num_threads(min(32, os.cpu_count() or 1))
     net = om.create_hg(stacks, 1, 16, chan)
     om.deterministic_fill_(net, seed=0)
     opt = ostep.make_optimizer(net)
@@ -52,17 +60,32 @@ def cpu_baseline(stacks, chan, B, res, budget_s=25.0):
     t0 = time.time()
     ostep.pose_train_step(net, opt, img, heat)
     per_img = (time.time() - t0) / 2
-    if per_img * B > budget_s:                            # bounded sample: shrink the batch, keep the workload
-        B = max(2, int(budget_s / per_img / 2))
+    if per_img * B * steps > budget_s:                    # bounded sample: shrink the batch, keep the workload
+        B = max(2, int(budget_s / steps / per_img))
     img, heat = batch(B)
-    n, t1 = 0, time.time()
-    while n < 1 or (time.time() - t1 < budget_s and n < 3):
+    if B != 2:
         ostep.pose_train_step(net, opt, img, heat)
-        n += 1
-    dt = (time.time() - t1) / n
-    return {'value': B / dt, 'unit': 'images/sec', 'cores': torch.get_num_threads(), 'kind': 'port',
-            'sample': '%d timed step(s) after 1 warm-up of the fp32 PyTorch-CPU oracle (oracle/step.py), %d-stack chan %d, '
-                      'B=%d, %dx%d, %.2f s/step' % (n, stacks, chan, B, res, res, dt)}
+    t1 = time.time()
+    for _ in range(steps):
+        ostep.pose_train_step(net, opt, img, heat)
+    dt = (time.time() - t1) / steps
+    return B / dt, B, dt
+
+
+def cpu_baseline(stacks, chan, B, res, budget_s=40.0, steps=5):
+    """The CPU oracle timed on this box's host cores: the benchmark's own configuration and the
+    reference's CPU-runnable plumbing case C1 (1-stack, B = 2), >= 5 timed steps each after a warm-up."""
+    # PyTorch's CPU convolutions stop scaling (and collapse when oversubscribed) well before the core count of a GPU
+    # host: 32 threads is the measured sweet spot; both the threads used and the cores present are reported.
+    threads = min(32, os.cpu_count() or 1)
+    torch.set_num_threads(threads)
+    v, b, dt = _time_oracle(stacks, chan, B, res, steps, budget_s)
+    v1, b1, dt1 = _time_oracle(1, chan, 2, res, steps, 10.0)
+    return {'value': v, 'unit': 'images/sec', 'cores': threads, 'host_cores': os.cpu_count(), 'cpu_model': cpu_model(), 'kind': 'port',
+            'sample': '%d timed steps after a warm-up of the fp32 PyTorch-CPU oracle (oracle/step.py: forward, MSE, backward, RMSprop, '
+                      'heat-map PCK), %d-stack chan %d, B=%d, %dx%d, %.2f s/step' % (steps, stacks, chan, b, res, res, dt),
+            'c1': {'value': v1, 'unit': 'images/sec',
+                   'sample': 'BASELINE configs[0]: 1-stack chan %d, B=%d, %dx%d, %d timed steps, %.3f s/step' % (chan, b1, res, res, steps, dt1)}}
 
 
 def main():
@@ -132,6 +155,11 @@ def main():
         rep = (C.c_double * 32)()
         _lib.check(_lib.lib().pa_net_profile_report(h, rep))
         _lib.check(_lib.lib().pa_net_set_multi_stream(h, 1))
+        if rank == 0 and os.environ.get('PA_BENCH_SEQ_OUT'):            # for tools/trace_classes.py (rocprofv3 runs of this command)
+            n = _lib.lib().pa_net_profile_classes(h, None, 0)
+            seq = (C.c_int32 * n)()
+            _lib.lib().pa_net_profile_classes(h, seq, n)
+            json.dump({'classes': PROF_NAMES, 'sequence': list(seq), 'steps': args.steps}, open(os.environ['PA_BENCH_SEQ_OUT'], 'w'))
         rows = []
         for i, name in enumerate(PROF_NAMES):
             ms, cnt, by, fl = rep[4 * i], rep[4 * i + 1], rep[4 * i + 2], rep[4 * i + 3]
@@ -149,14 +177,25 @@ def main():
         conv_ms = sum(r['ms_total'] for r in rows) / args.steps
         # HBM bytes per launch of that kernel class from the PMC counters (FETCH_SIZE x2 + WRITE_SIZE, collected in
         # separate rocprofv3 --pmc passes by tools/prof_pmc.sh and committed under profiles/); null if not collected
-        traffic = None
-        pmc_path = os.path.join(ROOT, 'profiles', 'round1_pmc.json')
-        if os.path.isfile(pmc_path):
-            pmc = json.load(open(pmc_path))
-            if dom['kernel'] in pmc:
-                traffic = round(pmc[dom['kernel']]['hbm_bytes_per_launch'], 1)
+        traffic, trace = None, None
+        for name in ('round2_pmc.json', 'round1_pmc.json'):
+            pmc_path = os.path.join(ROOT, 'profiles', name)
+            if os.path.isfile(pmc_path):
+                pmc = json.load(open(pmc_path))
+                if dom['kernel'] in pmc:
+                    traffic = round(pmc[dom['kernel']]['hbm_bytes_per_launch'], 1)
+                    break
+        # the same class from the committed rocprofv3 --kernel-trace of this command (tools/trace_classes.py): kernel
+        # durations without the event-to-event gaps; `frac` stays the live (event) number, `frac_trace` is quoted beside it
+        tr_path = os.path.join(ROOT, 'profiles', 'round2_trace_classes.json')
+        if os.path.isfile(tr_path):
+            tr = json.load(open(tr_path)).get(dom['kernel'])
+            if tr:
+                t_ach = (dom['flops'] if bound == 'mfma' else dom['bytes']) / dom['launches'] / (tr['avg_us'] * 1e-6) / (1e12 if bound == 'mfma' else 1e9)
+                trace = {'avg_kernel_us': tr['avg_us'], 'launches_per_step': tr['launches_per_step'], 'achieved': round(t_ach, 2),
+                         'frac': round(t_ach / peak, 4), 'source': tr.get('source', 'profiles/')}
         roofline = {'bound': bound, 'achieved': round(ach, 2), 'peak': peak, 'unit': unit, 'frac': round(ach / peak, 4),
-                    'traffic': traffic, 'kernel': dom['kernel'], 'avg_launch_us': round(dom['avg_us'], 2),
+                    'traffic': traffic, 'trace': trace, 'kernel': dom['kernel'], 'avg_launch_us': round(dom['avg_us'], 2),
                     'launches_per_step': dom['launches'] // args.steps,
                     'alg_bytes_per_launch': dom['bytes'] / dom['launches'], 'alg_flops_per_launch': dom['flops'] / dom['launches'],
                     'mfma_kernels_ms_per_step': round(conv_ms, 3),

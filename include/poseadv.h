@@ -249,6 +249,9 @@ int pa_hg_pckh(pa_net* net, int stack, const float* center, const float* scale, 
  * 5 wgrad 3x3, 6 stem fwd, 7 stem wgrad, and stop recording.  out is a HOST array. */
 int pa_net_profile_begin(pa_net* net);
 int pa_net_profile_report(pa_net* net, double* out_host);
+/* class (0..7 as above) of every timed launch of the last reported pass, in launch order: returns their number and fills
+ * out_host[0..min(cap, n)) (HOST array).  tools/trace_classes.py matches a rocprofv3 kernel trace of the same pass with it. */
+int pa_net_profile_classes(const pa_net* net, int32_t* out_host, int cap);
 
 /* The engine enqueues independent branches (hourglass skip blocks, weight gradients) on internal side
  * streams that fork from / join into the caller's stream by events.  on = 0 serialises everything on

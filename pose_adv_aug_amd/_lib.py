@@ -88,6 +88,7 @@ _PROTOS = {
     'pa_hg_pckh': (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
     'pa_net_profile_begin': (_i, [_vp]),
     'pa_net_profile_report': (_i, [_vp, C.POINTER(C.c_double)]),
+    'pa_net_profile_classes': (_i, [_vp, C.POINTER(C.c_int32), _i]),
     'pa_net_set_multi_stream': (_i, [_vp, _i]),
     'pa_hg_debug_tensor': (_i, [_vp, C.c_char_p, _i, _vp, C.POINTER(_i)]),
     'pa_asn_debug_tensor': (_i, [_vp, C.c_char_p, _i, _vp, C.POINTER(_i)]),
@@ -134,6 +135,12 @@ def ptr(t):
 
 def stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def device():
+    """The HIP device all tensors of the package live on (one per process: LOCAL_RANK's GPU)."""
+    require_gpu()
+    return torch.device('cuda', torch.cuda.current_device())
 
 
 def require_gpu():

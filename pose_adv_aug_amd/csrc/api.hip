@@ -313,7 +313,7 @@ pa_net* pa_hg_create(int num_stacks, int num_classes, int chan, int B, int res) 
     if (!p) return nullptr;
     Net& n = p->n;
     n.stacks = num_stacks; n.classes = num_classes; n.chan = chan; n.B = B; n.res = res;
-    n.immediate_reduce = getenv("PA_SHARED_SLAB") != nullptr;
+    n.immediate_reduce = pa_getenv("PA_SHARED_SLAB") != nullptr;
     n.declare_pose();
     n.workspace_bytes = n.layout_all(nullptr);
     return p;
@@ -329,7 +329,7 @@ pa_net* pa_asn_create(int chan, int scale_num, int rotation_num, int B, int res)
     if (!p) return nullptr;
     Net& n = p->n;
     n.chan = chan; n.B = B; n.res = res; n.scale_num = scale_num; n.rot_num = rotation_num; n.stacks = 0;
-    n.immediate_reduce = getenv("PA_SHARED_SLAB") != nullptr;
+    n.immediate_reduce = pa_getenv("PA_SHARED_SLAB") != nullptr;
     n.declare_asn();
     n.workspace_bytes = n.layout_asn(nullptr);
     return p;
@@ -345,7 +345,7 @@ pa_net* pa_asn_create_dropout(int chan, int B, int res) {
     if (!p) return nullptr;
     Net& n = p->n;
     n.chan = chan; n.B = B; n.res = res; n.stacks = 0; n.asn_dropout = true;
-    n.immediate_reduce = getenv("PA_SHARED_SLAB") != nullptr;
+    n.immediate_reduce = pa_getenv("PA_SHARED_SLAB") != nullptr;
     n.declare_asn();
     n.workspace_bytes = n.layout_asn(nullptr);
     return p;
@@ -507,6 +507,12 @@ int pa_net_profile_report(pa_net* net, double* out) {
     int r = net->n.prof.report(out);
     if (r) pa_set_error("profile report", (hipError_t)r, __FILE__, __LINE__);
     return r;
+}
+
+int pa_net_profile_classes(const pa_net* net, int32_t* out, int cap) {
+    const std::vector<int>& q = net->n.prof.last_seq;
+    for (int i = 0; i < cap && i < (int)q.size(); ++i) out[i] = q[i];
+    return (int)q.size();
 }
 
 int pa_net_set_multi_stream(pa_net* net, int on) {

@@ -19,6 +19,15 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
         if (_e != hipSuccess) { pa_set_error(#expr, _e, __FILE__, __LINE__); return (int)_e; } \
     } while (0)
 
+// A/B switches (PA_* environment variables selecting between parity-tested code paths) exist only in a
+// tuning build (PA_TUNING=1 bash build.sh -> -DPA_TUNING); the release library reads no environment at all.
+#include <stdlib.h>
+#ifdef PA_TUNING
+inline const char* pa_getenv(const char* name) { return getenv(name); }
+#else
+inline const char* pa_getenv(const char*) { return nullptr; }
+#endif
+
 void pa_set_error(const char* what, hipError_t e, const char* file, int line);
 void pa_set_error_msg(const char* msg);
 

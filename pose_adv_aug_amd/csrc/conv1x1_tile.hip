@@ -171,7 +171,7 @@ static void launch_row_ld(const PaConvArgs& a, dim3 grid, int nbw, hipStream_t s
 // workgroups 1.5 times (the last round runs half empty); 1536 tiles of 64 rows at 3 workgroups/CU are 2 full rounds
 static int row_bm(int Cin) {
     static int big = -1;
-    if (big < 0) big = getenv("PA_CONV1_BM128") ? 1 : 0;
+    if (big < 0) big = pa_getenv("PA_CONV1_BM128") ? 1 : 0;
     return (Cin == 256 || (Cin == 128 && !big)) ? 64 : 128;
 }
 

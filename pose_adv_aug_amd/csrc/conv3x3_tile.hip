@@ -244,7 +244,7 @@ static bool small_map(const PaConvArgs& a) { return (a.H == 8 && a.W == 8) || (a
 
 bool pa_conv3x3_tile_supported(const PaConvArgs& a) {
     static int nosmall = -1;
-    if (nosmall < 0) nosmall = getenv("PA_CONV3_NOSMALL") ? 1 : 0;
+    if (nosmall < 0) nosmall = pa_getenv("PA_CONV3_NOSMALL") ? 1 : 0;
     if (a.taps != 9 || (a.Cin != 64 && a.Cin != 128) || a.Cout % 64 != 0) return false;
     return (a.H % 8 == 0 && a.W % 16 == 0) || (!nosmall && small_map(a));
 }
@@ -256,19 +256,19 @@ int pa_launch_conv3x3_tile(const PaConvArgs& a, hipStream_t st, int* stat_rows) 
     // 16 x 4 pixel tiles (3 workgroups per CU) where 16 x 8 tiles would leave CUs idle: measured 64x64 maps (768 tiles)
     // 39.8 vs 42.8 us in favour of 16 x 8, 32x32 maps (192 tiles) 17.6 vs 14.6 us in favour of 16 x 4
     static int bm64 = -1;
-    if (bm64 < 0) { const char* e = getenv("PA_CONV3_BM64"); bm64 = e ? atoi(e) : -2; }
+    if (bm64 < 0) { const char* e = pa_getenv("PA_CONV3_BM64"); bm64 = e ? atoi(e) : -2; }
     const int tiles128 = small ? 0 : a.B * (a.H / 8) * (a.W / 16);
     const bool half = !small && a.Cin == 128 && (bm64 == -2 ? tiles128 < 512 : bm64 != 0);
     const int tiles = small ? (a.B + img - 1) / img : a.B * (a.H / (half ? 4 : 8)) * (a.W / 16);
     if (stat_rows) *stat_rows = tiles;
     if (a.ep.rows_out) *a.ep.rows_out = tiles;
     static int n64 = -1;
-    if (n64 < 0) n64 = getenv("PA_CONV3_BN64") ? 1 : 0;          // experiment: 64-channel halves
+    if (n64 < 0) n64 = pa_getenv("PA_CONV3_BN64") ? 1 : 0;          // experiment: 64-channel halves
     // the low-resolution levels have 3..12 pixel tiles: 64-channel halves double the number of workgroups
     const bool bigN = a.Cout % 128 == 0 && !n64 && !small;
     dim3 grid(tiles, a.Cout / (bigN ? 128 : 64));
     static int xcd = -1;
-    if (xcd < 0) xcd = getenv("PA_CONV3_NOXCD") ? 0 : 1;          // +0.3 % on the step (halo re-reads served by the XCD's own L2)
+    if (xcd < 0) xcd = pa_getenv("PA_CONV3_NOXCD") ? 0 : 1;          // +0.3 % on the step (halo re-reads served by the XCD's own L2)
     PaConvArgs b = a;
     b.xcd = (a.xcd & 2) | ((xcd && !small && tiles % 8 == 0) ? 1 : 0);
     if (half) launch_tile_shape<16, 4>(b, grid, bigN, st);

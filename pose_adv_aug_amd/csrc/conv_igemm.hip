@@ -222,7 +222,7 @@ int pa_launch_stem_conv(const PaConvArgs& a, hipStream_t st, int* stat_rows) {
 
 int pa_launch_conv(const PaConvArgs& a0, hipStream_t st, int* stat_rows) {
     static int bwd_direct = -1;
-    if (bwd_direct < 0) bwd_direct = getenv("PA_EPI_BWD_DIRECT") ? 2 : 0;      // A/B: direct BatchNorm-backward epilogue
+    if (bwd_direct < 0) bwd_direct = pa_getenv("PA_EPI_BWD_DIRECT") ? 2 : 0;      // A/B: direct BatchNorm-backward epilogue
     PaConvArgs a = a0;
     a.xcd = bwd_direct;
     if ((a.taps != 1 && a.taps != 9) || a.Cin % 64 != 0 || a.Cout % 64 != 0 || a.Cin > 512) {
@@ -230,10 +230,10 @@ int pa_launch_conv(const PaConvArgs& a0, hipStream_t st, int* stat_rows) {
         return 1;
     }
     static int old3 = -1;
-    if (old3 < 0) old3 = getenv("PA_CONV3_OLD") ? 1 : 0;          // experiments: force the generic kernel
+    if (old3 < 0) old3 = pa_getenv("PA_CONV3_OLD") ? 1 : 0;          // experiments: force the generic kernel
     if (!old3 && pa_conv3x3_tile_supported(a)) return pa_launch_conv3x3_tile(a, st, stat_rows);
     static int old1 = -1;
-    if (old1 < 0) old1 = getenv("PA_CONV1_OLD") ? 1 : 0;
+    if (old1 < 0) old1 = pa_getenv("PA_CONV1_OLD") ? 1 : 0;
     if (!old1 && pa_conv1x1_tile_supported(a)) return pa_launch_conv1x1_tile(a, st, stat_rows);
     const int M = a.B * a.H * a.W;
     // small problems get the 64-row tile so that the grid still covers the 256 CUs

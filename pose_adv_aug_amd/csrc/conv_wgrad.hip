@@ -229,8 +229,8 @@ static void tile_of(int Cin, int Cout, int taps, int& TN, int& TK) {
     TN = (Cout % 128 == 0) ? 128 : 64;
     TK = (Cin % 128 == 0) ? 128 : 64;
     static int t1 = -1, t9 = -1;
-    if (t1 < 0) { const char* e = getenv("PA_WGRAD_TILE1"); t1 = e ? atoi(e) : 0; }
-    if (t9 < 0) { const char* e = getenv("PA_WGRAD_TILE9"); t9 = e ? atoi(e) : 0; }
+    if (t1 < 0) { const char* e = pa_getenv("PA_WGRAD_TILE1"); t1 = e ? atoi(e) : 0; }
+    if (t9 < 0) { const char* e = pa_getenv("PA_WGRAD_TILE9"); t9 = e ? atoi(e) : 0; }
     const int f = taps == 1 ? t1 : t9;       // experiments: 1 = 64x64, 2 = 128x64, 3 = 64x128
     if (f == 1) { TN = 64; TK = 64; }
     if (f == 2) { TK = 64; }
@@ -250,7 +250,7 @@ int pa_wgrad_splits(int M, int H, int W, int Cin, int Cout, int taps) {
     // enough workgroups to keep every CU busy with several of them (measured on MI355X: 512 for the
     // 1x1 layers, 1024 for the 3x3 layers; PA_WGRAD_BLOCKS overrides for experiments)
     static int forced = -1;
-    if (forced < 0) { const char* e = getenv("PA_WGRAD_BLOCKS"); forced = e ? atoi(e) : 0; }
+    if (forced < 0) { const char* e = pa_getenv("PA_WGRAD_BLOCKS"); forced = e ? atoi(e) : 0; }
     const int target = forced >= 8 ? forced : (taps == 9 ? 1024 : 512);
     int s = round_up8((target + tiles - 1) / tiles);
     if (s > steps_total) s = steps_total;

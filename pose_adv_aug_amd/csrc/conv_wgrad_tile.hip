@@ -293,9 +293,9 @@ struct WgTileCfg { int nb, cb, ntiles, splits; };
 static bool wg_tile_cfg(int B, int H, int W, int Cin, int Cout, int taps, WgTileCfg& c) {
     static int off = -1, target1 = 0, target9 = 0;
     if (off < 0) {
-        off = getenv("PA_WGRAD_OLD") ? 1 : 0;
-        const char* e = getenv("PA_WGRAD_WGS1"); target1 = e ? atoi(e) : 256;
-        e = getenv("PA_WGRAD_WGS9"); target9 = e ? atoi(e) : 256;
+        off = pa_getenv("PA_WGRAD_OLD") ? 1 : 0;
+        const char* e = pa_getenv("PA_WGRAD_WGS1"); target1 = e ? atoi(e) : 256;
+        e = pa_getenv("PA_WGRAD_WGS9"); target9 = e ? atoi(e) : 256;
     }
     if (off || H <= 0 || W <= 0) return false;
     const int M = B * H * W;
@@ -307,7 +307,7 @@ static bool wg_tile_cfg(int B, int H, int W, int Cin, int Cout, int taps, WgTile
         if (Cin % 64 || Cout % 64) return false;
         c.nb = Cout % 128 == 0 ? 128 : 64; c.cb = Cin % 128 == 0 ? 128 : 64; c.ntiles = (M + 127) / 128;
         static int min1 = -1;
-        if (min1 < 0) min1 = getenv("PA_WGRAD_MIN1") ? atoi(getenv("PA_WGRAD_MIN1")) : 3;      // also the 16x16 ... 4x4 levels: 6.90 vs 6.97 ms (96)
+        if (min1 < 0) min1 = pa_getenv("PA_WGRAD_MIN1") ? atoi(pa_getenv("PA_WGRAD_MIN1")) : 3;      // also the 16x16 ... 4x4 levels: 6.90 vs 6.97 ms (96)
         if (c.ntiles < min1) return false;
     } else return false;
     const int types = (Cout / c.nb) * (Cin / c.cb);
@@ -337,7 +337,7 @@ static void launch_wt_modes(const PaWgradArgs& a, dim3 grid, int ntiles, hipStre
 // 7x7/2 stem weight gradient on the tile kernel: NB = 64 output channels x CB = 256 patch elements per workgroup, dy read once
 int pa_launch_stem_wgrad_tile(const PaWgradArgs& a, hipStream_t st) {
     static int off = -1;
-    if (off < 0) off = (getenv("PA_WGRAD_OLD") || getenv("PA_STEM_WGRAD_OLD")) ? 1 : 0;
+    if (off < 0) off = (pa_getenv("PA_WGRAD_OLD") || pa_getenv("PA_STEM_WGRAD_OLD")) ? 1 : 0;
     const int M = a.B * a.H * a.W, ntiles = (M + 127) / 128;
     if (off || a.Cin != 256 || a.Cout != 64 || a.splits > ntiles) return -1;
     dim3 grid(a.splits, 1, 1);

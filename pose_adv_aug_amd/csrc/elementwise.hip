@@ -349,7 +349,7 @@ __global__ __launch_bounds__(256) void pool_up_fwd_s_kernel(PaOperand a, PaOpera
 template <int OP>
 static bool launch_pool_up_fwd_s(const PaOperand& a, const PaOperand& b, bf16* out, int B, int H, int W, int C, hipStream_t st) {
     static int old = -1;
-    if (old < 0) old = getenv("PA_ELTWISE_OLD") ? 1 : 0;
+    if (old < 0) old = pa_getenv("PA_ELTWISE_OLD") ? 1 : 0;
     const int threads = 256;
     const size_t row_items = (size_t)(W / 2) * (C / 8);
     const bool ma = a.mode == PA_LD_PLAIN || a.mode == PA_LD_BNRELU, mb = OP == 0 || b.mode == PA_LD_PLAIN || b.mode == PA_LD_BNRELU;
@@ -540,7 +540,7 @@ int pa_launch_maxpool_bwd(const bf16* dout, const PaOperand& in, const PaOperand
     if (ep.rows_out) *ep.rows_out = blocks;
     {
         static int old = -1;
-        if (old < 0) old = getenv("PA_ELTWISE_OLD") ? 1 : 0;
+        if (old < 0) old = pa_getenv("PA_ELTWISE_OLD") ? 1 : 0;
         const size_t row_items = (size_t)(W / 2) * (C / 8);
         const bool in_ok = in.mode == PA_LD_PLAIN || in.mode == PA_LD_BNRELU;
         const bool add_ok = add.mode == PA_LD_NONE || add.mode == PA_LD_PLAIN;
@@ -704,7 +704,7 @@ int pa_launch_upadd_bwd(const bf16* dout, const PaEpilogue& ep_low, bf16* dlow, 
     if (ep_low.rows_out) *ep_low.rows_out = blocks;
     if (ep_skip.rows_out) *ep_skip.rows_out = blocks;
     static int old = -1;
-    if (old < 0) old = getenv("PA_ELTWISE_OLD") ? 1 : 0;
+    if (old < 0) old = pa_getenv("PA_ELTWISE_OLD") ? 1 : 0;
     const size_t row_items = (size_t)(W / 2) * (C / 8);
     if (!old && ep_low.mode == PA_OUT_BWD && ep_skip.mode == PA_OUT_BWD && threads % (C / 8) == 0 &&
         (row_items % threads == 0 || threads % row_items == 0) && (size_t)B * H * W * C < ((size_t)1 << 31)) {

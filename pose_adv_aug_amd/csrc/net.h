@@ -71,6 +71,7 @@ struct Prof {
     bool on = false;
     std::vector<ProfEntry> entries;
     size_t used = 0;
+    std::vector<int> last_seq;            // class of every launch of the last reported pass, in launch order
     ProfEntry* begin(int cls, double bytes, double flops, hipStream_t st);
     void end(ProfEntry* e, hipStream_t st);
     int report(double* out /* [PA_PROF_NCLS][4] = total ms, launches, algorithmic bytes, flops */);

@@ -5,8 +5,9 @@
 #include <stdio.h>
 #include <string.h>
 
-static int g_nosync = -1;      // PA_EXPERIMENT_NOSYNC: timing experiment only (results are garbage): no cross-stream waits
-static bool nosync() { if (g_nosync < 0) g_nosync = getenv("PA_EXPERIMENT_NOSYNC") ? atoi(getenv("PA_EXPERIMENT_NOSYNC")) : 0; return g_nosync != 0; }
+// (the round-1 timing experiment that removed cross-stream waits -- wrong results by design -- is gone from the library)
+static const int g_nosync = 0;
+static bool nosync() { return false; }
 #define TRY(x) do { int _r = (x); if (_r) return _r; } while (0)
 
 PaOperand pa_plain(const bf16* p) { PaOperand o; o.p = p; o.q = nullptr; o.k0 = o.k1 = o.k2 = nullptr; o.mode = PA_LD_PLAIN; return o; }
@@ -112,7 +113,7 @@ void Net::layout_conv(ConvLayer& c, Arena& a, int M, int H, int W) {
     c.splits = c.k == 7 ? pa_wgrad_splits(M, 0, 0, c.pcin, c.pcout, 1) : pa_wgrad_splits(M, H, W, c.pcin, c.pcout, c.taps());
     if (c.k == 7) {                              // stem: 64 KB slabs, so two workgroups per CU (their load / MFMA phases overlap)
         static int ss = -1;
-        if (ss < 0) { const char* e = getenv("PA_STEM_SPLITS"); ss = e ? atoi(e) : 512; }       // 6.96 vs 7.00 ms (256)
+        if (ss < 0) { const char* e = pa_getenv("PA_STEM_SPLITS"); ss = e ? atoi(e) : 512; }       // 6.96 vs 7.00 ms (256)
         if (ss > 0 && ss <= (M + 127) / 128) c.splits = ss;
     }
     c.part_floats = (size_t)c.splits * wn;
@@ -281,6 +282,8 @@ void Prof::end(ProfEntry* e, hipStream_t st) { if (e) hipEventRecord(e->e1, st);
 
 int Prof::report(double* out) {
     for (int i = 0; i < PA_PROF_NCLS * 4; ++i) out[i] = 0.0;
+    last_seq.clear();
+    for (size_t i = 0; i < used; ++i) last_seq.push_back(entries[i].cls);
     for (size_t i = 0; i < used; ++i) {
         ProfEntry& e = entries[i];
         hipError_t r = hipEventSynchronize(e.e1);
@@ -368,9 +371,9 @@ int Net::conv_dgrad(ConvLayer& c, const PaOperand& dy, int B_, int H, int W, con
     if (dz_done) *dz_done = false;
     if (dz_out && dy.mode == PA_LD_LIN2) {         // only the 1x1 row-tile kernel stores its transformed input
         static int off = -1;
-        if (off < 0) off = (getenv("PA_CONV1_OLD") || getenv("PA_NO_DZ3")) ? 1 : 0;
+        if (off < 0) off = (pa_getenv("PA_CONV1_OLD") || pa_getenv("PA_NO_DZ3")) ? 1 : 0;
         static int off3 = -1;
-        if (off3 < 0) off3 = (getenv("PA_CONV3_OLD") || getenv("PA_NO_DZ2")) ? 1 : 0;
+        if (off3 < 0) off3 = (pa_getenv("PA_CONV3_OLD") || pa_getenv("PA_NO_DZ2")) ? 1 : 0;
         if ((!off && a.taps == 1 && pa_conv1x1_tile_supported(a)) || (!off3 && a.taps == 9 && pa_conv3x3_tile_supported(a))) { a.dz_out = dz_out; if (dz_done) *dz_done = true; }
     }
     double wb, wf; conv_work(B_ * H * W, c.Cin, c.Cout, c.taps(), false, wb, wf);
@@ -607,21 +610,21 @@ int Hourglass::bwd(Net& n, const Act& in, const PaOperand& extra0) {
 
 int Net::ensure_streams() {
     if (streams_ready) return 0;
-    if (getenv("PA_SINGLE_STREAM")) { multi_stream = false; streams_ready = true; return 0; }
-    if (const char* e = getenv("PA_FORK_LEVELS")) fork_mask = atoi(e);
-    if (const char* e = getenv("PA_SIDE_STREAMS")) n_side = atoi(e) < 1 ? 1 : (atoi(e) > 4 ? 4 : atoi(e));
-    reduce_early = getenv("PA_WREDUCE_LATE") == nullptr;
-    if (const char* e = getenv("PA_WFLUSH_EVERY")) flush_every = atoi(e) > 0 ? atoi(e) : 1;
+    if (pa_getenv("PA_SINGLE_STREAM")) { multi_stream = false; streams_ready = true; return 0; }
+    if (const char* e = pa_getenv("PA_FORK_LEVELS")) fork_mask = atoi(e);
+    if (const char* e = pa_getenv("PA_SIDE_STREAMS")) n_side = atoi(e) < 1 ? 1 : (atoi(e) > 4 ? 4 : atoi(e));
+    reduce_early = pa_getenv("PA_WREDUCE_LATE") == nullptr;
+    if (const char* e = pa_getenv("PA_WFLUSH_EVERY")) flush_every = atoi(e) > 0 ? atoi(e) : 1;
     for (int k = 0; k < 4; ++k) {
         if (k < n_side) PA_CHECK(hipStreamCreateWithFlags(&side[k], hipStreamNonBlocking));
         else side[k] = side[k % n_side];            // levels share streams (in-order per stream: fork/join events keep it correct)
         PA_CHECK(hipEventCreateWithFlags(&ev_fork[k], hipEventDisableTiming));
         PA_CHECK(hipEventCreateWithFlags(&ev_join[k], hipEventDisableTiming));
     }
-    if (!getenv("PA_NO_WSTREAM")) {
+    if (!pa_getenv("PA_NO_WSTREAM")) {
         PA_CHECK(hipStreamCreateWithFlags(&wstream, hipStreamNonBlocking));
         wstreams[0] = wstream;
-        if (const char* e = getenv("PA_WSTREAMS")) n_w = atoi(e) < 1 ? 1 : (atoi(e) > 4 ? 4 : atoi(e));
+        if (const char* e = pa_getenv("PA_WSTREAMS")) n_w = atoi(e) < 1 ? 1 : (atoi(e) > 4 ? 4 : atoi(e));
         for (int i = 1; i < n_w; ++i) PA_CHECK(hipStreamCreateWithFlags(&wstreams[i], hipStreamNonBlocking));
         for (int i = 0; i < n_w; ++i) PA_CHECK(hipEventCreateWithFlags(&ev_wdone_x[i], hipEventDisableTiming));
         for (int i = 0; i < 16; ++i) PA_CHECK(hipEventCreateWithFlags(&ev_w[i], hipEventDisableTiming));

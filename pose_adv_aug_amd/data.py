@@ -11,6 +11,7 @@ A `DeviceBatch` holds MPII-shape annotations for B people:
 """
 import torch
 
+from . import _lib
 from ._lib import lib, check, ptr, stream, require_gpu
 from .pylib import HumanAug
 
@@ -20,7 +21,7 @@ class DeviceBatch(object):
         """sizes: optional [B][2] (width, height) of each person's own image when the frames are padded to a common size
         (real MPII images); index: optional dataset indices of the samples (validation predictions are stored by index)."""
         require_gpu()
-        dev = torch.device('cuda', torch.cuda.current_device())
+        dev = _lib.device()
         self.frames = frames.to(dev).contiguous()
         B, Hs, Ws, _ = self.frames.shape
         self.B, self.Hs, self.Ws = B, Hs, Ws

@@ -14,6 +14,7 @@ from collections import OrderedDict
 import numpy as np
 import torch
 
+from .. import _lib
 from .._lib import lib, check, ptr, stream, require_gpu, PoseAdvError
 
 
@@ -51,7 +52,7 @@ class _HipModule(object):
             h = self._create(B)
             if not h:
                 raise PoseAdvError('network creation failed: %s' % L.pa_last_error().decode())
-            dev = torch.device('cuda', torch.cuda.current_device())
+            dev = _lib.device()
             if self._table is None:
                 self._table = self._read_table(h)
                 self.flat_params = torch.zeros(L.pa_net_param_floats(h), dtype=torch.float32, device=dev)

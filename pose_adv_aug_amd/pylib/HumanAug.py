@@ -74,7 +74,7 @@ _CROP_WS = {}
 
 def _crop_workspace(B, Hs, Ws, res):
     """scratch of pa_crop (intermediate images of the staged crop), cached per shape and device"""
-    key = (B, Hs, Ws, res, torch.cuda.current_device())
+    key = (B, Hs, Ws, res, str(dev()))
     ws = _CROP_WS.get(key)
     if ws is None:
         ws = _CROP_WS[key] = torch.empty(lib().pa_crop_workspace_bytes(B, Hs, Ws, res), dtype=torch.uint8, device=dev())
@@ -85,7 +85,7 @@ def crop_batch(frames, params, res=256, want_nchw=False, want_nhwc4=True, want_u
     """device: uint8 frames [B][Hs][Ws][3] + params [B][8] -> network input (bf16 NHWC4) and/or fp32 NCHW and/or the uint8
     crop [B][res][res][3].  crop (pylib/HumanAug.py:117-176: pre-downscale, int-truncated window, PIL rotate, PIL resize)
     behind flip + colour gain (data/mpii_for_mpii.py:126-135), byte-exact against the reference over Pillow."""
-    f = frames if (isinstance(frames, torch.Tensor) and frames.is_cuda) else to_dev(frames, torch.uint8)
+    f = frames if (isinstance(frames, torch.Tensor) and frames.device == dev()) else to_dev(frames, torch.uint8)
     B, Hs, Ws, _ = f.shape
     out4 = torch.empty((B, res, res, 4), dtype=torch.bfloat16, device=dev()) if want_nhwc4 else None
     outf = torch.empty((B, 3, res, res), dtype=torch.float32, device=dev()) if want_nchw else None
@@ -98,7 +98,7 @@ def crop_batch(frames, params, res=256, want_nchw=False, want_nhwc4=True, want_u
 def warp_batch(frames, tinv, params, res=256, want_nchw=False, want_nhwc4=True, sizes=None):
     """device: the PURE inverse-affine bilinear sampler (2 x 2 taps at T^-1(u, v), no pre-filter) -- an operator, not the
     reference's crop pixels (crop_batch is what the loops use)."""
-    f = frames if (isinstance(frames, torch.Tensor) and frames.is_cuda) else to_dev(frames, torch.uint8)
+    f = frames if (isinstance(frames, torch.Tensor) and frames.device == dev()) else to_dev(frames, torch.uint8)
     B, Hs, Ws, _ = f.shape
     out4 = torch.empty((B, res, res, 4), dtype=torch.bfloat16, device=dev()) if want_nhwc4 else None
     outf = torch.empty((B, 3, res, res), dtype=torch.float32, device=dev()) if want_nchw else None

@@ -2,12 +2,12 @@
 import numpy as np
 import torch
 
+from .. import _lib
 from .._lib import lib, check, ptr, stream, require_gpu
 
 
 def dev():
-    require_gpu()
-    return torch.device('cuda', torch.cuda.current_device())
+    return _lib.device()
 
 
 def to_dev(x, dtype):

@@ -51,3 +51,73 @@ def test_flat_gradient_allreduce_world2():
     pref = torch.randn(1000, generator=torch.Generator().manual_seed(7))
     ostep.rmsprop_update(pref, ref * 0.5, torch.zeros(1000), 2.5e-4)
     assert torch.allclose(p0, pref)
+
+
+def _main_worker(rank, world, port, exp_dir, out):
+    """stack_hg.main() -- the REAL host control flow -- on 2 gloo ranks with the engine stubbed at the C ABI."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from tests import abi_stub
+    fake = abi_stub.install(rank)
+    orig_ar, orig_save = dist.all_reduce, torch.save
+    saves = []
+
+    def all_reduce(t, op=dist.ReduceOp.SUM, **kw):
+        fake.log.append(('all_reduce', (t.numel(), str(t.dtype))))
+        return orig_ar(t, op=op, **kw)
+
+    def save(obj, path, *a, **kw):
+        saves.append(os.path.basename(path))
+        return orig_save(obj, path, *a, **kw)
+    dist.all_reduce, torch.save = all_reduce, save
+    from pose_adv_aug_amd import stack_hg
+    captured = {}
+    orig_create = stack_hg.create_hg
+
+    def create(*a, **kw):
+        captured['net'] = orig_create(*a, **kw)
+        return captured['net']
+    stack_hg.create_hg = create
+    stack_hg.main(['--exp_dir', exp_dir, '--exp_id', 'dp', '--bs', '2', '--nEpochs', '1', '--is_train', '1', '--print_freq', '2'])
+    net = captured['net']
+    out[rank] = dict(log=[(n, a if n in ('pa_sample_aug', 'pa_rmsprop_step', 'all_reduce', 'pa_net_bind') else None) for n, a in fake.log],
+                     params=net.flat_params.clone(), buffers=net.flat_buffers.clone(), saves=saves)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_training_main_on_two_ranks_with_the_engine_stubbed_at_the_abi(tmp_path):
+    """SURVEY.md section 8e on the real host code (stack_hg.main -> train -> train_step -> RMSprop.step -> validate ->
+    checkpoint): per step every rank runs backward, then ONE all-reduce of the whole flat gradient, then the fused RMSprop
+    with gscale = 1/world on the stream the net was bound to, then the weight re-pack; ranks draw DIFFERENT augmentations
+    (seed + rank, same step counter); replicas stay bit-identical although their shard gradients differ; the logged meters
+    are all-reduced (2 x names numbers, at print time only); rank 0 alone writes checkpoints."""
+    mgr = mp.Manager()
+    out = mgr.dict()
+    port = 29500 + ((os.getpid() + 7) % 500)
+    mp.spawn(_main_worker, args=(2, port, str(tmp_path), out), nprocs=2, join=True)
+    r0, r1 = out[0], out[1]
+    assert torch.equal(r0['params'], r1['params']) and torch.equal(r0['buffers'], r1['buffers'])
+    for r in (r0, r1):
+        names = [n for n, _ in r['log']]
+        steps = [i for i, n in enumerate(names) if n == 'pa_hg_backward']
+        assert len(steps) == 4                                            # 4 synthetic batches, one epoch
+        for k, i in enumerate(steps):
+            end = steps[k + 1] if k + 1 < len(steps) else len(names)
+            seg = names[i:end]
+            ar = [j for j, n in enumerate(seg) if n == 'all_reduce' and r['log'][i + j][1][0] == 40]
+            rp = seg.index('pa_rmsprop_step')
+            assert len(ar) == 1 and 0 < ar[0] < rp < seg.index('pa_net_prepare_weights'), seg[:12]
+            assert 'pa_hg_accuracy' in seg[rp:] and 'pa_hg_pckh' in seg[rp:]                     # metrics after the update (stack-hg.py:176-178)
+        bind_stream = [a for n, a in r['log'] if n == 'pa_net_bind'][0][1]
+        for n, a in r['log']:
+            if n == 'pa_rmsprop_step':
+                assert a[0] == 40 and a[4] == 0.5 and a[5] == bind_stream and abs(a[1] - 2.5e-4) < 1e-12
+        meters = [a for n, a in r['log'] if n == 'all_reduce' and a[0] == 6]
+        assert len(meters) == 4                                           # prints at i = 0, 2 (print_freq 2) and 3 (last) + the epoch's return value
+    s0 = [a for n, a in r0['log'] if n == 'pa_sample_aug']
+    s1 = [a for n, a in r1['log'] if n == 'pa_sample_aug']
+    assert [a[1] for a in s0[:4]] == [1234] * 4 and [a[1] for a in s1[:4]] == [1235] * 4       # seed + rank
+    assert [a[2] for a in s0[:4]] == [0, 1, 2, 3] == [a[2] for a in s1[:4]]
+    assert len(r0['saves']) == 1 and r0['saves'][0].endswith('-0.pth.tar') and r1['saves'] == []
+    files = os.listdir(os.path.join(str(tmp_path), 'dp'))
+    assert any(f.endswith('-0.pth.tar') for f in files) and any(f.endswith('-0-preds.mat') for f in files) and 'train-log.txt' in files
