@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: images/sec of the full stage-1 training step of the 2-stack hourglass
-(BASELINE.json configs[1]: bs = 24 per GPU, 256x256 MPII-shape synthetic input, bf16 storage):
+(BASELINE.json configs[1]: bs = 24 per GPU, 256x256 MPII-shape synthetic input, bf16 storage; configs[4], the deep-stack
+stress case: --stacks 8 --res 384 --bs 16 --dtype fp16):
 
     on-device augmentation law + bilinear warp  ->  forward  ->  Gaussian-target MSE  ->  hand-written
     backward  ->  ONE all-reduce of the flat gradient (RCCL, N > 1)  ->  fused RMSprop + bf16 weight
@@ -97,11 +98,13 @@ def main():
     ap.add_argument('--stacks', type=int, default=2)
     ap.add_argument('--chan', type=int, default=256)
     ap.add_argument('--res', type=int, default=256, help='network input resolution (SURVEY.md C5: --stacks 8 --res 384 --bs 16)')
+    ap.add_argument('--dtype', choices=['bf16', 'fp16'], default='bf16', help='16-bit storage / MFMA operand type (BASELINE configs[4]: fp16)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     args = ap.parse_args()
 
     from pose_adv_aug_amd import _lib
+    _lib.set_dtype(args.dtype)
     from pose_adv_aug_amd.stack_hg import init_distributed, broadcast_parameters, train_step
     from pose_adv_aug_amd.data import Augmenter, DeviceBatch
     from pose_adv_aug_amd.models.asn_stacked_hg import create_hg
@@ -214,10 +217,11 @@ def main():
         line = {'metric': 'images/sec, %d-stack HG %dx%d bs=%d per GPU, full training step' % (args.stacks, res, res, B), 'value': round(value, 2),
                 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
                 'ms_per_step': round(1e3 * dt / args.steps, 3), 'higher_is_better': True, 'scaling': 'weak',
-                'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+                'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
                 'config': {'workload': '%s%d-stack hourglass chan %d, bs=%d/GPU, %dx%d MPII-shape synthetic frames '
                                        '(720x1280 uint8 resident in HBM), on-device HumanAug warp, heat-map MSE, RMSprop, PCKh'
-                                       % ('BASELINE configs[1]: ' if (args.stacks, args.chan, res, B) == (2, 256, 256, 24) else '', args.stacks, args.chan, B, res, res),
+                                       % ('BASELINE configs[1]: ' if (args.stacks, args.chan, res, B, args.dtype) == (2, 256, 256, 24, 'bf16') else
+                                          ('BASELINE configs[4]: ' if (args.stacks, args.chan, res, B, args.dtype) == (8, 256, 384, 16, 'fp16') else ''), args.stacks, args.chan, B, res, res),
                            'global_batch': world * B, 'parallelism': 'dp%d' % world,
                            'loss': float(loss), 'pckh': float(pckh), 'pckh_origin_res': float(pckh_o)},
                 'roofline': roofline, 'cpu_baseline': cpu}

@@ -24,6 +24,12 @@ extern "C" {
 
 const char* pa_last_error(void);
 int pa_version(void);
+/* Which build this is: 0 = bfloat16 storage (libposeadv_hip.so), 1 = IEEE-half storage (libposeadv_hip_fp16.so: "fp16 MFMA
+ * 1x1 convs" of the deep-stack configuration).  Same ABI; "bf16" in the comments below means this 16-bit type.
+ * pa_grad_scale: the factor every fp32 gradient the library returns carries (1 for bf16; the fp16 build runs its backward pass
+ * on scaled gradients so that they stay inside half's range): pass gscale = 1 / (world * pa_grad_scale()) to pa_rmsprop_step. */
+int pa_dtype(void);
+float pa_grad_scale(void);
 
 /* ---------------------------------------------------------------- pose library (pylib/) ---- */
 

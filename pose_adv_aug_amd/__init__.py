@@ -2,6 +2,6 @@
 training with adversarial scale/rotation augmentation as hand-written HIP (gfx950) kernels behind the
 reference's Python surface (models.create_hg / create_asn, pylib.*, utils.Checkpoint, options).
 There is no CPU compute path: importing works anywhere, running needs the HIP library and a GPU."""
-from ._lib import PoseAdvError, build, lib, LIB_PATH, EXPORTS  # noqa: F401
+from ._lib import PoseAdvError, build, lib, LIB_PATH, EXPORTS, set_dtype, act_dtype, grad_scale  # noqa: F401
 
-__all__ = ['PoseAdvError', 'build', 'lib', 'LIB_PATH', 'EXPORTS']
+__all__ = ['PoseAdvError', 'build', 'lib', 'LIB_PATH', 'EXPORTS', 'set_dtype', 'act_dtype', 'grad_scale']

@@ -8,11 +8,42 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libposeadv_hip.so')
+# One storage type per process: bfloat16 (default) or IEEE half (POSEADV_DTYPE=fp16 in the environment BEFORE the first call,
+# or set_dtype('fp16')): two builds of the same sources (csrc/build.sh), see csrc/common.h.
+DTYPE = os.environ.get('POSEADV_DTYPE', 'bf16').lower()
+if DTYPE not in ('bf16', 'fp16'):
+    raise ValueError('POSEADV_DTYPE must be bf16 or fp16')
+LIB_PATH = os.path.join(_HERE, 'libposeadv_hip.so' if DTYPE == 'bf16' else 'libposeadv_hip_fp16.so')
+
+
+def set_dtype(name):
+    """Select the library build ('bf16' / 'fp16') -- only before the library is loaded."""
+    global DTYPE, LIB_PATH
+    name = name.lower()
+    if name not in ('bf16', 'fp16'):
+        raise ValueError('dtype must be bf16 or fp16')
+    if _lib is not None and name != DTYPE:
+        raise PoseAdvError('the %s library is already loaded in this process' % DTYPE)
+    DTYPE = name
+    LIB_PATH = os.path.join(_HERE, 'libposeadv_hip.so' if name == 'bf16' else 'libposeadv_hip_fp16.so')
+
+
+def act_dtype():
+    """torch dtype of the library's 16-bit activations (network input NHWC4, operator-level tensors)"""
+    return torch.bfloat16 if DTYPE == 'bf16' else torch.float16
+
+
+def grad_scale():
+    """Factor carried by every gradient the loaded library returns (1 for bf16; the fp16 build runs its backward pass on
+    scaled gradients); the optimizer divides it out."""
+    return float(lib().pa_grad_scale())
 
 
 class PoseAdvError(RuntimeError):
     pass
+
+
+_lib = None
 
 
 def build(verbose=False):
@@ -27,13 +58,14 @@ def build(verbose=False):
     return LIB_PATH
 
 
-_lib = None
 
 _vp, _i, _f, _sz, _u64 = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_uint64
 
 _PROTOS = {
     'pa_last_error': (C.c_char_p, []),
     'pa_version': (_i, []),
+    'pa_grad_scale': (_f, []),
+    'pa_dtype': (_i, []),
     'pa_gaussian_heatmap': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     'pa_weighted_l2': (_i, [_vp, _vp, _vp, _sz, _vp, _vp]),
     'pa_get_preds': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
@@ -112,6 +144,8 @@ def lib():
             fn = getattr(l, name)
             fn.restype = res
             fn.argtypes = args
+        if l.pa_dtype() != (0 if DTYPE == 'bf16' else 1):
+            raise PoseAdvError('%s is not the %s build' % (LIB_PATH, DTYPE))
         _lib = l
     return _lib
 

@@ -19,6 +19,8 @@ struct pa_net { Net n; };
 extern "C" {
 
 const char* pa_last_error(void) { return g_err; }
+float pa_grad_scale(void) { return PA_GRAD_SCALE; }
+int pa_dtype(void) { return PA_DTYPE_ID; }
 int pa_version(void) { return 1; }
 
 int pa_gaussian_heatmap(const double* pts, float* out, int B, int J, int H, int W, void* s) {

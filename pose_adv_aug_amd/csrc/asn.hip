@@ -106,7 +106,7 @@ __global__ void asn_head_bwd_kernel(const float* probs, const float* target_s, c
         }
         for (int k = 0; k < kn; ++k) {
             const float g = -t[k] / ((float)B * (p[k] + leps));
-            const float dz = p[k] * (g - gp);
+            const float dz = PA_GRAD_SCALE * (p[k] * (g - gp));     // (fp16 build: scaled gradients, common.h)
             sm[k0 + k] = dz;
             dlogits[(size_t)b * K + k0 + k] = dz;
         }
@@ -165,14 +165,14 @@ __global__ void asn_mask_head_bwd_kernel(PaOperand x, const float* dlogits, cons
             float v = (float)x.p[(size_t)r * C + c];
             if (x.mode == PA_LD_BNRELU) v = fmaxf(fmaf(x.k0[c], v, x.k1[c]), 0.f);
             acc = fmaf(dlogits[r], v, acc);
-            dact[(size_t)r * C + c] = (bf16)(dlogits[r] * wc);
+            dact[(size_t)r * C + c] = (bf16)(PA_GRAD_SCALE * dlogits[r] * wc);
         }
-        dw[c] = acc;
+        dw[c] = PA_GRAD_SCALE * acc;
     }
     if (threadIdx.x == 0) {
         float s = 0.f;
         for (int r = 0; r < rows; ++r) s += dlogits[r];
-        db[0] = s;
+        db[0] = PA_GRAD_SCALE * s;
     }
 }
 

@@ -1,19 +1,26 @@
 #!/bin/bash
-# Build libposeadv_hip.so for gfx950 (MI355X) in-tree.  hipcc cross-compiles without a GPU.
+# Build libposeadv_hip.so (bf16 storage) and libposeadv_hip_fp16.so (IEEE-half storage, -DPA_FP16) for gfx950 (MI355X) in-tree.
+# hipcc cross-compiles without a GPU.  PA_TUNING=1: compile the A/B environment switches in (tools/sweep_env.sh); the default
+# (release) build reads no environment.
 set -e
 cd "$(dirname "$0")"
-mkdir -p ../build
-# PA_TUNING=1: compile the A/B environment switches in (tools/sweep_env.sh); the default (release) build has none
-FLAGS=""
-if [ -n "$PA_TUNING" ]; then FLAGS="-DPA_TUNING"; fi
-if [ "$(cat ../build/.flags 2>/dev/null)" != "$FLAGS" ]; then rm -f ../build/*.o; echo "$FLAGS" > ../build/.flags; fi
-OBJS=""
-for f in conv_igemm conv3x3_tile conv1x1_tile conv_wgrad conv_wgrad_tile elementwise pose_ops crop_warp net asn api; do
-  if [ ! -f ../build/$f.o ] || [ $f.hip -nt ../build/$f.o ] || [ common.h -nt ../build/$f.o ] || [ kernels.h -nt ../build/$f.o ] || [ conv_epilogue.h -nt ../build/$f.o ] || [ net.h -nt ../build/$f.o ] || [ pose_ops.h -nt ../build/$f.o ] || [ ../../include/poseadv.h -nt ../build/$f.o ]; then
-    hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $FLAGS -c $f.hip -o ../build/$f.o &
-  fi
-  OBJS="$OBJS ../build/$f.o"
-done
-wait
-hipcc --offload-arch=gfx950 -shared -fPIC $OBJS -o ../libposeadv_hip.so
-echo "built $(cd .. && pwd)/libposeadv_hip.so"
+SRCS="conv_igemm conv3x3_tile conv1x1_tile conv_wgrad conv_wgrad_tile elementwise pose_ops crop_warp net asn api"
+build_variant() {      # $1 = object directory, $2 = extra flags, $3 = library name
+  local dir=$1 flags=$2 lib=$3
+  mkdir -p $dir
+  if [ -n "$PA_TUNING" ]; then flags="$flags -DPA_TUNING"; fi
+  if [ "$(cat $dir/.flags 2>/dev/null)" != "$flags" ]; then rm -f $dir/*.o; echo "$flags" > $dir/.flags; fi
+  local objs=""
+  for f in $SRCS; do
+    local o=$dir/$f.o
+    if [ ! -f $o ] || [ $f.hip -nt $o ] || [ common.h -nt $o ] || [ kernels.h -nt $o ] || [ conv_epilogue.h -nt $o ] || [ net.h -nt $o ] || [ pose_ops.h -nt $o ] || [ ../../include/poseadv.h -nt $o ]; then
+      hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $flags -c $f.hip -o $o &
+    fi
+    objs="$objs $o"
+  done
+  wait
+  hipcc --offload-arch=gfx950 -shared -fPIC $objs -o ../$lib
+  echo "built $(cd .. && pwd)/$lib"
+}
+build_variant ../build "" libposeadv_hip.so
+build_variant ../build_fp16 "-DPA_FP16" libposeadv_hip_fp16.so

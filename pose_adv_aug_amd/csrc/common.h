@@ -4,10 +4,29 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// The 16-bit STORAGE / MFMA-operand type of this build of the library (accumulation, statistics, master weights are fp32
+// in both): bfloat16 (libposeadv_hip.so, the default: BASELINE configs[1-3]) or IEEE half (libposeadv_hip_fp16.so, built
+// from the same sources with -DPA_FP16: BASELINE configs[4] "fp16 MFMA 1x1 convs").  The type keeps the name `bf16` in the
+// sources; nothing below depends on its bit layout.  fp16 has 5 exponent bits: the backward pass runs on gradients
+// multiplied by PA_GRAD_SCALE at their origin (heat-map / agent-logit gradients), every fp32 gradient the library
+// returns carries that factor, and the optimizer divides it out (pa_grad_scale(), gscale of pa_rmsprop_step).
+#ifdef PA_FP16
+typedef _Float16 bf16;
+typedef _Float16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 bf16x2 __attribute__((ext_vector_type(2)));
+#define PA_MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0)
+#define PA_GRAD_SCALE 32768.f
+#define PA_DTYPE_ID 1
+#else
 typedef __bf16 bf16;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+#define PA_MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
+#define PA_GRAD_SCALE 1.f
+#define PA_DTYPE_ID 0
+#endif
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 

@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256, (TW == 16 ? (TH == 4 ? 3 : 2) : 1)) void conv3
             for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi)
-                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[ni], fa[mi], acc[ni][mi], 0, 0, 0);
+                    acc[ni][mi] = PA_MFMA_16x16x32(fw[ni], fa[mi], acc[ni][mi]);
         }
     }
     __syncthreads();            // every wave is done with the halo and the ring before the epilogue reuses the LDS

@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(PaWgradArgs a) {
                 for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
                     for (int ki = 0; ki < KI; ++ki)
-                        acc[ni][ki] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fq[ki], fp[ni], acc[ni][ki], 0, 0, 0);
+                        acc[ni][ki] = PA_MFMA_16x16x32(fq[ki], fp[ni], acc[ni][ki]);
             }
             __syncthreads();
             if (step + 1 < step1) {

@@ -238,7 +238,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile_kernel(PaWgradArgs a, int n
                     bf16x8 fx = tr8(xT + row * PWL * CB, xoff[t % 3][0], xoff[t % 3][1]);
 #pragma unroll
                     for (int f = 0; f < NF; ++f)
-                        acc[t][0][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fx, fd[f], acc[t][0][f], 0, 0, 0);
+                        acc[t][0][f] = PA_MFMA_16x16x32(fx, fd[f], acc[t][0][f]);
                 }
             }
         } else {
@@ -252,7 +252,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile_kernel(PaWgradArgs a, int n
                     bf16x8 fx = wg_tr_frag<CB>(xT, wc * CF + cf, [&](int kl) { return 32 * ks + kl; });
 #pragma unroll
                     for (int f = 0; f < NF; ++f)
-                        acc[0][cf][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fx, fd[f], acc[0][cf][f], 0, 0, 0);
+                        acc[0][cf][f] = PA_MFMA_16x16x32(fx, fd[f], acc[0][cf][f]);
                 }
             }
         }

@@ -710,7 +710,7 @@ int Net::forward_pose(const float* img_nchw, const bf16* img4_in, const double* 
 int Net::backward_pose() {
     TRY(ensure_streams());
     const int Hh = res / 4;
-    const float gscale = 1.f / ((float)B * 16.f * (float)Hh * (float)Hh);
+    const float gscale = PA_GRAD_SCALE / ((float)B * 16.f * (float)Hh * (float)Hh);      // (fp16 build: scaled gradients, common.h)
     for (int i = stacks - 1; i >= 0; --i) {
         const bool inner = i + 1 < stacks;
         if (inner) {

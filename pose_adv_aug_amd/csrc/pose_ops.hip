@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(PaOperand in, const bf16*
                         for (int j = 0; j < 8; ++j) fa[j] = (bf16)0.f;
                     }
                     bf16x8 fw = *reinterpret_cast<const bf16x8*>(ws + pl * WS + c);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw, fa, acc, 0, 0, 0);
+                    acc = PA_MFMA_16x16x32(fw, fa, acc);
                 }
             }
         }

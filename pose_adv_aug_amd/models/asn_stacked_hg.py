@@ -101,6 +101,7 @@ class _HipModule(object):
         return [p for _, p in self.named_parameters()]
 
     def named_grads(self):
+        """views into flat_grads; they carry _lib.grad_scale() (1 for the bf16 build)"""
         self._ensure_table()
         for name, shape, off, numel, kind in self._table:
             if kind == 0:
@@ -353,7 +354,7 @@ def dropout(x, masks):
     it inside pa_hg_forward): the [B][1][4][4] cell mask, nearest-upsampled to the map, times every channel."""
     B, Cc, H, W = x.shape
     pad = (-Cc) % 8
-    xh = torch.nn.functional.pad(x.permute(0, 2, 3, 1), (0, pad)).to(torch.bfloat16).contiguous()
+    xh = torch.nn.functional.pad(x.permute(0, 2, 3, 1), (0, pad)).to(_lib.act_dtype()).contiguous()
     out = torch.empty_like(xh)
     m = masks.to(x.device, torch.float32).reshape(B, 16).contiguous()
     check(lib().pa_cell_mask(ptr(xh), ptr(m), ptr(out), B, H, W, Cc + pad, stream()), 'pa_cell_mask')

@@ -1,5 +1,6 @@
 """pylib/HumanAug.py of the reference, on the GPU: similarity transforms, joint transforms and the
 scale/rotation crop (pre-downscale, window, rotate, resize: the reference's own pixel pipeline) on the device."""
+from .. import _lib
 from ._dev import lib, check, ptr, stream, dev, to_dev, np, torch
 
 FLIP_PAIRS = ((0, 5), (1, 4), (2, 3), (10, 15), (11, 14), (12, 13))          # pylib/HumanAug.py:241-244
@@ -87,7 +88,7 @@ def crop_batch(frames, params, res=256, want_nchw=False, want_nhwc4=True, want_u
     behind flip + colour gain (data/mpii_for_mpii.py:126-135), byte-exact against the reference over Pillow."""
     f = frames if (isinstance(frames, torch.Tensor) and frames.device == dev()) else to_dev(frames, torch.uint8)
     B, Hs, Ws, _ = f.shape
-    out4 = torch.empty((B, res, res, 4), dtype=torch.bfloat16, device=dev()) if want_nhwc4 else None
+    out4 = torch.empty((B, res, res, 4), dtype=_lib.act_dtype(), device=dev()) if want_nhwc4 else None
     outf = torch.empty((B, 3, res, res), dtype=torch.float32, device=dev()) if want_nchw else None
     out8 = torch.empty((B, res, res, 3), dtype=torch.uint8, device=dev()) if want_u8 else None
     check(lib().pa_crop(ptr(f), Hs, Ws, ptr(sizes), ptr(params), B, res, ptr(_crop_workspace(B, Hs, Ws, res)), ptr(out4), ptr(outf),
@@ -100,7 +101,7 @@ def warp_batch(frames, tinv, params, res=256, want_nchw=False, want_nhwc4=True, 
     reference's crop pixels (crop_batch is what the loops use)."""
     f = frames if (isinstance(frames, torch.Tensor) and frames.device == dev()) else to_dev(frames, torch.uint8)
     B, Hs, Ws, _ = f.shape
-    out4 = torch.empty((B, res, res, 4), dtype=torch.bfloat16, device=dev()) if want_nhwc4 else None
+    out4 = torch.empty((B, res, res, 4), dtype=_lib.act_dtype(), device=dev()) if want_nhwc4 else None
     outf = torch.empty((B, 3, res, res), dtype=torch.float32, device=dev()) if want_nchw else None
     if sizes is not None:
         check(lib().pa_affine_warp_bilinear_sized(ptr(f), Hs, Ws, ptr(sizes), ptr(tinv), ptr(params), B, res, ptr(out4), ptr(outf),

@@ -5,6 +5,7 @@ nn.DataParallel's broadcast/gather/reduce_add, stack-hg.py:49)."""
 import torch
 import torch.distributed as dist
 
+from .. import _lib
 from .._lib import lib, check, ptr, stream
 
 
@@ -30,7 +31,7 @@ class RMSprop(object):
 
     def step(self):
         g = self.param_groups[0]
-        gscale = self.allreduce_grads()
+        gscale = self.allreduce_grads() / _lib.grad_scale()          # 1/world, and the fp16 build's gradient scale divided out
         n = self.net.flat_params.numel()
         check(lib().pa_rmsprop_step(ptr(self.net.flat_params), ptr(self.net.flat_grads), ptr(self.square_avg), n,
                                     float(g['lr']), float(g['alpha']), float(g['eps']), float(gscale), stream()),

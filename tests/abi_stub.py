@@ -33,6 +33,12 @@ class FakeLib(object):
     def pa_last_error(self):
         return b'stub'
 
+    def pa_grad_scale(self):
+        return 1.0
+
+    def pa_dtype(self):
+        return 0
+
     def pa_hg_create(self, *a):
         self.log.append(('pa_hg_create', a))
         self.nets[len(self.nets) + 1] = {}
