@@ -106,7 +106,7 @@ def main():
     from pose_adv_aug_amd import _lib
     _lib.set_dtype(args.dtype)
     from pose_adv_aug_amd.stack_hg import init_distributed, broadcast_parameters, train_step
-    from pose_adv_aug_amd.data import Augmenter, DeviceBatch
+    from pose_adv_aug_amd.data import AugmentAhead, Augmenter, DeviceBatch
     from pose_adv_aug_amd.models.asn_stacked_hg import create_hg
     from pose_adv_aug_amd.utils.optim import RMSprop
 
@@ -129,10 +129,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    ahead = AugmentAhead(aug)
+
     def run(n):
+        """n steps of stack_hg.train's loop body: the NEXT batch's augmentation (law + crop + joints, all inside the timed
+        region) is enqueued one step ahead on its own stream, like the reference's DataLoader workers"""
         out = None
+        ahead.start(batches[0])
         for i in range(n):
-            out = train_step(net, opt, aug, batches[i % len(batches)])
+            data = ahead.take()
+            ahead.start(batches[(i + 1) % len(batches)] if i + 1 < n else None)
+            out = train_step(net, opt, aug, batches[i % len(batches)], data=data)
         return out
 
     run(args.warmup)

@@ -128,3 +128,53 @@ class Augmenter(object):
         p[:, 0:3] = batch.meta[:, 0:3].double()
         p[:, 5:8] = 1.0
         return self._finish(batch, want_nchw)
+
+
+class AugmentAhead(object):
+    """The reference's DataLoader workers prepare batch i + 1 while batch i trains (stack-hg.py:73-77, num_workers); here the
+    device augmentation of the NEXT batch (law, crop, joint transform: ~10 small launches, ~0.2 ms) is enqueued on its own
+    stream and overlaps the current step's forward pass instead of sitting in front of it.
+
+        ahead = AugmentAhead(augmenter); ahead.start(first_batch)
+        for batch, nxt in pairs:  data = ahead.take(); ahead.start(nxt); train_step(..., data=data)
+    """
+
+    def __init__(self, augmenter, kind='regular'):
+        self.augmenter, self.kind = augmenter, kind
+        self.stream = torch.cuda.Stream() if _lib.device().type == 'cuda' else None     # (None: the ABI-stub tests of the host flow)
+        self.pending = None
+
+    def start(self, batch):
+        if batch is None:
+            self.pending = None
+            return
+        if self.stream is None:
+            self.pending = getattr(self.augmenter, self.kind)(batch)
+            return
+        with torch.cuda.stream(self.stream):
+            self.pending = getattr(self.augmenter, self.kind)(batch)
+
+    def take(self):
+        data = self.pending
+        self.pending = None
+        if self.stream is None:
+            return data
+        main = torch.cuda.current_stream()
+        main.wait_stream(self.stream)
+        for v in data.values():
+            if isinstance(v, torch.Tensor):
+                v.record_stream(main)              # allocated on the augmentation stream, consumed on the caller's
+        return data
+
+
+def with_next(batches):
+    """(batch, next batch or None) pairs of a feed"""
+    it = iter(batches)
+    try:
+        cur = next(it)
+    except StopIteration:
+        return
+    for nxt in it:
+        yield cur, nxt
+        cur = nxt
+    yield cur, None

@@ -10,7 +10,7 @@ from collections import OrderedDict
 import torch
 import torch.distributed as dist
 
-from .data import Augmenter, BatchFeed, DeviceBatch, num_samples
+from .data import AugmentAhead, Augmenter, BatchFeed, DeviceBatch, num_samples, with_next
 from .models.asn_stacked_hg import create_hg
 from .utils.optim import RMSprop
 from .utils.util import AverageMeter, DeviceMeters, PoseTrainHistory, adjust_lr
@@ -41,9 +41,11 @@ def broadcast_parameters(net):
         net.weights_changed()
 
 
-def train_step(net, optimizer, augmenter, batch, want_pckh=True):
-    """stack-hg.py:134-180 for one batch.  Returns device scalars (loss, pckh, pckh_origin_res)."""
-    data = augmenter.regular(batch)
+def train_step(net, optimizer, augmenter, batch, want_pckh=True, data=None):
+    """stack-hg.py:134-180 for one batch.  Returns device scalars (loss, pckh, pckh_origin_res).
+    data: the batch's augmented input if it was prepared ahead (data.AugmentAhead), else it is made here."""
+    if data is None:
+        data = augmenter.regular(batch)
     loss, _ = net.loss_and_backward(img4=data['img4'], pts=data['pts'])
     optimizer.step()
     if not want_pckh:
@@ -59,8 +61,13 @@ def train(batches, net, optimizer, augmenter, epoch, opt, log=print):
     net.train()
     n = len(batches)
     meters = None
-    for i, batch in enumerate(batches):
-        loss, pckh, pckh_o = train_step(net, optimizer, augmenter, batch)
+    ahead = AugmentAhead(augmenter)
+    for i, (batch, nxt) in enumerate(with_next(batches)):
+        if i == 0:
+            ahead.start(batch)
+        data = ahead.take()
+        ahead.start(nxt)                                   # the next batch's crop runs beside this step's forward pass
+        loss, pckh, pckh_o = train_step(net, optimizer, augmenter, batch, data=data)
         if meters is None:
             meters = DeviceMeters(('loss', 'pckh', 'pckh_origin_res'), loss.device)
         meters.update({'loss': loss, 'pckh': pckh, 'pckh_origin_res': pckh_o})

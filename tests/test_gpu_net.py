@@ -363,3 +363,31 @@ def test_network_step_stays_inside_its_workspace():
         assert bool((big[:SL] == 0x5A).all()) and bool((big[SL + nws:] == 0x5A).all())
     assert bool(torch.isfinite(loss).all()) and bool(torch.isfinite(keep_p[1]).all()) and bool(torch.isfinite(keep_a[1]).all())
     L.pa_net_destroy(hp); L.pa_net_destroy(ha)
+
+
+def test_augmentation_one_step_ahead_changes_nothing():
+    """stack_hg.train / bench.py enqueue the NEXT batch's augmentation on a side stream one step ahead (data.AugmentAhead):
+    same draws, same crops, same parameters after 4 steps -- bitwise -- as augmenting in front of every step."""
+    from pose_adv_aug_amd.models.asn_stacked_hg import create_hg
+    from pose_adv_aug_amd.utils.optim import RMSprop
+    from pose_adv_aug_amd.data import AugmentAhead, Augmenter, DeviceBatch
+    from pose_adv_aug_amd.stack_hg import train_step
+    batches = [DeviceBatch.synthetic(4, seed=k) for k in range(2)]
+    finals = []
+    for mode in ('inline', 'ahead'):
+        net = create_hg(1, 1, 16, 128, default_batch=4); net.reset_parameters(seed=3); net.train()
+        opt = RMSprop(net, lr=2.5e-4)
+        aug = Augmenter(seed=9)
+        ahead = AugmentAhead(aug)
+        if mode == 'ahead':
+            ahead.start(batches[0])
+        for i in range(4):
+            data = None
+            if mode == 'ahead':
+                data = ahead.take()
+                ahead.start(batches[(i + 1) % 2] if i < 3 else None)
+            loss, _, _ = train_step(net, opt, aug, batches[i % 2], data=data)
+        torch.cuda.synchronize()
+        finals.append((net.flat_params.clone(), net.flat_buffers.clone(), float(loss)))
+    assert torch.equal(finals[0][0], finals[1][0]) and torch.equal(finals[0][1], finals[1][1])
+    assert abs(finals[0][2] - finals[1][2]) < 1e-6 * abs(finals[0][2])        # (the reported loss is summed with one float atomic per workgroup)
