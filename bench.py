@@ -99,6 +99,7 @@ def main():
     ap.add_argument('--chan', type=int, default=256)
     ap.add_argument('--res', type=int, default=256, help='network input resolution (SURVEY.md C5: --stacks 8 --res 384 --bs 16)')
     ap.add_argument('--dtype', choices=['bf16', 'fp16'], default='bf16', help='16-bit storage / MFMA operand type (BASELINE configs[4]: fp16)')
+    ap.add_argument('--graph', type=int, default=0, help='1: forward + backward replayed from a captured HIP graph (pa_hg_train_step)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     args = ap.parse_args()
@@ -118,6 +119,7 @@ def main():
     B, res = args.bs, args.res
     net = create_hg(args.stacks, 1, 16, args.chan, res=res, default_batch=B)
     net.reset_parameters(seed=0)
+    net.use_graph = bool(args.graph)
     broadcast_parameters(net)
     opt = RMSprop(net, lr=2.5e-4, alpha=0.99, eps=1e-8)
     aug = Augmenter(seed=100 + rank, inp_res=res, out_res=res // 4)
@@ -159,6 +161,7 @@ def main():
         h = net._net(B)
         # per-kernel durations are taken with the engine's side streams off: with them on, launches of independent
         # branches overlap and a launch's event interval contains other kernels' work
+        net.use_graph = False
         _lib.check(_lib.lib().pa_net_set_multi_stream(h, 0))
         _lib.check(_lib.lib().pa_net_profile_begin(h))
         run(args.steps)

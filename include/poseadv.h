@@ -205,6 +205,13 @@ int pa_hg_heatmap_nchw(pa_net* net, int stack, float* out);
 /* loss.backward() (stack-hg.py:164): fills the flat gradient array bound with pa_net_bind */
 int pa_hg_backward(pa_net* net);
 
+/* pa_hg_forward(img4, pts) + pa_hg_backward in ONE call (stack-hg.py:153-164 without the optimizer).  use_graph != 0: the
+ * ~650 launches of the two passes (main stream + the engine's side / weight-gradient streams, their fork / join events as
+ * edges) are captured into a HIP graph on the first call and replayed afterwards; img4 / pts are copied into the engine's
+ * own input buffers first (the graph's pointers are fixed).  Not available while dropout masks are set or the launch
+ * profiler runs.  The gradient lands in the bound flat array; loss_per_stack (device, [num_stacks]) may be NULL. */
+int pa_hg_train_step(pa_net* net, const void* img4, const double* pts, int train, int use_graph, float* loss_per_stack);
+
 /* Half-hourglass forward (models/asn_stacked_hg.py:300-304 with is_half_hg): stem + the down path of
  * hg[0] up to the neck -- everything the agent reads.  train != 0 updates the BatchNorm running
  * statistics of those layers, as the reference does on the agent-augmentation steps (Appendix A.9);

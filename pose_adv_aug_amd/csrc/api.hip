@@ -437,6 +437,7 @@ size_t pa_net_workspace_bytes(const pa_net* net) { return net->n.workspace_bytes
 int pa_net_bind(pa_net* net, float* params, float* grads, float* buffers, void* workspace, void* s) {
     g_err[0] = 0;
     Net& n = net->n;
+    n.release_graph();                    // (a captured step holds the old pointers)
     n.params = params; n.grads = grads; n.buffers = buffers; n.workspace = reinterpret_cast<char*>(workspace); n.st = ST(s);
     if (n.is_agent) n.layout_asn(n.workspace); else n.layout_all(n.workspace);
     TRY(n.upload_tables());
@@ -461,6 +462,22 @@ int pa_hg_heatmap_nchw(pa_net* net, int stack, float* out) {
 }
 
 int pa_hg_backward(pa_net* net) { g_err[0] = 0; TRY(net->n.backward_pose()); return 0; }
+
+int pa_hg_train_step(pa_net* net, const void* img4, const double* pts, int train, int use_graph, float* loss_per_stack) {
+    g_err[0] = 0;
+    Net& n = net->n;
+    if (!img4 || !pts) { pa_set_error_msg("pa_hg_train_step: img4 and pts are required"); return 1; }
+    if (!use_graph) {
+        TRY(n.forward_pose(nullptr, reinterpret_cast<const bf16*>(img4), pts, train != 0, loss_per_stack));
+        return n.backward_pose();
+    }
+    // the graph reads the engine's own input buffers: bring the caller's tensors there first (12.6 MB + 6 KB at B = 24)
+    if (img4 != n.img4) PA_CHECK(hipMemcpyAsync(n.img4, img4, (size_t)n.B * n.res * n.res * 4 * sizeof(bf16), hipMemcpyDeviceToDevice, n.st));
+    if (pts != n.pts_dev) PA_CHECK(hipMemcpyAsync(n.pts_dev, pts, (size_t)n.B * n.classes * 2 * sizeof(double), hipMemcpyDeviceToDevice, n.st));
+    TRY(n.train_step_graph(train != 0));
+    if (loss_per_stack) PA_CHECK(hipMemcpyAsync(loss_per_stack, n.loss_dev, n.stacks * sizeof(float), hipMemcpyDeviceToDevice, n.st));
+    return 0;
+}
 
 int pa_hg_accuracy(pa_net* net, int stack, const int32_t* idxs, int nidx, float* acc, float* scratch) {
     g_err[0] = 0;
@@ -519,6 +536,7 @@ int pa_net_profile_classes(const pa_net* net, int32_t* out, int cap) {
 
 int pa_net_set_multi_stream(pa_net* net, int on) {
     if (net->n.ensure_streams()) return 1;
+    net->n.release_graph();
     net->n.multi_stream = on != 0 && net->n.side[0] != nullptr;
     return 0;
 }

@@ -167,6 +167,11 @@ struct Net {
     int record_join(int k);                    // mark the end of the work enqueued on side[k]
     int wait_join(int k);                      // st waits for that mark
     Prof prof;
+    // forward + loss + backward of the training step captured ONCE into a HIP graph (fork / join events of the side and
+    // weight-gradient streams become graph edges) and replayed: pa_hg_train_step with use_graph
+    hipGraph_t step_graph = nullptr; hipGraphExec_t step_exec = nullptr; int step_key = -1;
+    int train_step_graph(bool train);
+    void release_graph();
     bool train_bn = true;
     int bn_update = 1;                         // 0: use batch statistics without touching the running estimates
     float momentum = 0.1f, eps = 1e-5f;

@@ -8,6 +8,9 @@
 // (the round-1 timing experiment that removed cross-stream waits -- wrong results by design -- is gone from the library)
 static const int g_nosync = 0;
 static bool nosync() { return false; }
+// PA_ABLATE=<mask> (tuning builds only; results are WRONG, timing bounds only): 1 no slab reductions, 2 no weight-gradient
+// launches, 4 no BatchNorm finalize launches, 8 no 3x3 convolutions, 16 no 1x1 data gradients
+static int ablate() { static int v = -1; if (v < 0) { const char* e = pa_getenv("PA_ABLATE"); v = e ? atoi(e) : 0; } return v; }
 #define TRY(x) do { int _r = (x); if (_r) return _r; } while (0)
 
 PaOperand pa_plain(const bf16* p) { PaOperand o; o.p = p; o.q = nullptr; o.k0 = o.k1 = o.k2 = nullptr; o.mode = PA_LD_PLAIN; return o; }
@@ -329,12 +332,14 @@ PaEpilogue Net::final_ep(const Act& a) const {
 
 int Net::finish_grad(const Act& a) {
     if (!a.bn) return 0;
+    if (ablate() & 4) return 0;
     BNLayer* b = a.bn;
     return pa_launch_bn_bwd_finalize(b->bstats, b->bstat_rows, b->scale, b->mean, b->invstd, b->kA, b->kB, b->kC, grads + b->p_gamma,
                                      grads + b->p_beta, b->C, (float)a.M(), st);
 }
 
 int Net::finish_grad2(const Act& a, const Act& b) {
+    if (ablate() & 4) return 0;
     if (!a.bn || !b.bn) { TRY(finish_grad(a)); return finish_grad(b); }
     BNLayer *x = a.bn, *y = b.bn;
     return pa_launch_bn_bwd_finalize2(x->bstats, x->bstat_rows, x->scale, x->mean, x->invstd, x->kA, x->kB, x->kC, grads + x->p_gamma, grads + x->p_beta,
@@ -353,10 +358,10 @@ int Net::conv_fwd(ConvLayer& c, const PaOperand& in, int B_, int H, int W, const
     double wb, wf; conv_work(B_ * H * W, c.k == 7 ? 147 : c.Cin, c.Cout, c.k == 7 ? 1 : c.taps(), false, wb, wf);
     if (c.k == 7) wb = 2.0 * B_ * (4.0 * H * W * 4 + (double)H * W * 64) + 2.0 * 64 * 147;      // image read once (4-ch padded) + output
     ProfEntry* pe = prof.begin(c.k == 7 ? PA_PROF_STEM_FWD : (c.k == 3 ? PA_PROF_FWD3 : PA_PROF_FWD1), wb, wf, st);
-    int rc = (c.k == 7) ? pa_launch_stem_conv(a, st) : pa_launch_conv(a, st);
+    int rc = (c.k == 3 && (ablate() & 8)) ? 0 : ((c.k == 7) ? pa_launch_stem_conv(a, st) : pa_launch_conv(a, st));
     prof.end(pe, st);
     TRY(rc);
-    if (bn_after && train_bn)
+    if (bn_after && train_bn && !(ablate() & 4))
         TRY(pa_launch_bn_finalize(bn_after->stats, bn_after->stat_rows, params + bn_after->p_gamma, params + bn_after->p_beta,
                                   buffers + bn_after->b_rmean, buffers + bn_after->b_rvar, bn_after->scale, bn_after->shift,
                                   bn_after->mean, bn_after->invstd, bn_after->C, (float)(B_ * H * W), momentum, eps, bn_update, st));
@@ -378,6 +383,7 @@ int Net::conv_dgrad(ConvLayer& c, const PaOperand& dy, int B_, int H, int W, con
     }
     double wb, wf; conv_work(B_ * H * W, c.Cin, c.Cout, c.taps(), false, wb, wf);
     ProfEntry* pe = prof.begin(c.k == 3 ? PA_PROF_DGRAD3 : PA_PROF_DGRAD1, wb, wf, st);
+    if ((c.k == 3 && (ablate() & 8)) || (c.k == 1 && (ablate() & 16))) { if (a.ep.rows_out) *a.ep.rows_out = 1; prof.end(pe, st); return 0; }
     int rc = pa_launch_conv(a, st);
     prof.end(pe, st);
     return rc;
@@ -390,6 +396,7 @@ int Net::conv_wgrad(ConvLayer& c, const PaOperand& dy, const PaOperand& x, int B
     double wb, wf; conv_work(B_ * H * W, c.k == 7 ? 147 : c.Cin, c.Cout, c.k == 7 ? 1 : c.taps(), true, wb, wf);
     if (c.k == 7) wb = 2.0 * B_ * (4.0 * H * W * 4 + (double)H * W * 64) + 4.0 * 64 * 147;
     const int cls = c.k == 7 ? PA_PROF_STEM_WGRAD : (c.k == 3 ? PA_PROF_WGRAD3 : PA_PROF_WGRAD1);
+    if (ablate() & 2) return 0;
     if (multi_stream && wstream) {        // deferred: flush_wgrads() launches it on the weight-gradient stream
         PendingWgrad p; p.a = a; p.cls = cls; p.bytes = wb; p.flops = wf; p.stem = c.k == 7; p.c = &c;
         pending_wgrads.push_back(p);
@@ -434,7 +441,7 @@ int Net::flush_wgrads() {
             }
         }
     }
-    if (reduce_early && !immediate_reduce) {                    // the group's slabs are summed while they are still in the Infinity Cache
+    if (reduce_early && !immediate_reduce && !(ablate() & 1)) {                    // the group's slabs are summed while they are still in the Infinity Cache
         int lo = 1 << 30, hi = -1, cnt = 0, mx = 0;
         for (PendingWgrad& p : pending_wgrads) {
             if (p.stem) {
@@ -634,6 +641,7 @@ int Net::ensure_streams() {
     return 0;
 }
 void Net::release_streams() {
+    release_graph();
     for (int k = 0; k < 4; ++k) {
         if (side[k]) {
             if (k < n_side) { (void)hipStreamSynchronize(side[k]); (void)hipStreamDestroy(side[k]); }
@@ -749,6 +757,47 @@ int Net::backward_pose() {
     TRY(finish_grad(a0));
     TRY(conv_wgrad(stem_conv, gradop(a0), pa_plain(cur_image), B, res / 2, res / 2));
     return reduce_grads();
+}
+
+// One training step (forward, loss, backward) as a HIP graph.  Inputs live in the engine's own buffers (img4, pts_dev:
+// the caller copies into them on `st` before the launch), every pointer and shape inside is fixed by the layout, so the
+// graph is captured once per (mode, bound memory) and replayed.  The capture runs the normal enqueue code: the side streams
+// fork from / join into `st` by events, which the capture turns into graph dependencies.
+int Net::train_step_graph(bool train) {
+    TRY(ensure_streams());
+    const int key = (train ? 1 : 0) | (multi_stream ? 2 : 0);
+    if (drop_mask || prof.on) { pa_set_error_msg("train_step_graph: not with the occlusion branch / the launch profiler"); return 1; }
+    if (!step_exec || step_key != key) {
+        release_graph();
+        // the caller's stream may be the legacy default stream, which cannot capture: capture on a stream of our own
+        hipStream_t cap = nullptr, caller = st;
+        PA_CHECK(hipStreamCreateWithFlags(&cap, hipStreamNonBlocking));
+        st = cap;
+        hipError_t e = hipStreamBeginCapture(cap, hipStreamCaptureModeRelaxed);
+        if (e != hipSuccess) { st = caller; (void)hipStreamDestroy(cap); pa_set_error("hipStreamBeginCapture", e, __FILE__, __LINE__); return (int)e; }
+        int rc = forward_pose(nullptr, img4, pts_dev, train, nullptr);
+        if (!rc) rc = backward_pose();
+        hipGraph_t g = nullptr;
+        e = hipStreamEndCapture(cap, &g);
+        st = caller;
+        (void)hipStreamDestroy(cap);
+        if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
+        if (e != hipSuccess) { pa_set_error("hipStreamEndCapture", e, __FILE__, __LINE__); return (int)e; }
+        step_graph = g;
+        PA_CHECK(hipGraphInstantiate(&step_exec, step_graph, nullptr, nullptr, 0));
+        step_key = key;
+    }
+    train_bn = train;
+    cur_image = img4;
+    heat_peak_valid.assign(stacks, 0);
+    PA_CHECK(hipGraphLaunch(step_exec, st));
+    return 0;
+}
+
+void Net::release_graph() {
+    if (step_exec) { (void)hipGraphExecDestroy(step_exec); step_exec = nullptr; }
+    if (step_graph) { (void)hipGraphDestroy(step_graph); step_graph = nullptr; }
+    step_key = -1;
 }
 
 int Net::reduce_grads() {

@@ -268,6 +268,8 @@ class HourglassNet(_HipModule):
             outs.append(o)
         return outs
 
+    use_graph = False        # loss_and_backward(img4=...) replays a captured HIP graph of forward + backward (pa_hg_train_step)
+
     def loss_and_backward(self, x=None, pts=None, img4=None, want_outputs=False, dropout_masks=None):
         """One pass of stack-hg.py:153-164 without the optimizer: forward in the current mode, loss
         sum_stacks mean((out - gaussian(pts))^2) with the target generated on the fly from `pts`
@@ -278,6 +280,11 @@ class HourglassNet(_HipModule):
         self._last_B = B
         p = pts.to(torch.float64).contiguous()
         losses = torch.empty(self.num_stacks, dtype=torch.float32, device=self.flat_params.device)      # the engine copies every entry
+        if self.use_graph and x is None and dropout_masks is None:
+            check(lib().pa_hg_train_step(h, ptr(img4), ptr(p), 1 if self.training else 0, 1, ptr(losses)), 'pa_hg_train_step')
+            if self.training:
+                self._nbt += 1
+            return losses.sum(), (self.heatmaps(B) if want_outputs else None)
         keep = self._set_masks(h, dropout_masks)
         try:
             check(lib().pa_hg_forward(h, ptr(x.contiguous().float()) if x is not None else None, ptr(img4), ptr(p),

@@ -391,3 +391,27 @@ def test_augmentation_one_step_ahead_changes_nothing():
         finals.append((net.flat_params.clone(), net.flat_buffers.clone(), float(loss)))
     assert torch.equal(finals[0][0], finals[1][0]) and torch.equal(finals[0][1], finals[1][1])
     assert abs(finals[0][2] - finals[1][2]) < 1e-6 * abs(finals[0][2])        # (the reported loss is summed with one float atomic per workgroup)
+
+
+@pytest.mark.parametrize('stacks,chan,B', [(1, 128, 4), (2, 256, 24)])
+def test_hip_graph_replay_equals_eager_enqueue(stacks, chan, B):
+    """pa_hg_train_step(use_graph=1): forward + backward captured once into a HIP graph (side / weight-gradient streams as
+    graph branches) and replayed -- bitwise the parameters, running statistics and gradients of the eager launch sequence,
+    over 4 steps on changing inputs (the capture happens at step 0, steps 1-3 are replays)."""
+    from pose_adv_aug_amd.models.asn_stacked_hg import create_hg
+    from pose_adv_aug_amd.utils.optim import RMSprop
+    from pose_adv_aug_amd.data import Augmenter, DeviceBatch
+    from pose_adv_aug_amd.stack_hg import train_step
+    batches = [DeviceBatch.synthetic(B, seed=40 + k) for k in range(2)]
+    finals = []
+    for graph in (False, True):
+        net = create_hg(stacks, 1, 16, chan, default_batch=B); net.reset_parameters(seed=3); net.train()
+        net.use_graph = graph
+        opt = RMSprop(net, lr=2.5e-4)
+        aug = Augmenter(seed=9)
+        for i in range(4):
+            loss, pckh, pckh_o = train_step(net, opt, aug, batches[i % 2])
+        torch.cuda.synchronize()
+        finals.append((net.flat_params.clone(), net.flat_buffers.clone(), net.flat_grads.clone(), float(loss), float(pckh_o)))
+    assert torch.equal(finals[0][0], finals[1][0]) and torch.equal(finals[0][1], finals[1][1]) and torch.equal(finals[0][2], finals[1][2])
+    assert abs(finals[0][3] - finals[1][3]) < 1e-6 * abs(finals[0][3]) and finals[0][4] == finals[1][4]
