@@ -10,7 +10,7 @@ JSON record fields used (data/mpii_for_mpii.py:29-4
   dataset ('MPII'), isValidation, img_paths, joint_self [16][3], objpos [2], scale_provided, normalizer."""
 import json
 import os
-from concurrent.futures import ThreadPoolExecutor
+from concurrent.futures import ProcessPoolExecutor, ThreadPoolExecutor
 
 import numpy as np
 import torch
@@ -77,11 +77,13 @@ class MPII(object):
         return DeviceBatch(frames, np.stack([r[2] for r in recs]), np.asarray([r[3] for r in recs]),
                            np.stack([r[1] for r in recs]), np.asarray([r[4] for r in recs]), sizes=sizes, index=list(indices))
 
-    def batches(self, batch_size, shuffle=None, seed=0, drop_last=False, workers=8, rank=0, world=1):
+    def batches(self, batch_size, shuffle=None, seed=0, drop_last=False, workers=8, rank=0, world=1, decoder='thread'):
         """A sized BatchFeed over the split (shuffle defaults to is_train, stack-hg.py:73-83): len() = number of batches,
         every iter() is one pass in a fresh order (seed + pass number); the next batch is decoded by a thread pool
         (PIL releases the GIL while decoding) while the caller trains on the current one.  Data parallel: all ranks draw
-        the SAME order and rank r takes batches r, r + world, ... (equal counts on every rank)."""
+        the SAME order and rank r takes batches r, r + world, ... (equal counts on every rank).
+        decoder: 'thread' (PIL drops the GIL inside the JPEG decoder) or 'process' (the reference's DataLoader workers,
+        stack-hg.py:75 num_workers: decoded frames come back through a pipe; no GIL at all)."""
         from .data import BatchFeed
         n = len(self)
         nb_all = n // batch_size if drop_last else (n + batch_size - 1) // batch_size
@@ -95,7 +97,10 @@ class MPII(object):
             passes[0] += 1
             chunks = [order[i:i + batch_size].tolist() for i in range(0, n, batch_size)][:nb_all]
             chunks = chunks[rank::world][:nb] if world > 1 else chunks
-            with ThreadPoolExecutor(max_workers=max(1, workers)) as pool, ThreadPoolExecutor(max_workers=1) as ahead:
+            import multiprocessing as mp
+            make_pool = (lambda: ProcessPoolExecutor(max_workers=max(1, workers), mp_context=mp.get_context('spawn'))) if decoder == 'process' \
+                else (lambda: ThreadPoolExecutor(max_workers=max(1, workers)))
+            with make_pool() as pool, ThreadPoolExecutor(max_workers=1) as ahead:
                 fut = ahead.submit(self.load_batch, chunks[0], pool) if chunks else None
                 for k in range(len(chunks)):
                     batch = fut.result()
