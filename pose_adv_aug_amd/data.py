@@ -40,6 +40,12 @@ class DeviceBatch(object):
         self.normalizer = torch.as_tensor(normalizer, dtype=torch.float32).to(dev).contiguous()
         self.params = torch.zeros(B, 8, dtype=torch.float64, device=dev)
 
+    def record_stream(self, stream):
+        """the batch was built on another stream (an asynchronous feeder): tell the allocator who consumes it"""
+        for t in (self.frames, self.meta, self.joints, self.normalizer, self.params, self.sizes):
+            if t is not None and t.is_cuda:
+                t.record_stream(stream)
+
     @staticmethod
     def synthetic(B, seed=0, Hs=720, Ws=1280):
         """MPII-shape synthetic people."""

@@ -36,7 +36,7 @@ def make_dataset(root, n):
 
 
 def main():
-    n = int(sys.argv[1]) if len(sys.argv) > 1 else 240
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 960
     from pose_adv_aug_amd.mpii_for_mpii import MPII
     from pose_adv_aug_amd.models.asn_stacked_hg import create_hg
     from pose_adv_aug_amd.utils.optim import RMSprop
@@ -47,8 +47,11 @@ def main():
     path = make_dataset(root, n)
     ds = MPII(path, root, is_train=True, log=lambda m: None)
     print('host: %d cores (%s)' % (os.cpu_count(), open('/proc/cpuinfo').read().split('model name')[1].split('\n')[0].strip(': \t')))
-    for decoder, workers in (('thread', 8), ('thread', 32), ('process', 16), ('process', 32)):
+    for decoder, workers in (('thread', 8), ('thread', 32), ('process', 32), ('process', 64), ('process', 96)):
         feed = ds.batches(24, shuffle=False, drop_last=True, workers=workers, decoder=decoder)
+        if decoder == 'process':
+            for b in feed:                                   # first pass forks the pool and page-locks the slots
+                pass
         t0 = time.perf_counter(); cnt = 0
         for b in feed:
             cnt += b.B
@@ -58,12 +61,13 @@ def main():
     opt_ = RMSprop(net, lr=2.5e-4)
     aug = Augmenter(seed=1)
     opt = types.SimpleNamespace(print_freq=10 ** 9)
-    feed = ds.batches(24, shuffle=True, drop_last=True, workers=32, decoder='process')
+    feed = ds.batches(24, shuffle=True, drop_last=True, workers=64, decoder='process')
+    print('frame slots page-locked:', ds._frame_slots(24, 64, 6).pinned)
     stack_hg.train(feed, net, opt_, aug, 0, opt, log=lambda m: None)                   # warm-up pass (pools, kernels)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     stack_hg.train(feed, net, opt_, aug, 1, opt, log=lambda m: None)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
-    print('stack_hg.train over MPII.batches (process pool, 32 workers): %.1f img/s fed (%d images, %.2f s)' % (feed.num_samples / dt, feed.num_samples, dt))
+    print('stack_hg.train over MPII.batches (64 forked decode workers, 6 batches in flight): %.1f img/s fed (%d images, %.2f s)' % (feed.num_samples / dt, feed.num_samples, dt))
     resident = list(feed)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     stack_hg.train(resident, net, opt_, aug, 2, opt, log=lambda m: None)
