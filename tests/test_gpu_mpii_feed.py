@@ -79,3 +79,37 @@ def test_padded_batch_equals_single_image_batches(tmp_path):
         d1 = aug._finish(single)
         assert torch.equal(d1['img4'][0], data['img4'][k]), k
         assert torch.equal(d1['pts'][0], data['pts'][k]) and torch.equal(d1['grnd_pts'][0], data['grnd_pts'][k]), k
+
+
+def test_process_pool_feed_equals_thread_feed_and_drives_train(tmp_path):
+    """decoder='process' (forked workers decoding into shared page-locked frame slots, several batches in flight, copies on
+    their own stream) yields the same batches as the thread feeder -- indices, sizes, annotations, and every pixel inside each
+    sample's own frame -- over two passes (slots are reused), and stack_hg.train / validate run from the sized feed
+    (len(), enumerate, num_samples) like the reference's loops from their DataLoader (stack-hg.py:133,183)."""
+    import types
+    from pose_adv_aug_amd.mpii_for_mpii import MPII
+    from pose_adv_aug_amd.models.asn_stacked_hg import create_hg
+    from pose_adv_aug_amd.utils.optim import RMSprop
+    from pose_adv_aug_amd.data import Augmenter
+    from pose_adv_aug_amd import stack_hg
+    path, anno, sizes = _make_dataset(tmp_path, n=7)
+    ds = MPII(path, str(tmp_path), is_train=True, log=lambda *_: None)
+    ft = ds.batches(2, shuffle=False, decoder='thread')
+    fp = ds.batches(2, shuffle=False, decoder='process', workers=3, prefetch=2)
+    assert len(ft) == len(fp) == 2 and fp.num_samples == 4
+    for _ in range(2):
+        for a, b in zip(ft, fp):
+            assert a.index == b.index and torch.equal(a.sizes, b.sizes) and torch.equal(a.meta, b.meta)
+            assert torch.equal(a.joints, b.joints) and torch.equal(a.normalizer, b.normalizer)
+            for k in range(a.B):
+                w, h = a.sizes[k].tolist()
+                assert torch.equal(a.frames[k, :h, :w], b.frames[k, :h, :w]), (a.index, k)
+    net = create_hg(1, 1, 16, 128, default_batch=2); net.reset_parameters(seed=0)
+    opt = RMSprop(net, lr=2.5e-4)
+    o = types.SimpleNamespace(print_freq=1)
+    lines = []
+    tl, tp = stack_hg.train(fp, net, opt, Augmenter(seed=1), 0, o, log=lines.append)
+    assert len(lines) == 2 and lines[0].startswith('epoch:0, iters:0/2 loss: ') and np.isfinite(tl)
+    va = MPII(path, str(tmp_path), is_train=False, log=lambda *_: None).batches(2, decoder='process', workers=2, prefetch=2)
+    vl, vp, preds = stack_hg.validate(va, net, Augmenter(seed=2), 0, o, log=lambda m: None)
+    assert preds.shape == (3, 16, 2) and np.isfinite(vl)
