@@ -12,12 +12,19 @@ reference file:line it follows (paths relative to the reference checkout).
 
 How it is pinned: the reference has no tests, golden vectors or fixtures of
 its own, and it is Python-2 / torch-0.3 source that cannot
-be imported as-is.  ``tools/make_goldens.py`` transliterates the reference
+be imported as-is.  ``tests/golden/make_goldens.py`` transliterates the reference
 into ``/tmp`` (lib2to3 + integer-division fixes, nothing committed), imports
 it in the build container and writes small input/output vectors to
 ``tests/golden/*.npz``.  ``tests/test_oracle_golden.py`` checks this oracle
-against every one of those vectors.  The one exception is the image warp
-(``HumanAug.crop``): its pixels depend on an unpinned scipy.misc/PIL pair, so
-for that row only the *geometry* is pinned exactly and pixel parity is
-"parity unpinned" (tolerance test against a PIL shim) -- see DESIGN.md.
+against every one of those vectors.  The image crop (``HumanAug.crop``) delegates
+its pixels to scipy.misc (< 1.3) over PIL, both absent from the reference tree and
+unpinned by it: the generator restates the three thin scipy wrappers over the REAL
+Pillow of the build container (12.2) and runs the reference's own crop();
+``oracle/crop.py`` restates the wrappers and Pillow's resampling arithmetic in numpy
+and must reproduce those outputs byte for byte (it does) -- see DESIGN.md section 2.
+Restatements WITHOUT a reference fixture (the reference's scripts cannot be imported
+even transliterated): ``step.py`` -- the loop bodies of stack-hg.py,
+joint-train-pose-s-r-agent.py (train_agent_sr) and the stage-2 scripts; they are
+compositions of pinned pieces (model, losses, PCKh, gen_groundtruth) in the
+reference's order, each line citing the script line it follows.
 """
