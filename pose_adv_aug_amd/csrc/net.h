@@ -161,6 +161,10 @@ struct Net {
     std::vector<PendingWgrad> pending_wgrads;
     int flush_every = 1, flush_ctr = 0; bool on_side = false;   // main-stream blocks flush every flush_every-th time (PA_WFLUSH_EVERY)
     int flush_wgrads();                        // record on `st`, make wstream wait, launch the collected weight gradients
+    // hold the weight gradients of an hourglass' high-resolution levels back until its backward pass reaches level `hold_level`
+    // (the low-resolution stretch, where the main chain leaves the GPU almost empty): 0 = off
+    int hold_level = 0; bool hold = false;
+    int release_held(int k);
     int ensure_streams();
     void release_streams();                    // destroys the side streams / events (pa_net_destroy)
     int fork_to(int k);                        // side[k] waits for everything enqueued on st so far

@@ -419,8 +419,17 @@ int Net::conv_wgrad(ConvLayer& c, const PaOperand& dy, const PaOperand& x, int B
 
 // Operands of the collected launches are final on `st` at this point (their producers were enqueued before).  The
 // gradient buffers they read are written once per step, so deferring a launch is always safe.
+int Net::release_held(int k) {
+    if (!hold) return 0;
+    hold = false;
+    hipStream_t ws = wstreams[w_rr];
+    for (int kk = 0; kk < k && kk < 4; ++kk)          // the held groups of the skip branches: their operands are final at ev_join[kk]
+        if (forks(kk)) PA_CHECK(hipStreamWaitEvent(ws, ev_join[kk], 0));
+    return flush_wgrads();
+}
+
 int Net::flush_wgrads() {
-    if (pending_wgrads.empty()) return 0;
+    if (pending_wgrads.empty() || hold) return 0;
     hipStream_t ws = wstreams[w_rr]; w_rr = (w_rr + 1) % n_w;
     if (!(nosync() && (g_nosync & 4))) {
         hipEvent_t ev = ev_w[ev_w_next]; ev_w_next = (ev_w_next + 1) & 15;
@@ -573,7 +582,9 @@ int Hourglass::decode(Net& n) {
 // precondition: merged[0].grad holds the finished (plain) gradient of the hourglass output.
 // extra0: gradient reaching the hourglass INPUT from consumers outside the hourglass.
 int Hourglass::bwd(Net& n, const Act& in, const PaOperand& extra0) {
+    if (n.hold_level > 0 && n.multi_stream && n.wstream) n.hold = true;
     for (int k = 0; k < 4; ++k) {
+        if (k == n.hold_level) TRY(n.release_held(k));
         const Act& m = merged[k];
         if (n.drop_mask) {              // the skip tensor entered the sum through the cell mask: d skip = mask * d (masked skip)
             TRY(pa_launch_upadd_bwd(m.grad, n.final_ep(up[k].x3), up[k].x3.grad, ep_plain(), skipm[k].grad, m.B, m.H, m.W, m.C, n.st));
@@ -596,6 +607,7 @@ int Hourglass::bwd(Net& n, const Act& in, const PaOperand& extra0) {
         const Act& x = neck.x3;
         TRY(pa_launch_cell_mask(pa_plain(neckm.grad), n.drop_mask, n.final_ep(x), x.grad, x.B, x.H, x.W, x.C, n.st));
     }
+    TRY(n.release_held(4));
     TRY(n.finish_grad(neck.x3));
     TRY(neck.bwd(n, down[3].x3, pa_none(), true));
     TRY(n.finish_grad(down[3].x3));
@@ -622,6 +634,7 @@ int Net::ensure_streams() {
     if (const char* e = pa_getenv("PA_SIDE_STREAMS")) n_side = atoi(e) < 1 ? 1 : (atoi(e) > 4 ? 4 : atoi(e));
     reduce_early = pa_getenv("PA_WREDUCE_LATE") == nullptr;
     if (const char* e = pa_getenv("PA_WFLUSH_EVERY")) flush_every = atoi(e) > 0 ? atoi(e) : 1;
+    if (const char* e = pa_getenv("PA_WHOLD")) hold_level = atoi(e);
     for (int k = 0; k < 4; ++k) {
         if (k < n_side) PA_CHECK(hipStreamCreateWithFlags(&side[k], hipStreamNonBlocking));
         else side[k] = side[k % n_side];            // levels share streams (in-order per stream: fork/join events keep it correct)
