@@ -239,7 +239,8 @@ def gen_nets(R):
                         grads=np.concatenate([p.grad.flatten().numpy() for p in blk.parameters()]),
                         running=np.concatenate([b.flatten().float().numpy() for b in blk.buffers()]))
     # --- small 1-stack net: every gradient and the post-RMSprop parameters (a2,a3,a6,a19)
-    for tag, (stacks, chan, seed) in {'hg_s1c8': (1, 8, 31), 'hg_s2c16': (2, 16, 32)}.items():
+    # hg_s1c128: a width the HIP engine runs (chan % 128 == 0): the engine is compared with THIS reference output directly
+    for tag, (stacks, chan, seed) in {'hg_s1c8': (1, 8, 31), 'hg_s2c16': (2, 16, 32), 'hg_s1c128': (1, 128, 33)}.items():
         net = M.create_hg(num_stacks=stacks, num_modules=1, num_classes=16, chan=chan)
         deterministic_fill_(net, seed=seed)
         net.train()
@@ -265,6 +266,11 @@ def gen_nets(R):
                    nparams=np.array(sum(p.numel() for p in net.parameters())))
         if tag == 'hg_s1c8':
             rec['grads'] = np.concatenate([g.flatten().numpy() for g in grads])
+        if tag == 'hg_s1c128':                   # the output layers' gradients in full (the engine is compared with them)
+            names = [n for n, _ in net.named_parameters()]
+            rec['head_names'] = np.array([n for n in names if n.startswith('out_conv.0.') or n.startswith('linear.0.1.')])
+            rec['head_grads'] = np.concatenate([g.flatten().numpy() for n, g in zip(names, grads)
+                                                if n.startswith('out_conv.0.') or n.startswith('linear.0.1.')])
         # eval-mode forward with the updated running stats
         net.eval()
         with torch.no_grad():
@@ -396,6 +402,9 @@ if __name__ == '__main__':
     R = load_ref()
     if len(sys.argv) > 1 and sys.argv[1] == 'crop':
         gen_crop(R)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'nets':
+        gen_nets(R)
         sys.exit(0)
     gen_pylib(R)
     gen_nets(R)

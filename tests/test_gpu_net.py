@@ -5,6 +5,7 @@ Tolerances (stated per check): activations are stored in bf16 (8 mantissa bits, 
 between every convolution, so after ~100 layers outputs agree to a few 1e-2 of their RMS; gradients
 likewise.  rel_rms(a, b) = rms(a - b) / rms(b)."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -471,3 +472,34 @@ def test_training_trajectory_tracks_the_oracle_over_150_steps():
     assert abs(a_dev - a_ref) <= 0.12 and abs(v_dev - v_ref) / v_ref < 0.2, (a_ref, a_dev, v_ref, v_dev)
     # ... and the engine's own metric kernel on its own maps says the same as the oracle code on those maps
     assert abs(float(net.accuracy(idx)[0]) - a_dev) < 1e-4
+
+
+def test_engine_against_the_reference_golden_directly():
+    """tests/golden/hg_s1c128.npz holds the outputs of the REFERENCE's own modules (transliterated, make_goldens.py) for a
+    width the engine runs: 1-stack, chan 128, B = 2, 128x128, deterministic weights.  The engine is compared with those
+    arrays directly (no oracle in between): train-mode heat maps (bf16 storage: 15 % of their RMS, as in the oracle tests),
+    loss 1 %, heat-map PCK equal, the output layers' gradients 5 % / cosine .998, eval-mode heat maps after the step."""
+    from pose_adv_aug_amd.models.asn_stacked_hg import create_hg
+    from pose_adv_aug_amd.utils.optim import RMSprop
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'hg_s1c128.npz'))
+    ref = om.create_hg(1, 1, 16, 128)                 # (only the carrier of the deterministic weights and the parameter names)
+    om.deterministic_fill_(ref, seed=33)
+    net = create_hg(1, 1, 16, 128, res=128, default_batch=2)
+    net.load_state_dict(ref.state_dict())
+    assert net.num_params() == int(g['nparams'])
+    img = t(inputs.images(133, 2, 128)); pts = inputs.heat_pts(233, 2, res=32)
+    heat = t(inputs.heatmaps_from_pts(pts, res=32))
+    net.train()
+    opt = RMSprop(net, lr=2.5e-4, alpha=0.99, eps=1e-8)
+    loss, outs = net.loss_and_backward(img.cuda(), t(pts).cuda(), want_outputs=True)
+    assert abs(float(loss) - float(g['loss'])) / float(g['loss']) < 1e-2
+    assert rel_rms(outs[0].cpu(), t(g['out'][0])) < 0.15
+    acc = net.accuracy([0, 1, 2, 3, 4, 5, 10, 11, 14, 15]).cpu().numpy()
+    assert np.allclose(acc, opl.accuracy(outs[0].cpu(), heat, [0, 1, 2, 3, 4, 5, 10, 11, 14, 15]).numpy(), atol=1e-4)
+    grads = dict(net.named_grads())
+    mine = torch.cat([grads[str(n)].flatten().cpu() for n in g['head_names']])
+    assert rel_rms(mine, t(g['head_grads'])) < 5e-2 and cosine(mine, t(g['head_grads'])) > 0.998
+    opt.step()
+    net.eval()
+    oe = net(img.cuda())
+    assert rel_rms(oe[0].cpu(), t(g['out_eval'][0])) < 0.15

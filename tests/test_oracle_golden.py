@@ -123,7 +123,7 @@ def test_residual_block():
     assert np.allclose(np.concatenate([b.flatten().float().numpy() for b in blk.buffers()]), g['running'], atol=1e-6)
 
 
-@pytest.mark.parametrize('tag,stacks,chan,seed', [('hg_s1c8', 1, 8, 31), ('hg_s2c16', 2, 16, 32)])
+@pytest.mark.parametrize('tag,stacks,chan,seed', [('hg_s1c8', 1, 8, 31), ('hg_s2c16', 2, 16, 32), ('hg_s1c128', 1, 128, 33)])
 def test_hourglass_train_step(tag, stacks, chan, seed):
     g = load(tag + '.npz')
     torch.set_num_threads(8)
@@ -142,6 +142,11 @@ def test_hourglass_train_step(tag, stacks, chan, seed):
     assert np.allclose(digest(grads), g['grad_digest'], rtol=1e-3, atol=1e-6)
     if 'grads' in g:
         assert np.allclose(np.concatenate([x.flatten().numpy() for x in grads]), g['grads'], rtol=1e-3, atol=1e-7)
+    if 'head_grads' in g:
+        names = [n for n, _ in net.named_parameters()]
+        assert [n for n in names if n.startswith('out_conv.0.') or n.startswith('linear.0.1.')] == list(g['head_names'])
+        mine = np.concatenate([x.flatten().numpy() for n, x in zip(names, grads) if n.startswith('out_conv.0.') or n.startswith('linear.0.1.')])
+        assert np.allclose(mine, g['head_grads'], rtol=1e-3, atol=1e-7)
     # RMSprop's first step is ~ +-10 lr * sign(g): near-zero gradients (biases in front of a
     # BN) are rounding noise whose sign is not reproducible, so compare digests loosely ...
     assert np.allclose(digest([p.detach() for p in net.parameters()])[:, 1], g['param_digest'][:, 1], rtol=2e-2, atol=1e-3)
