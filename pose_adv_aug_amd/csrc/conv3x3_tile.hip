@@ -38,19 +38,36 @@ __device__ __forceinline__ int halo_sw(int p) { return CPP == 16 ? ((p & 7) | ((
 // 16 x 4 (BM = 64 pixels): smaller halo and a ring of 3 slices = 52 KB of LDS -> THREE workgroups per CU, and 1536
 // instead of 768 workgroups for a 24 x 64 x 64 map (2 full rounds): staging, K loop and epilogue of different
 // workgroups overlap instead of running in lockstep.
-template <int CIN, int BN, int LDMODE, int TW = 16, int TH = 8>
-__global__ __launch_bounds__(256, (TW == 16 ? (TH == 4 ? 3 : 2) : 1)) void conv3x3_tile_kernel(PaConvArgs a) {
+// SPS = weight slices consumed per K-loop step (per barrier).  The small problems -- the 8x8 / 4x4 maps (3..12 workgroups on
+// the whole chip) and the 16 x 4 tiles of the 32x32 level (1.5 workgroups per CU) -- are bound by the LATENCY of their 36
+// serial steps (barrier, LDS-DMA wait, fragment reads: ~0.35 us each for 8-16 MFMAs per wave), not by MFMA or memory
+// throughput: with a whole tap (SPS = 4) or half a tap (SPS = 2) per barrier the chain is 9 / 18 steps long.
+template <int N> __device__ __forceinline__ void pa_wait_vmcnt() {
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else static_assert(N == 0, "unsupported vmcnt");
+}
+
+template <int CIN, int BN, int LDMODE, int TW = 16, int TH = 8, int SPS = 1>
+__global__ __launch_bounds__(256, (TW == 16 ? (TH == 4 ? (SPS == 1 ? 3 : 2) : 2) : 1)) void conv3x3_tile_kernel(PaConvArgs a) {
     constexpr int BM = (TW == 16 && TH == 4) ? 64 : 128;
     constexpr int IMG = BM / (TW * TH), PW = TW + 2, PHh = TH + 2, HP = IMG * PHh * PW;   // 180 / 108 / 200 / 288 halo pixels
     constexpr int CPP = CIN / 8;                                         // 16-byte chunks per pixel
     constexpr int NI = BN / 32, MI = BM / 32;
     constexpr int NSL = CIN / 32;                                        // 32-channel weight slices per tap
-    constexpr int NIT = 9 * NSL, NBUF = BM == 64 ? 3 : 4, NIW = BN / 64;  // ring of NBUF slices [BN][32]; glds per wave per slice
-    constexpr int AHEAD = NBUF - 2;                                      // slices still in flight while one is consumed
+    constexpr int NIT = 9 * NSL, NIW = BN / 64;                          // slices [BN][32]; glds per wave per slice
+    constexpr int NST = NIT / SPS, GPT = NSL / SPS;                      // K-loop steps, steps per tap
+    constexpr int NBUF = SPS == 1 ? (BM == 64 ? 3 : 4) : 3;              // ring of NBUF step buffers [SPS][BN][32]
+    constexpr int AHEAD = NBUF - 2;                                      // steps still in flight while one is consumed
+    static_assert(NSL % SPS == 0, "a step stays inside one tap");
     constexpr int PSTEP = 256 / CPP;                                     // halo pixels staged per pass
     constexpr int NPASS = (HP + PSTEP - 1) / PSTEP;
     // ONE shared object (a second one makes hipcc drain vmcnt(0) before every ds_read of the pipeline)
-    __shared__ __attribute__((aligned(16))) bf16 lds[HP * CIN + NBUF * BN * 32];
+    __shared__ __attribute__((aligned(16))) bf16 lds[HP * CIN + NBUF * SPS * BN * 32];
     bf16* halo = lds;
     bf16* wbuf = lds + HP * CIN;
 
@@ -78,11 +95,14 @@ __global__ __launch_bounds__(256, (TW == 16 ? (TH == 4 ? 3 : 2) : 1)) void conv3
         const int slot = lane & 3;
         wsrc[i] = a.w + (size_t)(n0 + pa_weight_row_of_lds_row<BN, NI>(lr)) * K + ((slot ^ ((-(lr >> 2)) & 3)) << 3);
     }
-    auto issue_w = [&](int it) {
-        bf16* dst = wbuf + (it % NBUF) * (BN * 32) + wave * (BN / 4) * 32;
+    auto issue_w = [&](int st) {                       // step st = slices st*SPS .. st*SPS+SPS-1
 #pragma unroll
-        for (int i = 0; i < NIW; ++i)
-            __builtin_amdgcn_global_load_lds(PA_GLOBAL_PTR(wsrc[i] + it * 32), PA_LDS_PTR(dst + i * 16 * 32), 16, 0, 0);
+        for (int j = 0; j < SPS; ++j) {
+            bf16* dst = wbuf + ((st % NBUF) * SPS + j) * (BN * 32) + wave * (BN / 4) * 32;
+#pragma unroll
+            for (int i = 0; i < NIW; ++i)
+                __builtin_amdgcn_global_load_lds(PA_GLOBAL_PTR(wsrc[i] + (st * SPS + j) * 32), PA_LDS_PTR(dst + i * 16 * 32), 16, 0, 0);
+        }
     };
     issue_w(0); issue_w(1);
     if (NBUF == 4) issue_w(2);
@@ -173,8 +193,8 @@ __global__ __launch_bounds__(256, (TW == 16 ? (TH == 4 ? 3 : 2) : 1)) void conv3
         boff[ni] = row * 32 + ((fchk ^ ((-(row >> 2)) & 3)) << 3);
     }
 
-    // K loop: slice `it` is consumed while slices it+1, it+2 are in flight and it+3 is issued right after the barrier
-    // into the buffer that was read in iteration it-1.  Counted vmcnt + raw s_barrier: __syncthreads() would drain
+    // K loop: step `st` is consumed while steps st+1 (, st+2) are in flight and step st+NBUF-1 is issued right after the
+    // barrier into the buffer that was read in step st-1.  Counted vmcnt + raw s_barrier: __syncthreads() would drain
     // the LDS-DMA queue (vmcnt(0)) and expose one L2 round trip per slice, which is what bounded the first version
     // of this kernel (0.7 us per 64-channel slice = 30 % MFMA utilisation).
     for (int tap = 0; tap < 9; ++tap) {
@@ -189,29 +209,32 @@ __global__ __launch_bounds__(256, (TW == 16 ? (TH == 4 ? 3 : 2) : 1)) void conv3
             aoff[mi] = p * CIN + ((fchk ^ halo_sw<CPP>(p)) << 3);
         }
 #pragma unroll
-        for (int sub = 0; sub < NSL; ++sub) {
-            const int it = tap * NSL + sub;
-            const int rem = NIT - 1 - it;                       // slices issued after this one (at most 2 outstanding)
-            const int fly = rem < AHEAD ? rem : AHEAD;          // slices issued after this one that may stay in flight
-            if (fly * NIW == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else if (fly * NIW == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-            else if (fly * NIW == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        for (int g = 0; g < GPT; ++g) {
+            const int st = tap * GPT + g;
+            const int rem = NST - 1 - st;                       // steps issued after this one
+            const int fly = rem < AHEAD ? rem : AHEAD;          // ... that may stay in flight
+            if (fly == 2) pa_wait_vmcnt<2 * SPS * NIW>();
+            else if (fly == 1) pa_wait_vmcnt<SPS * NIW>();
+            else pa_wait_vmcnt<0>();
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            if (it + NBUF - 1 < NIT) issue_w(it + NBUF - 1);
-            const bf16* Bs = wbuf + (it % NBUF) * (BN * 32);
-            bf16x8 fa[MI], fw[NI];
+            if (st + NBUF - 1 < NST) issue_w(st + NBUF - 1);
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-                fa[mi] = *reinterpret_cast<const bf16x8*>(halo + (aoff[mi] ^ ((sub * 4) << 3)));
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni)
-                fw[ni] = *reinterpret_cast<const bf16x8*>(Bs + boff[ni]);
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni)
+            for (int j = 0; j < SPS; ++j) {
+                const int sub = g * SPS + j;
+                const bf16* Bs = wbuf + ((st % NBUF) * SPS + j) * (BN * 32);
+                bf16x8 fa[MI], fw[NI];
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi)
-                    acc[ni][mi] = PA_MFMA_16x16x32(fw[ni], fa[mi], acc[ni][mi]);
+                    fa[mi] = *reinterpret_cast<const bf16x8*>(halo + (aoff[mi] ^ ((sub * 4) << 3)));
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+                    fw[ni] = *reinterpret_cast<const bf16x8*>(Bs + boff[ni]);
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi)
+                        acc[ni][mi] = PA_MFMA_16x16x32(fw[ni], fa[mi], acc[ni][mi]);
+            }
         }
     }
     __syncthreads();            // every wave is done with the halo and the ring before the epilogue reuses the LDS
@@ -225,19 +248,26 @@ __global__ __launch_bounds__(256, (TW == 16 ? (TH == 4 ? 3 : 2) : 1)) void conv3
                                      reinterpret_cast<float*>(lds), (int)blockIdx.x);
 }
 
-template <int CIN, int BN, int TW, int TH>
+template <int CIN, int BN, int TW, int TH, int SPS>
 static void launch_tile_ld(const PaConvArgs& a, dim3 grid, hipStream_t st) {
     switch (a.in.mode) {
-        case PA_LD_PLAIN: hipLaunchKernelGGL((conv3x3_tile_kernel<CIN, BN, PA_LD_PLAIN, TW, TH>), grid, dim3(256), 0, st, a); break;
-        case PA_LD_BNRELU: hipLaunchKernelGGL((conv3x3_tile_kernel<CIN, BN, PA_LD_BNRELU, TW, TH>), grid, dim3(256), 0, st, a); break;
-        default: hipLaunchKernelGGL((conv3x3_tile_kernel<CIN, BN, PA_LD_LIN2, TW, TH>), grid, dim3(256), 0, st, a); break;
+        case PA_LD_PLAIN: hipLaunchKernelGGL((conv3x3_tile_kernel<CIN, BN, PA_LD_PLAIN, TW, TH, SPS>), grid, dim3(256), 0, st, a); break;
+        case PA_LD_BNRELU: hipLaunchKernelGGL((conv3x3_tile_kernel<CIN, BN, PA_LD_BNRELU, TW, TH, SPS>), grid, dim3(256), 0, st, a); break;
+        default: hipLaunchKernelGGL((conv3x3_tile_kernel<CIN, BN, PA_LD_LIN2, TW, TH, SPS>), grid, dim3(256), 0, st, a); break;
     }
 }
 
-template <int TW, int TH>
+// SPS: slices per K-loop step of the latency-bound variants (128 input channels): a whole tap for the 8x8 / 4x4 maps, half a
+// tap for the 16 x 4 tiles; 1 everywhere else (the 16 x 8 tiles of the big maps are throughput-bound and need their LDS for 2
+// workgroups per CU)
+template <int TW, int TH, int SPS>
 static void launch_tile_shape(const PaConvArgs& a, dim3 grid, bool bigN, hipStream_t st) {
-    if (a.Cin == 128) { if (bigN) launch_tile_ld<128, 128, TW, TH>(a, grid, st); else launch_tile_ld<128, 64, TW, TH>(a, grid, st); }
-    else { if (bigN) launch_tile_ld<64, 128, TW, TH>(a, grid, st); else launch_tile_ld<64, 64, TW, TH>(a, grid, st); }
+    if constexpr (TW != 16) {                      // the small maps always run 64-channel halves (bigN is false for them)
+        if (a.Cin == 128) launch_tile_ld<128, 64, TW, TH, SPS>(a, grid, st); else launch_tile_ld<64, 64, TW, TH, 1>(a, grid, st);
+    } else {
+        if (a.Cin == 128) { if (bigN) launch_tile_ld<128, 128, TW, TH, SPS>(a, grid, st); else launch_tile_ld<128, 64, TW, TH, SPS>(a, grid, st); }
+        else { if (bigN) launch_tile_ld<64, 128, TW, TH, 1>(a, grid, st); else launch_tile_ld<64, 64, TW, TH, 1>(a, grid, st); }
+    }
 }
 
 static bool small_map(const PaConvArgs& a) { return (a.H == 8 && a.W == 8) || (a.H == 4 && a.W == 4); }
@@ -271,9 +301,11 @@ int pa_launch_conv3x3_tile(const PaConvArgs& a, hipStream_t st, int* stat_rows) 
     if (xcd < 0) xcd = pa_getenv("PA_CONV3_NOXCD") ? 0 : 1;          // +0.3 % on the step (halo re-reads served by the XCD's own L2)
     PaConvArgs b = a;
     b.xcd = (a.xcd & 2) | ((xcd && !small && tiles % 8 == 0) ? 1 : 0);
-    if (half) launch_tile_shape<16, 4>(b, grid, bigN, st);
-    else if (!small) launch_tile_shape<16, 8>(b, grid, bigN, st);
-    else if (a.H == 8) launch_tile_shape<8, 8>(b, grid, bigN, st);
-    else launch_tile_shape<4, 4>(b, grid, bigN, st);
+    static int sps = -1;
+    if (sps < 0) { const char* e = pa_getenv("PA_CONV3_SPS"); sps = e ? atoi(e) : 1; }      // 0: one slice per step everywhere (round 1)
+    if (half) { if (sps) launch_tile_shape<16, 4, 2>(b, grid, bigN, st); else launch_tile_shape<16, 4, 1>(b, grid, bigN, st); }
+    else if (!small) launch_tile_shape<16, 8, 1>(b, grid, bigN, st);
+    else if (a.H == 8) { if (sps) launch_tile_shape<8, 8, 4>(b, grid, bigN, st); else launch_tile_shape<8, 8, 1>(b, grid, bigN, st); }
+    else { if (sps) launch_tile_shape<4, 4, 4>(b, grid, bigN, st); else launch_tile_shape<4, 4, 1>(b, grid, bigN, st); }
     return (int)hipGetLastError();
 }

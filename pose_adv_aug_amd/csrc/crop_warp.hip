@@ -182,6 +182,10 @@ __global__ void crop_down_h_kernel(const unsigned char* src, int Hs, int Ws, con
     const long total = (long)ncol * nrow;
     const unsigned char* img = src + (size_t)blockIdx.y * Hs * Ws * 3;
     uchar4* out = t1 + (size_t)blockIdx.y * t1_stride;
+    // the byte -> byte map of this sample (fp32 / 255, gain, clamp, toimage: an IEEE division per pixel otherwise), once per block
+    __shared__ unsigned char lut[3][256];
+    for (int k = threadIdx.x; k < 768; k += blockDim.x) lut[k >> 8][k & 255] = (unsigned char)src_byte((unsigned char)(k & 255), P.gain[k >> 8], true);
+    __syncthreads();
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int r = (int)(i / ncol), xc = (int)(i - (long)r * ncol);
         const int* e = tap_entry(table, blockIdx.y, 0, axis_max, xc);
@@ -193,7 +197,7 @@ __global__ void crop_down_h_kernel(const unsigned char* src, int Hs, int Ws, con
                 const int xs = xmin + k;
                 const unsigned char* px = row + (size_t)(P.flip ? P.wb - 1 - xs : xs) * 3;
                 const int w = e[2 + k];
-                a0 += src_byte(px[0], P.gain[0], true) * w; a1 += src_byte(px[1], P.gain[1], true) * w; a2 += src_byte(px[2], P.gain[2], true) * w;
+                a0 += (int)lut[0][px[0]] * w; a1 += (int)lut[1][px[1]] * w; a2 += (int)lut[2][px[2]] * w;
             }
         } else {
             const Taps t = taps_of(P.dx0 + xc, P.wb, P.sx);
