@@ -39,6 +39,7 @@ class DeviceBatch(object):
         self.joints = torch.as_tensor(joints, dtype=torch.float32).to(dev).contiguous()
         self.normalizer = torch.as_tensor(normalizer, dtype=torch.float32).to(dev).contiguous()
         self.params = torch.zeros(B, 8, dtype=torch.float64, device=dev)
+        self.ready = None          # event after which the tensors above are valid on ANY stream (set by asynchronous feeders)
 
     def record_stream(self, stream):
         """the batch was built on another stream (an asynchronous feeder): tell the allocator who consumes it"""
@@ -157,6 +158,10 @@ class AugmentAhead(object):
         if self.stream is None:
             self.pending = getattr(self.augmenter, self.kind)(batch)
             return
+        ready = getattr(batch, 'ready', None)          # an asynchronous feeder's copy event (mpii_for_mpii.MPII.batches)
+        if ready is not None:
+            self.stream.wait_event(ready)
+            batch.record_stream(self.stream)
         with torch.cuda.stream(self.stream):
             self.pending = getattr(self.augmenter, self.kind)(batch)
 

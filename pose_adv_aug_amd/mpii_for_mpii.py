@@ -219,4 +219,5 @@ class MPII(object):
                                 np.stack([r[1] for r in recs]), np.asarray([r[4] for r in recs]), sizes=sizes, index=list(indices))
             ev = torch.cuda.Event()
             ev.record(copy_stream)
+        batch.ready = ev
         return batch, ev, slot
