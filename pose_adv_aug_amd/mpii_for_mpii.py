@@ -137,8 +137,12 @@ class MPII(object):
             h, w = im.shape[0], im.shape[1]
             frames[b, :h, :w] = torch.from_numpy(im)
             sizes[b] = (w, h)
-        return DeviceBatch(frames, np.stack([r[2] for r in recs]), np.asarray([r[3] for r in recs]),
-                           np.stack([r[1] for r in recs]), np.asarray([r[4] for r in recs]), sizes=sizes, index=list(indices))
+        batch = DeviceBatch(frames, np.stack([r[2] for r in recs]), np.asarray([r[3] for r in recs]),
+                            np.stack([r[1] for r in recs]), np.asarray([r[4] for r in recs]), sizes=sizes, index=list(indices))
+        if torch.cuda.is_available():            # the copies from the page-locked staging tensor are asynchronous: consumers on
+            batch.ready = torch.cuda.Event()     # other streams (data.AugmentAhead) wait for this event
+            batch.ready.record()
+        return batch
 
     def batches(self, batch_size, shuffle=None, seed=0, drop_last=False, workers=8, rank=0, world=1, decoder='thread', prefetch=6):
         """A sized BatchFeed over the split (shuffle defaults to is_train, stack-hg.py:73-83): len() = number of batches,
