@@ -6,7 +6,7 @@
  *     pa_last_error() gives the message.  No C++ exception crosses the ABI.
  *   - all pointers are CALLER-OWNED DEVICE pointers unless the name ends in _host; the library
  *     never allocates persistent device memory: a network runs inside one caller-provided workspace
- *     whose size comes from pa_net_workspace_bytes().
+ *     whose size comes from pa_net_workspace_bytes() (cleared by pa_net_bind).
  *   - calls are asynchronous on the given hipStream_t (passed as void*); one host thread per net.
  *   - activations are NHWC bf16 inside the library; the entry points that mirror the reference's
  *     Python signatures take/return NCHW fp32 exactly like the reference's torch tensors.
@@ -187,7 +187,7 @@ size_t pa_net_buffer_floats(const pa_net* net);
 size_t pa_net_workspace_bytes(const pa_net* net);
 
 /* params / grads / buffers: flat fp32 device arrays of pa_net_param_floats / pa_net_buffer_floats;
- * workspace: pa_net_workspace_bytes bytes, ZERO-FILLED by the caller once. */
+ * workspace: pa_net_workspace_bytes bytes; pa_net_bind clears it (no initialisation needed from the caller). */
 int pa_net_bind(pa_net* net, float* params, float* grads, float* buffers, void* workspace, void* stream);
 /* refresh the bf16 compute copies of the weights (after load_state_dict / an optimizer step) */
 int pa_net_prepare_weights(pa_net* net);

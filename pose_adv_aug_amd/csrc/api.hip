@@ -439,7 +439,10 @@ int pa_net_bind(pa_net* net, float* params, float* grads, float* buffers, void* 
     Net& n = net->n;
     n.release_graph();                    // (a captured step holds the old pointers)
     n.params = params; n.grads = grads; n.buffers = buffers; n.workspace = reinterpret_cast<char*>(workspace); n.st = ST(s);
-    if (n.is_agent) n.layout_asn(n.workspace); else n.layout_all(n.workspace);
+    const size_t bytes = n.is_agent ? n.layout_asn(n.workspace) : n.layout_all(n.workspace);
+    // the layout relies on zeros in a few places (padding channels of the 16-channel head tensors, statistic accumulators):
+    // clear the whole workspace here, once, so that the caller does not have to
+    PA_CHECK(hipMemsetAsync(n.workspace, 0, bytes, n.st));
     TRY(n.upload_tables());
     return n.prepare_weights();
 }

@@ -62,7 +62,7 @@ class _HipModule(object):
                     if kind == 1 and name.endswith('running_var'):
                         self.flat_buffers[off:off + numel] = 1.0
                 self.reset_parameters()
-            ws = torch.zeros(L.pa_net_workspace_bytes(h), dtype=torch.uint8, device=dev)
+            ws = torch.empty(L.pa_net_workspace_bytes(h), dtype=torch.uint8, device=dev)       # (pa_net_bind clears it)
             check(L.pa_net_bind(h, ptr(self.flat_params), ptr(self.flat_grads), ptr(self.flat_buffers), ptr(ws), stream()),
                   'pa_net_bind')
             self._nets[B] = (h, ws)               # (binding packs THIS handle's bf16 weights; a pending change still has to reach
