@@ -28,7 +28,8 @@ def init_distributed():
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
-        dist.init_process_group('nccl' if torch.cuda.is_available() else 'gloo', rank=rank, world_size=world)
+        backend = os.environ.get('POSEADV_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')     # nccl = RCCL over xGMI
+        dist.init_process_group(backend, rank=rank, world_size=world)
     return rank, world, local
 
 
