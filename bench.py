@@ -99,6 +99,7 @@ def main():
     ap.add_argument('--chan', type=int, default=256)
     ap.add_argument('--res', type=int, default=256, help='network input resolution (SURVEY.md C5: --stacks 8 --res 384 --bs 16)')
     ap.add_argument('--dtype', choices=['bf16', 'fp16'], default='bf16', help='16-bit storage / MFMA operand type (BASELINE configs[4]: fp16)')
+    ap.add_argument('--overlap', type=int, default=0, help='1 (N > 1): exchange each stack\'s hourglass gradients during the rest of the backward pass (RMSprop(overlap=True))')
     ap.add_argument('--graph', type=int, default=0, help='1: forward + backward replayed from a captured HIP graph (pa_hg_train_step)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
@@ -121,7 +122,7 @@ def main():
     net.reset_parameters(seed=0)
     net.use_graph = bool(args.graph)
     broadcast_parameters(net)
-    opt = RMSprop(net, lr=2.5e-4, alpha=0.99, eps=1e-8)
+    opt = RMSprop(net, lr=2.5e-4, alpha=0.99, eps=1e-8, overlap=bool(args.overlap) and world > 1)
     aug = Augmenter(seed=100 + rank, inp_res=res, out_res=res // 4)
     batches = [DeviceBatch.synthetic(B, seed=rank * 100 + k) for k in range(2)]       # resident in HBM
     net.train()
@@ -232,7 +233,7 @@ def main():
                                        '(720x1280 uint8 resident in HBM), on-device HumanAug warp, heat-map MSE, RMSprop, PCKh'
                                        % ('BASELINE configs[1]: ' if (args.stacks, args.chan, res, B, args.dtype) == (2, 256, 256, 24, 'bf16') else
                                           ('BASELINE configs[4]: ' if (args.stacks, args.chan, res, B, args.dtype) == (8, 256, 384, 16, 'fp16') else ''), args.stacks, args.chan, B, res, res),
-                           'global_batch': world * B, 'parallelism': 'dp%d' % world,
+                           'global_batch': world * B, 'parallelism': 'dp%d' % world + ('+overlapped-exchange' if args.overlap and world > 1 else ''),
                            'loss': float(loss), 'pckh': float(pckh), 'pckh_origin_res': float(pckh_o)},
                 'roofline': roofline, 'cpu_baseline': cpu}
         print(json.dumps(line))

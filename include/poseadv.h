@@ -205,6 +205,19 @@ int pa_hg_heatmap_nchw(pa_net* net, int stack, float* out);
 /* loss.backward() (stack-hg.py:164): fills the flat gradient array bound with pa_net_bind */
 int pa_hg_backward(pa_net* net);
 
+/* loss.backward() in phases, for a data-parallel gradient exchange that overlaps the backward pass:
+ * phase p = 0 .. num_stacks-1 enqueues the backward pass of stack num_stacks-1-p (its head layers, post block and hourglass),
+ * phase num_stacks the stem and the final reductions; all phases in order == pa_hg_backward.
+ * pa_hg_bucket_range: [lo, hi) = the contiguous range of the flat parameter / gradient array that holds hg.<stack> (13
+ * residual blocks: 42 % of a 2-stack net's parameters each).
+ * pa_hg_bucket_wait: call after the phase of `stack`: makes `stream` (the caller's communication stream) wait until every
+ * gradient in that range is final -- the main chain's work so far AND the slab reductions of the engine's weight-gradient
+ * stream.  Returns 0, or -1 if the current stream mode finishes gradients only at the end (exchange everything after the
+ * last phase then). */
+int pa_hg_backward_phase(pa_net* net, int phase);
+int pa_hg_bucket_range(const pa_net* net, int stack, size_t* lo, size_t* hi);
+int pa_hg_bucket_wait(pa_net* net, int stack, void* stream);
+
 /* pa_hg_forward(img4, pts) + pa_hg_backward in ONE call (stack-hg.py:153-164 without the optimizer).  use_graph != 0: the
  * ~650 launches of the two passes (main stream + the engine's side / weight-gradient streams, their fork / join events as
  * edges) are captured into a HIP graph on the first call and replayed afterwards; img4 / pts are copied into the engine's

@@ -111,6 +111,9 @@ _PROTOS = {
     'pa_hg_heatmap_nhwc': (_vp, [_vp, _i]),
     'pa_hg_heatmap_nchw': (_i, [_vp, _i, _vp]),
     'pa_hg_backward': (_i, [_vp]),
+    'pa_hg_backward_phase': (_i, [_vp, _i]),
+    'pa_hg_bucket_range': (_i, [_vp, _i, C.POINTER(_sz), C.POINTER(_sz)]),
+    'pa_hg_bucket_wait': (_i, [_vp, _i, _vp]),
     'pa_hg_train_step': (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     'pa_hg_accuracy': (_i, [_vp, _i, _vp, _i, _vp, _vp]),
     'pa_hg_forward_half': (_i, [_vp, _vp, _vp, _i]),

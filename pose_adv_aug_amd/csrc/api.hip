@@ -466,6 +466,36 @@ int pa_hg_heatmap_nchw(pa_net* net, int stack, float* out) {
 
 int pa_hg_backward(pa_net* net) { g_err[0] = 0; TRY(net->n.backward_pose()); return 0; }
 
+int pa_hg_backward_phase(pa_net* net, int phase) {
+    g_err[0] = 0;
+    Net& n = net->n;
+    if (phase < 0 || phase > n.stacks) { pa_set_error_msg("pa_hg_backward_phase: phase out of range"); return 1; }
+    TRY(n.ensure_streams());
+    if (phase == n.stacks) return n.backward_stem();
+    return n.backward_stack(n.stacks - 1 - phase);
+}
+
+int pa_hg_bucket_range(const pa_net* net, int stack, size_t* lo, size_t* hi) {
+    const Net& n = net->n;
+    char prefix[32]; snprintf(prefix, sizeof prefix, "hg.%d.", stack);
+    size_t a = (size_t)-1, b = 0;
+    for (const TensorInfo& t : n.tensors)
+        if (t.is_buffer == 0 && t.name.compare(0, strlen(prefix), prefix) == 0) { if (t.offset < a) a = t.offset; if (t.offset + t.numel > b) b = t.offset + t.numel; }
+    if (b == 0) { pa_set_error_msg("pa_hg_bucket_range: no such stack"); return 1; }
+    *lo = a; *hi = b;
+    return 0;
+}
+
+int pa_hg_bucket_wait(pa_net* net, int stack, void* stream) {
+    g_err[0] = 0;
+    Net& n = net->n;
+    const int r = n.mark_bucket(stack);
+    if (r < 0) return -1;                      // no early bucket in this stream mode: exchange everything at the end
+    if (r > 0) return r;
+    PA_CHECK(hipStreamWaitEvent(ST(stream), n.ev_bucket[stack], 0));
+    return 0;
+}
+
 int pa_hg_train_step(pa_net* net, const void* img4, const double* pts, int train, int use_graph, float* loss_per_stack) {
     g_err[0] = 0;
     Net& n = net->n;

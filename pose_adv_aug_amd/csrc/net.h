@@ -231,6 +231,12 @@ struct Net {
     const bf16* cur_image = nullptr;
     int forward_pose(const float* img_nchw, const bf16* img4_in, const double* pts, bool train, float* loss_out_dev);
     int backward_pose();
+    // the backward pass in phases (data-parallel gradient exchange of a finished stack while the earlier ones still run):
+    // phase p < stacks = head layers + post block + hourglass of stack (stacks-1-p); phase == stacks = stem + final reductions
+    int backward_stack(int i);
+    int backward_stem();
+    hipEvent_t ev_bucket[16], ev_bucket_main = nullptr; bool bucket_events = false;
+    int mark_bucket(int stack);                     // record "every gradient of hg.<stack> is final" (after its slabs are reduced)
     int reduce_grads();
     int forward_half(const float* img_nchw, const bf16* img4_in, bool train);     // stem + hg[0] down path (agent features)
 

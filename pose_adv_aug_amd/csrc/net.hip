@@ -655,6 +655,7 @@ int Net::ensure_streams() {
 }
 void Net::release_streams() {
     release_graph();
+    if (bucket_events) { for (int i = 0; i < 16; ++i) (void)hipEventDestroy(ev_bucket[i]); (void)hipEventDestroy(ev_bucket_main); bucket_events = false; }
     for (int k = 0; k < 4; ++k) {
         if (side[k]) {
             if (k < n_side) { (void)hipStreamSynchronize(side[k]); (void)hipStreamDestroy(side[k]); }
@@ -728,39 +729,40 @@ int Net::forward_pose(const float* img_nchw, const bf16* img4_in, const double* 
 }
 
 // hand-written backward of the whole pose net; gradients land in the flat `grads` array
-int Net::backward_pose() {
-    TRY(ensure_streams());
+int Net::backward_stack(int i) {
     const int Hh = res / 4;
     const float gscale = PA_GRAD_SCALE / ((float)B * 16.f * (float)Hh * (float)Hh);      // (fp16 build: scaled gradients, common.h)
-    for (int i = stacks - 1; i >= 0; --i) {
-        const bool inner = i + 1 < stacks;
-        if (inner) {
-            const PaOperand gx = pa_plain(xin[i + 1].grad);
-            TRY(conv_wgrad(inc[i], gx, pa_plain(heat64[i]), B, Hh, Hh));
-            TRY(conv_dgrad(inc[i], gx, B, Hh, Hh, pa_none(), pa_none(), ep_plain(), dheat_in[i]));
-            TRY(conv_wgrad(forth[i], gx, op(lin_out[i]), B, Hh, Hh));
-        }
-        TRY(pa_launch_heat_grad(heat[i], pts_dev, inner ? dheat_in[i] : nullptr, dheat64[i], gscale, B, Hh, Hh, st));
-        const PaOperand gh = pa_plain(dheat64[i]);
-        TRY(conv_wgrad(outc[i], gh, op(lin_out[i]), B, Hh, Hh));
-        if (inner) {
-            TRY(conv_dgrad(outc[i], gh, B, Hh, Hh, pa_none(), pa_none(), ep_plain(), lgrad_tmp[i]));
-            TRY(conv_dgrad(forth[i], pa_plain(xin[i + 1].grad), B, Hh, Hh, pa_plain(lgrad_tmp[i]), pa_none(),
-                           final_ep(lin_out[i]), lin_out[i].grad));
-        } else {
-            TRY(conv_dgrad(outc[i], gh, B, Hh, Hh, pa_none(), pa_none(), final_ep(lin_out[i]), lin_out[i].grad));
-        }
-        TRY(finish_grad(lin_out[i]));
-        PaOperand gl = gradop(lin_out[i]);
-        bool gl_stored = false;                  // lgrad_tmp[i] is free again: the data gradient stores dz there for the weight gradient
-        TRY(conv_dgrad(lin[i], gl, B, Hh, Hh, pa_none(), pa_none(), final_ep(post[i].x3), post[i].x3.grad, lgrad_tmp[i], &gl_stored));
-        if (gl_stored) gl = pa_plain(lgrad_tmp[i]);
-        TRY(conv_wgrad(lin[i], gl, op(post[i].x3), B, Hh, Hh));
-        TRY(finish_grad(post[i].x3));
-        TRY(post[i].bwd(*this, hg[i].out(), pa_none(), true));
-        TRY(hg[i].bwd(*this, xin[i], inner ? pa_plain(xin[i + 1].grad) : pa_none()));
+    const bool inner = i + 1 < stacks;
+    if (inner) {
+        const PaOperand gx = pa_plain(xin[i + 1].grad);
+        TRY(conv_wgrad(inc[i], gx, pa_plain(heat64[i]), B, Hh, Hh));
+        TRY(conv_dgrad(inc[i], gx, B, Hh, Hh, pa_none(), pa_none(), ep_plain(), dheat_in[i]));
+        TRY(conv_wgrad(forth[i], gx, op(lin_out[i]), B, Hh, Hh));
     }
-    // stem: residual3 <- residual2 <- maxpool <- residual1 <- 7x7 conv
+    TRY(pa_launch_heat_grad(heat[i], pts_dev, inner ? dheat_in[i] : nullptr, dheat64[i], gscale, B, Hh, Hh, st));
+    const PaOperand gh = pa_plain(dheat64[i]);
+    TRY(conv_wgrad(outc[i], gh, op(lin_out[i]), B, Hh, Hh));
+    if (inner) {
+        TRY(conv_dgrad(outc[i], gh, B, Hh, Hh, pa_none(), pa_none(), ep_plain(), lgrad_tmp[i]));
+        TRY(conv_dgrad(forth[i], pa_plain(xin[i + 1].grad), B, Hh, Hh, pa_plain(lgrad_tmp[i]), pa_none(),
+                       final_ep(lin_out[i]), lin_out[i].grad));
+    } else {
+        TRY(conv_dgrad(outc[i], gh, B, Hh, Hh, pa_none(), pa_none(), final_ep(lin_out[i]), lin_out[i].grad));
+    }
+    TRY(finish_grad(lin_out[i]));
+    PaOperand gl = gradop(lin_out[i]);
+    bool gl_stored = false;                  // lgrad_tmp[i] is free again: the data gradient stores dz there for the weight gradient
+    TRY(conv_dgrad(lin[i], gl, B, Hh, Hh, pa_none(), pa_none(), final_ep(post[i].x3), post[i].x3.grad, lgrad_tmp[i], &gl_stored));
+    if (gl_stored) gl = pa_plain(lgrad_tmp[i]);
+    TRY(conv_wgrad(lin[i], gl, op(post[i].x3), B, Hh, Hh));
+    TRY(finish_grad(post[i].x3));
+    TRY(post[i].bwd(*this, hg[i].out(), pa_none(), true));
+    TRY(hg[i].bwd(*this, xin[i], inner ? pa_plain(xin[i + 1].grad) : pa_none()));
+    return 0;
+}
+
+// stem: residual3 <- residual2 <- maxpool <- residual1 <- 7x7 conv
+int Net::backward_stem() {
     TRY(res3.bwd(*this, res2.x3, pa_none(), true));
     TRY(finish_grad(res2.x3));
     TRY(res2.bwd(*this, pool0, pa_none(), true));
@@ -770,6 +772,35 @@ int Net::backward_pose() {
     TRY(finish_grad(a0));
     TRY(conv_wgrad(stem_conv, gradop(a0), pa_plain(cur_image), B, res / 2, res / 2));
     return reduce_grads();
+}
+
+int Net::backward_pose() {
+    TRY(ensure_streams());
+    for (int i = stacks - 1; i >= 0; --i) TRY(backward_stack(i));
+    return backward_stem();
+}
+
+// every gradient of hourglass `stack` is final once the main chain has enqueued its backward pass (the side branches are joined
+// inside it) AND the weight-gradient stream has reduced its slabs: an event on that stream behind one on the main stream
+int Net::mark_bucket(int stack) {
+    if (stack < 0 || stack >= 16) return 1;
+    if (!bucket_events) {
+        for (int i = 0; i < 16; ++i) PA_CHECK(hipEventCreateWithFlags(&ev_bucket[i], hipEventDisableTiming));
+        PA_CHECK(hipEventCreateWithFlags(&ev_bucket_main, hipEventDisableTiming));
+        bucket_events = true;
+    }
+    TRY(flush_wgrads());
+    if (multi_stream && wstream && (reduce_early || immediate_reduce)) {
+        PA_CHECK(hipEventRecord(ev_bucket_main, st));
+        for (int i = 0; i < n_w; ++i) PA_CHECK(hipStreamWaitEvent(wstreams[i], ev_bucket_main, 0));
+        for (int i = 1; i < n_w; ++i) {         // (more than one weight-gradient stream: fold them into the first)
+            PA_CHECK(hipEventRecord(ev_wdone_x[i], wstreams[i]));
+            PA_CHECK(hipStreamWaitEvent(wstreams[0], ev_wdone_x[i], 0));
+        }
+        PA_CHECK(hipEventRecord(ev_bucket[stack], wstreams[0]));
+        return 0;
+    }
+    return -1;            // slabs are only reduced at the very end in this mode: no early bucket
 }
 
 // One training step (forward, loss, backward) as a HIP graph.  Inputs live in the engine's own buffers (img4, pts_dev:

@@ -269,6 +269,7 @@ class HourglassNet(_HipModule):
         return outs
 
     use_graph = False        # loss_and_backward(img4=...) replays a captured HIP graph of forward + backward (pa_hg_train_step)
+    on_stack_done = None     # callback(stack index) after the backward pass of a stack is enqueued (utils.optim.RMSprop(overlap=True))
 
     def loss_and_backward(self, x=None, pts=None, img4=None, want_outputs=False, dropout_masks=None):
         """One pass of stack-hg.py:153-164 without the optimizer: forward in the current mode, loss
@@ -291,7 +292,13 @@ class HourglassNet(_HipModule):
                                       1 if self.training else 0, ptr(losses)), 'pa_hg_forward')
             if self.training:
                 self._nbt += 1
-            check(lib().pa_hg_backward(h), 'pa_hg_backward')
+            if self.on_stack_done is not None:                  # the backward pass in phases: a finished stack's gradients can travel
+                for phase in range(self.num_stacks + 1):
+                    check(lib().pa_hg_backward_phase(h, phase), 'pa_hg_backward_phase')
+                    if phase < self.num_stacks:
+                        self.on_stack_done(self.num_stacks - 1 - phase)
+            else:
+                check(lib().pa_hg_backward(h), 'pa_hg_backward')
             outs = self.heatmaps(B) if want_outputs else None
         finally:
             if keep is not None:
