@@ -182,15 +182,26 @@ class MPII(object):
             copy_stream = torch.cuda.Stream()
             with ThreadPoolExecutor(max_workers=max(1, prefetch)) as assemblers:
                 futs = [assemblers.submit(self._assemble, c, slots, copy_stream) for c in chunks[:prefetch]]
-                for k in range(len(chunks)):
-                    batch, ev, slot = futs[k].result()
-                    torch.cuda.current_stream().wait_event(ev)
-                    batch.record_stream(torch.cuda.current_stream())     # allocated on the copy stream, consumed on the caller's
-                    if k + prefetch < len(chunks):
-                        futs.append(assemblers.submit(self._assemble, chunks[k + prefetch], slots, copy_stream))
-                    yield batch
-                    ev.synchronize()                      # (long done: the copy finished before the batch was trained on)
-                    slots.free.put(slot)
+                released = 0
+                try:
+                    for k in range(len(chunks)):
+                        batch, ev, slot = futs[k].result()
+                        torch.cuda.current_stream().wait_event(ev)
+                        batch.record_stream(torch.cuda.current_stream())     # allocated on the copy stream, consumed on the caller's
+                        if k + prefetch < len(chunks):
+                            futs.append(assemblers.submit(self._assemble, chunks[k + prefetch], slots, copy_stream))
+                        yield batch
+                        ev.synchronize()                      # (long done: the copy finished before the batch was trained on)
+                        slots.free.put(slot)
+                        released = k + 1
+                finally:                                      # a pass abandoned early (next(iter(feed))): hand every slot back
+                    for f in futs[released:]:
+                        try:
+                            _, ev, slot = f.result()
+                            ev.synchronize()
+                            slots.free.put(slot)
+                        except Exception:
+                            pass
 
         total = sum(min(batch_size, n - k * batch_size) for k in (range(rank, nb_all, world) if world > 1 else range(nb_all)))
         return BatchFeed(nb, total if world == 1 else min(total, nb * batch_size), one_pass_processes if decoder == 'process' else one_pass_threads)

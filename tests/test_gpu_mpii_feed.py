@@ -113,3 +113,15 @@ def test_process_pool_feed_equals_thread_feed_and_drives_train(tmp_path):
     va = MPII(path, str(tmp_path), is_train=False, log=lambda *_: None).batches(2, decoder='process', workers=2, prefetch=2)
     vl, vp, preds = stack_hg.validate(va, net, Augmenter(seed=2), 0, o, log=lambda m: None)
     assert preds.shape == (3, 16, 2) and np.isfinite(vl)
+
+
+def test_abandoned_passes_return_their_frame_slots(tmp_path):
+    """joint-train...:180-191 takes ONE batch of a fresh pass per epoch (next(iter(feed))): every abandoned pass must hand its
+    frame slots back, or the feed runs dry after a few epochs"""
+    from pose_adv_aug_amd.mpii_for_mpii import MPII
+    path, anno, sizes = _make_dataset(tmp_path, n=7)
+    ds = MPII(path, str(tmp_path), is_train=True, log=lambda *_: None)
+    feed = ds.batches(1, shuffle=False, decoder='process', workers=2, prefetch=2)
+    first = [next(iter(feed)).index for _ in range(12)]          # 12 abandoned passes with 4 slots
+    assert first == [[0]] * 12
+    assert [b.index for b in feed] == [[0], [1], [2], [3]]
