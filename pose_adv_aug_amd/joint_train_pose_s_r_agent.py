@@ -70,6 +70,8 @@ def train_hg(batches, hg, optimizer_hg, agent_sr, augmenter, epoch, opt, log=pri
         meters.update({'loss_hg': loss, 'pckh': pckh, tag[0]: loss, tag[1]: pckh})
         if i % opt.print_freq == 0 or i == n - 1:
             log('epoch:%d, iters:%d/%d ' % (epoch, i, n) + ' '.join('%s: %.4f' % kv for kv in meters.averages().items()))
+    if meters is None:                                    # an empty feed
+        return 0.0, 0.0
     d = meters.averages()
     return d['loss_hg'], d['pckh']
 

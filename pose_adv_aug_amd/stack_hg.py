@@ -74,6 +74,8 @@ def train(batches, net, optimizer, augmenter, epoch, opt, log=print):
         meters.update({'loss': loss, 'pckh': pckh, 'pckh_origin_res': pckh_o})
         if i % opt.print_freq == 0 or i == n - 1:          # the only host sync
             log('epoch:%d, iters:%d/%d ' % (epoch, i, n) + ''.join('%s: %.4f ' % kv for kv in meters.averages().items()))   # utils/visualizer.py:70-72
+    if meters is None:                                    # an empty feed
+        return 0.0, 0.0
     d = meters.averages()
     return d['loss'], d['pckh_origin_res']
 
