@@ -151,3 +151,32 @@ def test_augmentation_laws_value_for_value(P):
     p3 = out.cpu().numpy()
     assert np.array_equal(p2[:, 2], p[:, 2]) and np.all(p2[:, 3] == 0) and np.all(p2[:, 4] == 0) and np.all(p2[:, 5:] == 1)
     assert np.array_equal(p3[:, 3], p[:, 3]) and np.array_equal(p3[:, 2], meta[:, 2].astype(np.float64)) and np.all(p3[:, 4] == 0)
+
+
+@pytest.mark.parametrize('res', [64, 128, 256, 384])
+def test_crop_edge_cases_equal_the_oracle(P, res):
+    """Code paths the benchmark's laws never reach, byte for byte against oracle.crop (quirk off): other output resolutions,
+    scale factors above 11 (coefficients computed in the passes instead of the tables), heavy up-scaling, windows partly and
+    completely outside the frame, a tiny ragged frame, a single sample, rotations by 180 / 90 / 360 degrees."""
+    from oracle import crop as oc
+    g = inputs.rng(98, res)
+    big = g.integers(0, 256, (300, 420, 3), dtype=np.uint8)
+    tiny = g.integers(0, 256, (37, 53, 3), dtype=np.uint8)
+    k = res / 256.0
+    cases = [(big, (210.3, 150.7), 1.7 * k, 0.0), (big, (210.3, 150.7), 14.5 * k, 21.0), (big, (200.0, 140.0), 0.31 * k, -33.0),
+             (big, (5.5, 8.25), 1.1 * k, 10.0), (big, (-400.0, -300.0), 0.9 * k, 0.0), (big, (419.0, 299.0), 3.3 * k, 180.0),
+             (big, (180.0, 160.0), 2.7 * k, 90.0), (big, (222.0, 111.0), 1.3 * k, 360.0), (tiny, (26.0, 18.0), 0.21 * k, 15.0),
+             (tiny, (20.0, 20.0), 4.1 * k, 0.0)]
+    for frame, c, s, r in cases:
+        s32 = float(np.float32(s))
+        params = P.HumanAug.make_params(np.array([c], dtype=np.float32).astype(np.float64), [s32], [r])
+        _, _, out8 = P.HumanAug.crop_batch(np.ascontiguousarray(frame)[None], params, res=res, want_nhwc4=False, want_u8=True)
+        got = out8[0].cpu().numpy()
+        if c[0] < -300:                           # window completely outside: the reference's slice assignment raises there; the device pads
+            with pytest.raises(ValueError):
+                oc.crop(oc.source_image(frame), np.array(c, dtype=np.float32), np.float32(s), r, res, 200, quirk=False)
+            assert got.shape == (res, res, 3) and not got.any()
+            continue
+        want = oc.crop(oc.source_image(frame), np.array(c, dtype=np.float32), np.float32(s), r, res, 200, quirk=False)
+        assert got.shape == want.shape and np.array_equal(got, want), (res, c, s, r, int(np.abs(got.astype(int) - want.astype(int)).max()),
+                                                                      float((got != want).mean()))
