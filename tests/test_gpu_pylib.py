@@ -211,3 +211,41 @@ def test_samplers_follow_the_reference_laws():
     assert np.allclose(probs[0].cpu().numpy(), ref, atol=1e-6)
     freq = np.bincount(idx.cpu().numpy(), minlength=7) / B
     assert np.abs(freq - ref).max() < 0.03
+
+
+def test_metric_edge_cases_against_oracle(P):
+    """Degenerate inputs of the metrics (pylib/Evaluation.py:21-22,41-52,60-75,105-167), device vs oracle: a person with NO
+    annotated joint, a joint annotated on nobody (its per-joint accuracy is -1 and is left out of the mean), all-negative and
+    all-zero heat maps (prediction (0, 0)), a peak on the first row / column (ground truth there counts as invalid in heat-map
+    mode), ties (first maximum wins), a single sample, thresholds hit exactly."""
+    from oracle import pylib as opl
+    E = P.Evaluation
+    B = 5
+    c, s, r, gpts, norm = inputs.person_meta(91, B)
+    gpts[1] = 0.0                                   # nobody annotated on sample 1
+    gpts[:, 7] = 0.0                                # joint 7 annotated on no sample
+    tp = np.stack([opl.transform_pts(gpts[i], c[i], s[i], r[i], 64) for i in range(B)])
+    tp[gpts[..., 0] <= 0] = 0
+    tp[2, 3] = [0.5, 20.0]                          # Gaussian peak in column 0 -> 1-based x = 1: not > 1
+    tgt = inputs.heatmaps_from_pts(tp, 64)
+    pred = inputs.noisy_heatmaps(92, tgt, noise=0.1)
+    pred[0, 2] = -1.0                               # all negative
+    pred[0, 4] = 0.0                                # all zero
+    pred[3, 5] = 0.25                               # a plateau: every pixel ties
+    pred[4, 6, 10, 20] = pred[4, 6, 40, 50] = 9.0   # two equal maxima
+    idx = list(range(16))
+    cT, sT, rT = t(c).float(), t(s).float().view(B, 1), t(r).float().view(B, 1)
+    for sl in (slice(0, B), slice(1, 2)):           # the whole batch, and the unannotated person alone
+        pr, tg = t(pred[sl]), t(tgt[sl])
+        args = (cT[sl], sT[sl], [64, 64], t(gpts[sl]).float(), t(norm[sl]).float(), rT[sl])
+        assert np.array_equal(E.get_preds(pr).cpu().numpy(), opl.get_preds(pr).numpy())
+        assert np.allclose(E.accuracy(pr, tg, idx).cpu().numpy(), opl.accuracy(pr, tg, idx).numpy(), atol=1e-6)
+        assert np.array_equal(E.final_preds(pr, cT[sl], sT[sl], [64, 64], rT[sl]).cpu().numpy(), opl.final_preds(pr, cT[sl], sT[sl], [64, 64], rT[sl]).numpy())
+        assert np.allclose(E.accuracy_origin_res(pr, *args).cpu().numpy(), opl.accuracy_origin_res(pr, *args).numpy(), atol=1e-6)
+        assert np.allclose(E.per_person_pckh(pr, tg, *args).cpu().numpy(), opl.per_person_pckh(pr, tg, *args).numpy(), atol=1e-6)
+    a = opl.accuracy(t(pred), t(tgt), idx).numpy()
+    assert a[8] == -1 and float(opl.per_person_pckh(t(pred), t(tgt), cT, sT, [64, 64], t(gpts).float(), t(norm).float(), rT)[1]) == 0.0
+    # heat maps and the loss at the borders of the validity rule (pylib/HumanPts.py:41-43): x or y <= 0, > W, == W
+    pts = np.zeros((1, 16, 2)); pts[0, :6] = [[64.0, 64.0], [64.001, 10.0], [1e-9, 1e-9], [0.0, 5.0], [63.999, 0.001], [32.5, 64.0]]
+    hm = P.HumanPts.pts2heatmap_batch(torch.from_numpy(pts).cuda(), 64, 64).cpu().numpy()
+    assert np.array_equal(hm[0], inputs.heatmaps_from_pts(pts, 64)[0])
