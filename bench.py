@@ -101,6 +101,7 @@ def main():
     ap.add_argument('--dtype', choices=['bf16', 'fp16'], default='bf16', help='16-bit storage / MFMA operand type (BASELINE configs[4]: fp16)')
     ap.add_argument('--overlap', type=int, default=0, help='1 (N > 1): exchange each stack\'s hourglass gradients during the rest of the backward pass (RMSprop(overlap=True))')
     ap.add_argument('--graph', type=int, default=0, help='1: forward + backward replayed from a captured HIP graph (pa_hg_train_step)')
+    ap.add_argument('--single-stream', type=int, default=0, help='1: the engine\'s side / weight-gradient streams off for the timed region too (experiments)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     args = ap.parse_args()
@@ -126,6 +127,8 @@ def main():
     aug = Augmenter(seed=100 + rank, inp_res=res, out_res=res // 4)
     batches = [DeviceBatch.synthetic(B, seed=rank * 100 + k) for k in range(2)]       # resident in HBM
     net.train()
+    if args.single_stream:
+        _lib.check(_lib.lib().pa_net_set_multi_stream(net._net(B), 0))
 
     def sync():
         if world > 1:
