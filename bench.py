@@ -89,6 +89,41 @@ def cpu_baseline(stacks, chan, B, res, budget_s=40.0, steps=5):
                    'sample': 'BASELINE configs[0]: 1-stack chan %d, B=%d, %dx%d, %d timed steps, %.3f s/step' % (chan, b1, res, res, steps, dt1)}}
 
 
+def pckh_parity(net, aug, batch, B, res):
+    """The "PCKh match" half of BASELINE.json's metric, on the driver's line (outside the timed region; the oracle is the
+    CHECKER here): the engine's in-step metrics (pa_hg_accuracy, pa_hg_pckh) of one more training step against the oracle's
+    pylib/Evaluation.py:54-97 restatement on the engine's own heat maps, and -- an untrained net on noise frames scores ~0 --
+    the same two entry points on target + noise maps (pylib.Evaluation = the C ABI's pa_accuracy / pa_accuracy_origin_res)."""
+    import numpy as np
+    from oracle import pylib as opl
+    from tests import inputs
+    from pose_adv_aug_amd import pylib
+    from pose_adv_aug_amd.stack_hg import PCK_IDX
+    H = res // 4
+    data = aug.regular(batch)
+    net.loss_and_backward(img4=data['img4'], pts=data['pts'])
+    maps = net.heatmaps(B)[-1].cpu()
+    target = pylib.HumanPts.pts2heatmap_batch(data['pts'], H, H).cpu()
+    c, s, r = data['c'].cpu().float(), data['s'].cpu().float().view(B, 1), data['r'].cpu().float().view(B, 1)
+    g, nm = data['grnd_pts'].cpu().float(), data['normalizer'].cpu().float()
+    e_acc = net.accuracy(PCK_IDX).cpu().numpy()
+    e_pck = net.pckh_origin_res(data['c'], data['s'], data['r'], data['grnd_pts'], data['normalizer'])[0].cpu().numpy()
+    o_acc = opl.accuracy(maps, target, PCK_IDX).numpy()
+    o_pck = opl.accuracy_origin_res(maps, c, s, [H, H], g, nm, r).numpy()
+    noisy = torch.from_numpy(inputs.noisy_heatmaps(43, target.numpy(), noise=0.2))
+    e2_acc = pylib.Evaluation.accuracy(noisy, target, PCK_IDX).cpu().numpy()
+    e2_pck = pylib.Evaluation.accuracy_origin_res(noisy, c, s, [H, H], g, nm, r).cpu().numpy()
+    o2_acc = opl.accuracy(noisy, target, PCK_IDX).numpy()
+    o2_pck = opl.accuracy_origin_res(noisy, c, s, [H, H], g, nm, r).numpy()
+    diffs = [np.abs(a - b).max() for a, b in ((e_acc, o_acc), (e_pck, o_pck), (e2_acc, o2_acc), (e2_pck, o2_pck))]
+    return {'tolerance': 1e-4, 'abs_diff': float(max(diffs)), 'match': bool(max(diffs) <= 1e-4),
+            'untrained_net': {'engine': {'pck_heatmap': float(e_acc[0]), 'pckh_origin_res': float(e_pck[0])},
+                              'oracle': {'pck_heatmap': float(o_acc[0]), 'pckh_origin_res': float(o_pck[0])}},
+            'target_plus_noise_maps': {'engine': {'pck_heatmap': float(e2_acc[0]), 'pckh_origin_res': float(e2_pck[0])},
+                                       'oracle': {'pck_heatmap': float(o2_acc[0]), 'pckh_origin_res': float(o2_pck[0])}},
+            'per_joint_values_compared': int(sum(len(x) for x in (e_acc, e_pck, e2_acc, e2_pck)))}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -104,6 +139,7 @@ def main():
     ap.add_argument('--single-stream', type=int, default=0, help='1: the engine\'s side / weight-gradient streams off for the timed region too (experiments)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--no-parity', action='store_true')
     args = ap.parse_args()
 
     from pose_adv_aug_amd import _lib
@@ -123,7 +159,7 @@ def main():
     net.reset_parameters(seed=0)
     net.use_graph = bool(args.graph)
     broadcast_parameters(net)
-    opt = RMSprop(net, lr=2.5e-4, alpha=0.99, eps=1e-8, overlap=bool(args.overlap) and world > 1)
+    opt = RMSprop(net, lr=2.5e-4, alpha=0.99, eps=1e-8, overlap=bool(args.overlap) and (world > 1 or os.environ.get('POSEADV_FORCE_DIST') == '1'))
     aug = Augmenter(seed=100 + rank, inp_res=res, out_res=res // 4)
     batches = [DeviceBatch.synthetic(B, seed=rank * 100 + k) for k in range(2)]       # resident in HBM
     net.train()
@@ -194,23 +230,29 @@ def main():
         conv_ms = sum(r['ms_total'] for r in rows) / args.steps
         # HBM bytes per launch of that kernel class from the PMC counters (FETCH_SIZE x2 + WRITE_SIZE, collected in
         # separate rocprofv3 --pmc passes by tools/prof_pmc.sh and committed under profiles/); null if not collected
+        # (recorded numbers carry their source; they belong to the 2-stack bf16 benchmark configuration only)
         traffic, trace = None, None
-        for name in ('round2_pmc.json', 'round1_pmc.json'):
+        is_c2 = (args.stacks, args.chan, res, B, args.dtype) == (2, 256, 256, 24, 'bf16')
+        for name in ('round3_pmc.json', 'round2_pmc.json'):
             pmc_path = os.path.join(ROOT, 'profiles', name)
-            if os.path.isfile(pmc_path):
+            if is_c2 and os.path.isfile(pmc_path):
                 pmc = json.load(open(pmc_path))
                 if dom['kernel'] in pmc:
-                    traffic = round(pmc[dom['kernel']]['hbm_bytes_per_launch'], 1)
+                    traffic = {'hbm_bytes_per_launch': round(pmc[dom['kernel']]['hbm_bytes_per_launch'], 1),
+                               'source': 'profiles/%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE passes of this command, recorded; not measured in this run)' % name}
                     break
         # the same class from the committed rocprofv3 --kernel-trace of this command (tools/trace_classes.py): kernel
-        # durations without the event-to-event gaps; `frac` stays the live (event) number, `frac_trace` is quoted beside it
-        tr_path = os.path.join(ROOT, 'profiles', 'round2_trace_classes.json')
-        if os.path.isfile(tr_path):
+        # durations without the event-to-event gaps; `frac` stays the live (event) number, `trace.frac` is quoted beside it
+        for name in ('round3_trace_classes.json', 'round2_trace_classes.json'):
+            tr_path = os.path.join(ROOT, 'profiles', name)
+            if not (is_c2 and os.path.isfile(tr_path)):
+                continue
             tr = json.load(open(tr_path)).get(dom['kernel'])
             if tr:
                 t_ach = (dom['flops'] if bound == 'mfma' else dom['bytes']) / dom['launches'] / (tr['avg_us'] * 1e-6) / (1e12 if bound == 'mfma' else 1e9)
                 trace = {'avg_kernel_us': tr['avg_us'], 'launches_per_step': tr['launches_per_step'], 'achieved': round(t_ach, 2),
-                         'frac': round(t_ach / peak, 4), 'source': tr.get('source', 'profiles/')}
+                         'frac': round(t_ach / peak, 4), 'source': 'profiles/%s (recorded; not measured in this run)' % name}
+            break
         roofline = {'bound': bound, 'achieved': round(ach, 2), 'peak': peak, 'unit': unit, 'frac': round(ach / peak, 4),
                     'traffic': traffic, 'trace': trace, 'kernel': dom['kernel'], 'avg_launch_us': round(dom['avg_us'], 2),
                     'launches_per_step': dom['launches'] // args.steps,
@@ -222,6 +264,10 @@ def main():
                     'whole_step': ({'hbm_frac': round(value / world * 380.5e6 / HBM_PEAK, 4),
                                     'mfma_frac': round(value / world * 50.0e9 / MFMA_PEAK, 4)}
                                    if (args.stacks, args.chan, res) == (2, 256, 256) else None)}
+
+    parity = None
+    if rank == 0 and not args.no_parity:
+        parity = pckh_parity(net, aug, batches[0], B, res)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -238,7 +284,7 @@ def main():
                                           ('BASELINE configs[4]: ' if (args.stacks, args.chan, res, B, args.dtype) == (8, 256, 384, 16, 'fp16') else ''), args.stacks, args.chan, B, res, res),
                            'global_batch': world * B, 'parallelism': 'dp%d' % world + ('+overlapped-exchange' if args.overlap and world > 1 else ''),
                            'loss': float(loss), 'pckh': float(pckh), 'pckh_origin_res': float(pckh_o)},
-                'roofline': roofline, 'cpu_baseline': cpu}
+                'pckh_parity': parity, 'roofline': roofline, 'cpu_baseline': cpu}
         print(json.dumps(line))
     if world > 1:
         dist.barrier()

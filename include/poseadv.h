@@ -138,6 +138,10 @@ int pa_cell_mask(const void* x_bf16, const float* masks, void* out_bf16, int B, 
  * gscale multiplies the gradient first (1/world after a sum all-reduce). */
 int pa_rmsprop_step(float* param, const float* grad, float* square_avg, size_t n, float lr, float alpha,
                     float eps, float gscale, void* stream);
+/* Half-precision build (pa_dtype() == 1) only: a step whose gradient holds inf / NaN (an fp16 overflow in the scaled backward
+ * pass) is SKIPPED -- parameters and square_avg untouched, the loss-scaling convention the reference's fp32 path never needs --
+ * and counted.  *count = steps skipped so far in this process (synchronises `stream`); always 0 in the bf16 build. */
+int pa_rmsprop_skipped_steps(long long* count, void* stream);
 
 /* ---------------------------------------------------------------- operator level ---------- */
 /* One residual bottleneck block _Residual(C, C) (models/asn_stacked_hg.py:11-49), forward + backward,

@@ -106,6 +106,7 @@ int pa_cell_mask(const void* x, const float* masks, void* out, int B, int H, int
 int pa_rmsprop_step(float* p, const float* g, float* v, size_t n, float lr, float alpha, float eps, float gscale, void* s) {
     TRY(pa_launch_rmsprop(p, g, v, n, lr, alpha, eps, gscale, ST(s))); return 0;
 }
+int pa_rmsprop_skipped_steps(long long* count, void* s) { if (!count) return 1; TRY(pa_rmsprop_skipped(count, ST(s))); return 0; }
 int pa_nchw_to_nhwc(const float* src, void* dst, int B, int C, int H, int W, void* s) {
     TRY(pa_launch_nchw_f32_to_nhwc_bf16(src, reinterpret_cast<bf16*>(dst), B, C, H, W, ST(s))); return 0;
 }
@@ -482,6 +483,13 @@ int pa_hg_bucket_range(const pa_net* net, int stack, size_t* lo, size_t* hi) {
     for (const TensorInfo& t : n.tensors)
         if (t.is_buffer == 0 && t.name.compare(0, strlen(prefix), prefix) == 0) { if (t.offset < a) a = t.offset; if (t.offset + t.numel > b) b = t.offset + t.numel; }
     if (b == 0) { pa_set_error_msg("pa_hg_bucket_range: no such stack"); return 1; }
+    // the caller all-reduces [lo, hi) EARLY and skips it at the end: no other parameter may live inside the range (this holds
+    // by the declaration order of declare_pose; a parameter interleaved later would be reduced before its gradient is final)
+    for (const TensorInfo& t : n.tensors)
+        if (t.is_buffer == 0 && t.name.compare(0, strlen(prefix), prefix) != 0 && t.offset < b && t.offset + t.numel > a) {
+            pa_set_error_msg("pa_hg_bucket_range: a parameter of another module lies inside the stack's range");
+            return 1;
+        }
     *lo = a; *hi = b;
     return 0;
 }

@@ -742,13 +742,74 @@ __global__ void rmsprop_kernel(float* p, const float* g, float* v, size_t n, flo
     }
 }
 
+// Half-precision build only (gradients travel multiplied by PA_GRAD_SCALE, common.h): an overflow anywhere in the backward
+// pass shows up as inf / NaN in the flat gradient.  A step whose gradient holds a non-finite value is SKIPPED (parameters and
+// square_avg untouched, the loss-scaling convention) and counted; pa_rmsprop_skipped_steps reads the counter.
+__device__ int g_grad_state[2];            // [0] this step's gradient holds a non-finite value, [1] steps skipped so far
+
+__global__ void grad_check_reset_kernel() { g_grad_state[0] = 0; }
+
+__global__ void grad_check_kernel(const float* g, size_t n) {
+    size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const size_t stride = (size_t)gridDim.x * blockDim.x * 4;
+    bool bad = false;
+    for (; i + 3 < n; i += stride) {
+        const f32x4 gg = *reinterpret_cast<const f32x4*>(g + i);
+        bad |= !(isfinite(gg[0]) && isfinite(gg[1]) && isfinite(gg[2]) && isfinite(gg[3]));
+    }
+    for (; i < n && i + 3 >= n; ++i) bad |= !isfinite(g[i]);
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(&g_grad_state[0], 1);
+}
+
+__global__ void rmsprop_checked_kernel(float* p, const float* g, float* v, size_t n, float lr, float alpha, float eps, float gscale) {
+    if (g_grad_state[0]) {                  // uniform over the grid: every thread reads the same word
+        if (blockIdx.x == 0 && threadIdx.x == 0) g_grad_state[1] += 1;
+        return;
+    }
+    size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const size_t stride = (size_t)gridDim.x * blockDim.x * 4;
+    for (; i + 3 < n; i += stride) {
+        f32x4 gg = *reinterpret_cast<const f32x4*>(g + i), vv = *reinterpret_cast<f32x4*>(v + i), pp = *reinterpret_cast<f32x4*>(p + i);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float gr = gg[j] * gscale;
+            vv[j] = alpha * vv[j] + (1.f - alpha) * gr * gr;
+            pp[j] = pp[j] - lr * (gr / (sqrtf(vv[j]) + eps));
+        }
+        *reinterpret_cast<f32x4*>(v + i) = vv;
+        *reinterpret_cast<f32x4*>(p + i) = pp;
+    }
+    for (; i < n && i + 3 >= n; ++i) {
+        float gr = g[i] * gscale;
+        v[i] = alpha * v[i] + (1.f - alpha) * gr * gr;
+        p[i] = p[i] - lr * (gr / (sqrtf(v[i]) + eps));
+    }
+}
+
 int pa_launch_rmsprop(float* p, const float* g, float* v, size_t n, float lr, float alpha, float eps, float gscale, hipStream_t st) {
     if (n == 0) return 0;
     int blocks = (int)((n / 4 + 255) / 256);
     if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;
+#ifdef PA_FP16
+    hipLaunchKernelGGL(grad_check_reset_kernel, dim3(1), dim3(1), 0, st);
+    hipLaunchKernelGGL(grad_check_kernel, dim3(blocks), dim3(256), 0, st, g, n);
+    hipLaunchKernelGGL(rmsprop_checked_kernel, dim3(blocks), dim3(256), 0, st, p, g, v, n, lr, alpha, eps, gscale);
+#else
     hipLaunchKernelGGL(rmsprop_kernel, dim3(blocks), dim3(256), 0, st, p, g, v, n, lr, alpha, eps, gscale);
+#endif
     return (int)hipGetLastError();
+}
+
+int pa_rmsprop_skipped(long long* out, hipStream_t st) {
+    int h[2] = {0, 0};
+#ifdef PA_FP16
+    hipError_t e = hipMemcpyFromSymbolAsync(h, HIP_SYMBOL(g_grad_state), sizeof h, 0, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) return (int)e;
+#endif
+    *out = h[1];
+    return 0;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -63,10 +63,18 @@ def read_grnd_distri_from_txt(load_path):
     return grnd_distri_list
 
 
-def _targets(distri_list, first, B, dev):
-    """data/pretrain_s_r_agent.py:127-128: rows renormalised (the text file rounds to 2 decimals)."""
-    t = torch.stack(distri_list[first:first + B], 0)
+def _targets(distri_list, rows, dev):
+    """data/pretrain_s_r_agent.py:127-128: the distribution of DATASET index `index` (scale_distri[index]), rows
+    renormalised (the text file rounds to 2 decimals)."""
+    t = torch.stack([distri_list[int(r)] for r in rows], 0)
     return (t / t.sum(1, keepdim=True)).to(dev)
+
+
+def _rows(batch, first):
+    """dataset indices of a batch's people: the feed's own (`batch.index`, MPII feeds incl. shuffled passes) or, for
+    resident synthetic batches, the position in feed order"""
+    index = getattr(batch, 'index', None)
+    return list(range(first, first + batch.B)) if index is None else [int(v) for v in index]
 
 
 def _run(batches, scale_distri, rotation_distri, hg, agent, optimizer, augmenter, epoch, opt, log):
@@ -75,7 +83,8 @@ def _run(batches, scale_distri, rotation_distri, hg, agent, optimizer, augmenter
     first, n = 0, len(batches)
     for i, batch in enumerate(batches):
         dev = batch.params.device
-        ts, tr = _targets(scale_distri, first, batch.B, dev), _targets(rotation_distri, first, batch.B, dev)
+        rows = _rows(batch, first)
+        ts, tr = _targets(scale_distri, rows, dev), _targets(rotation_distri, rows, dev)
         first += batch.B
         std = augmenter.standard(batch)
         ls, lr = hg(asn=agent, img4=std['img4'], is_half_hg=True, is_aug=True)         # pretrain-s-r-agent.py:172-173
@@ -114,7 +123,8 @@ def main(argv=None):
     from .stack_hg import make_feeds
     from .utils.checkpoint import Checkpoint
     from .utils.optim import RMSprop
-    from .utils.util import ASNTrainHistory, adjust_lr
+    from .utils.logger import Logger
+    from .utils.util import ASNTrainHistory
     from .models.asn_stacked_hg import create_hg, create_asn
     opt = TrainOptions().parse(argv)
     exp = os.path.join(opt.exp_dir, opt.exp_id)
@@ -133,24 +143,33 @@ def main(argv=None):
         ckpt.load_checkpoint(agent, optimizer, history)
     ckpt.save_prefix = sr_dir + '/'
     aug = Augmenter(seed=4321)
+    # the feeds are STREAMED every pass (an MPII split resident in HBM would be 60-130 GB of padded frames): the collection
+    # pass walks each split once in dataset order (row i of a text file = person i, collect-scale-ditri.py:123-255), the
+    # training passes look a person's distribution up by its dataset index (data/pretrain_s_r_agent.py:127-128)
     train_feed, val_feed = make_feeds(opt)
-    sets = {'train': list(train_feed), 'val': list(val_feed)}                                 # the distributions are per person, in feed order
+    ordered_train, _ = make_feeds(opt, shuffle_train=False, log=lambda m: None)
     distri = {}
-    for split, batches in sets.items():
+    for split, feed in (('train', ordered_train), ('val', val_feed)):
         for kind, fname in (('scale', '%s_scales.txt' % split), ('rotation', '%s_rotations.txt' % split)):
             path = os.path.join(sr_dir, fname)
             if not os.path.isfile(path):
-                collect_data(batches, hg, aug, kind, path)
+                collect_data(feed, hg, aug, kind, path)
             distri[(split, kind)] = read_grnd_distri_from_txt(path)
+    summary = sr_dir + '/' + 'training-summary.txt'
+    resumed = opt.load_prefix_sr != '' and os.path.isfile(summary)
+    logger = Logger(summary, title='training-summary', resume=resumed)                      # :120-122
+    if not resumed:
+        logger.set_names(['Epoch', 'LR', 'Train Loss', 'Val Loss'])
     start = history.epoch[-1]['epoch'] + 1 if history.epoch else 0
-    for epoch in range(start, opt.nEpochs):
-        adjust_lr(opt, optimizer, epoch)
-        tl = train(sets['train'], distri[('train', 'scale')], distri[('train', 'rotation')], hg, agent, optimizer, aug, epoch, opt)
-        vl = validate(sets['val'], distri[('val', 'scale')], distri[('val', 'rotation')], hg, agent, aug, epoch, opt)
-        history.update(OrderedDict([('epoch', epoch)]), OrderedDict([('lr', optimizer.param_groups[0]['lr'])]),
+    for epoch in range(start, opt.nEpochs):               # (:127-141: the learning rate stays at opt.lr, adjust_lr is imported but never called)
+        tl = train(train_feed, distri[('train', 'scale')], distri[('train', 'rotation')], hg, agent, optimizer, aug, epoch, opt)
+        vl = validate(val_feed, distri[('val', 'scale')], distri[('val', 'rotation')], hg, agent, aug, epoch, opt)
+        lr_now = optimizer.param_groups[0]['lr']
+        history.update(OrderedDict([('epoch', epoch)]), OrderedDict([('lr', lr_now)]),
                        OrderedDict([('train_loss', tl), ('val_loss', vl)]))
         ckpt.save_checkpoint(agent, optimizer, history, is_asn=True)
-
+        logger.append([epoch, lr_now, tl, vl])                                              # :141
+    logger.close()
 
 if __name__ == '__main__':
     main()

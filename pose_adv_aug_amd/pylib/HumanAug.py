@@ -74,11 +74,16 @@ _CROP_WS = {}
 
 
 def _crop_workspace(B, Hs, Ws, res):
-    """scratch of pa_crop (intermediate images of the staged crop), cached per shape and device"""
-    key = (B, Hs, Ws, res, str(dev()))
+    """scratch of pa_crop (intermediate images of the staged crop): ONE grow-only buffer per (device, stream it is used
+    on), re-allocated only when pa_crop_workspace_bytes asks for more than it holds -- the MPII feed pads every batch to its
+    own (Hs, Ws), a cache per shape would grow by ~90 MB per new shape.  Keyed by the stream so that the crop enqueued one step
+    ahead on the augmentation stream (data.AugmentAhead) and a crop on the main stream (validate) never share scratch; a
+    buffer that is outgrown is released through torch's stream-ordered allocator on the stream that used it."""
+    need = int(lib().pa_crop_workspace_bytes(B, Hs, Ws, res))
+    key = (str(dev()), int(getattr(stream(), 'value', stream()) or 0))
     ws = _CROP_WS.get(key)
-    if ws is None:
-        ws = _CROP_WS[key] = torch.empty(lib().pa_crop_workspace_bytes(B, Hs, Ws, res), dtype=torch.uint8, device=dev())
+    if ws is None or ws.numel() < need:
+        ws = _CROP_WS[key] = torch.empty(need, dtype=torch.uint8, device=dev())
     return ws
 
 

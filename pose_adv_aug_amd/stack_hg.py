@@ -25,17 +25,29 @@ def init_distributed():
     local = int(os.environ.get('LOCAL_RANK', '0'))
     if torch.cuda.is_available():
         torch.cuda.set_device(local % max(1, torch.cuda.device_count()))
-    if world > 1 and not dist.is_initialized():
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        os.environ.setdefault('MASTER_PORT', '29500')
+    # POSEADV_FORCE_DIST=1: take the distributed branch with WORLD_SIZE=1 too (one rank through RCCL: the collective and
+    # the overlapped bucket path run on the engine's real streams on a single-GPU box, tests/test_gpu_rccl.py)
+    force = os.environ.get('POSEADV_FORCE_DIST') == '1'
+    if (world > 1 or force) and not dist.is_initialized():
         backend = os.environ.get('POSEADV_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')     # nccl = RCCL over xGMI
-        dist.init_process_group(backend, rank=rank, world_size=world)
+        init = os.environ.get('POSEADV_DIST_INIT')               # e.g. file:///tmp/rendezvous (no TCP port at all); default: env://
+        if init:
+            dist.init_process_group(backend, init_method=init, rank=rank, world_size=world)
+        else:
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            os.environ.setdefault('MASTER_PORT', '29500')
+            dist.init_process_group(backend, rank=rank, world_size=world)
     return rank, world, local
+
+
+def dist_active():
+    """True when gradients have to go through the process group: world > 1, or a forced single-rank group."""
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or os.environ.get('POSEADV_FORCE_DIST') == '1')
 
 
 def broadcast_parameters(net):
     """Identical replicas at start (replaces DataParallel's per-forward broadcast, stack-hg.py:49)."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist_active():
         net._ensure_table()
         dist.broadcast(net.flat_params, src=0)
         dist.broadcast(net.flat_buffers, src=0)
@@ -123,7 +135,7 @@ def validate(batches, net, augmenter, epoch, opt, num_classes=16, log=print):
 MPII_JSON = 'mpii-hr-lsp-normalizer.json'                # stack-hg.py:73 ('dataset/mpii-hr-lsp-normalizer.json')
 
 
-def make_feeds(opt, rank=0, world=1, log=print):
+def make_feeds(opt, rank=0, world=1, log=print, shuffle_train=True):
     """stack-hg.py:73-83: the MPII train / validation loaders.  With <data_dir>/mpii-hr-lsp-normalizer.json present the
     feeds are MPII.batches() (JSON + image decode on the host, everything else on the device; rank r trains on batches
     r, r + world, ... of one common order); otherwise synthetic MPII-shape people resident in HBM (the benchmark input)."""
@@ -132,7 +144,7 @@ def make_feeds(opt, rank=0, world=1, log=print):
         from .mpii_for_mpii import MPII
         tr = MPII(path, opt.data_dir, is_train=True, log=log)
         va = MPII(path, opt.data_dir, is_train=False, log=log)
-        return (tr.batches(opt.bs, shuffle=True, seed=0, drop_last=True, workers=opt.nThreads, rank=rank, world=world),
+        return (tr.batches(opt.bs, shuffle=shuffle_train, seed=0, drop_last=shuffle_train, workers=opt.nThreads, rank=rank, world=world),
                 va.batches(opt.bs, shuffle=False, workers=opt.nThreads))
     log('no %s: synthetic MPII-shape people' % path)
     return (BatchFeed.of(DeviceBatch.synthetic(opt.bs, seed=rank * 1000 + k) for k in range(4)),

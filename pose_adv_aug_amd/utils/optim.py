@@ -2,11 +2,19 @@
 lr, alpha=0.99, eps=1e-8, momentum=0, weight_decay=0), stack-hg.py:51-52) with the data-parallel
 gradient exchange folded in: ONE all-reduce of the flat gradient over RCCL per step (replaces
 nn.DataParallel's broadcast/gather/reduce_add, stack-hg.py:49)."""
+import os
+
 import torch
 import torch.distributed as dist
 
 from .. import _lib
 from .._lib import lib, check, ptr, stream
+
+
+def _dist_on():
+    """Gradients go through the process group: world > 1, or a single rank forced through it (POSEADV_FORCE_DIST=1: RCCL
+    on a one-GPU box, tests/test_gpu_rccl.py)."""
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or os.environ.get('POSEADV_FORCE_DIST') == '1')
 
 
 class RMSprop(object):
@@ -30,14 +38,14 @@ class RMSprop(object):
 
     def allreduce_grads(self):
         """Sum the flat gradient over all ranks (RCCL when the process group backend is nccl)."""
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if _dist_on():
             dist.all_reduce(self.net.flat_grads, op=dist.ReduceOp.SUM)
             return 1.0 / dist.get_world_size()
         return 1.0
 
     def _exchange_stack(self, stack):
         """hook of HourglassNet.loss_and_backward: the backward pass of `stack` has just been enqueued"""
-        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        if not _dist_on():
             return
         import ctypes as C
         net = self.net
@@ -83,6 +91,13 @@ class RMSprop(object):
         self.steps += 1
         self.net.weights_changed()
         self.net._net(self.net._last_B or self.net.default_batch)      # refresh the bf16 weight copies now
+
+    def skipped_steps(self):
+        """fp16 build: optimizer steps the engine skipped because the (scaled) gradient held inf / NaN; 0 in the bf16 build"""
+        import ctypes as C
+        n = C.c_longlong(0)
+        check(lib().pa_rmsprop_skipped_steps(C.byref(n), stream()), 'pa_rmsprop_skipped_steps')
+        return int(n.value)
 
     # torch.optim-compatible (de)serialisation: per-parameter state keyed by index, in parameters() order
     def state_dict(self):

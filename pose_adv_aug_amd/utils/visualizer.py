@@ -2,6 +2,19 @@
 log line and the log file."""
 import os
 
+RULE = '#' * 42
+
+
+def format_log(epoch, it, total, meters, extra=None):
+    """The reference's log line (utils/visualizer.py:66-78): 'epoch:E, iters:I/N k: v.vvvv ...', an optional second line
+    'k:v.vvv ...', and a rule of 42 '#' after the last iteration of an epoch."""
+    lines = ['epoch:%d, iters:%d/%d ' % (epoch, it, total) + ''.join('%s: %.4f ' % kv for kv in meters.items())]
+    if extra:
+        lines.append(''.join('%s:%.3f ' % kv for kv in extra.items()))
+    if it == total - 1:
+        lines.append(RULE)
+    return '\n'.join(lines)
+
 
 class Visualizer(object):
     def __init__(self, opt=None, log_path=None):
@@ -9,16 +22,8 @@ class Visualizer(object):
         self.log_path = log_path
 
     def print_log(self, epoch, iter, total_iter, value1, value2=None):
-        """utils/visualizer.py:66-80: 'epoch:E, iters:I/N k: v.vvvv ...' (+ a rule after the last iteration)."""
-        msg = 'epoch:%d, iters:%d/%d ' % (epoch, iter, total_iter)
-        for k, v in value1.items():
-            msg += '%s: %.4f ' % (k, v)
-        if value2:
-            msg += '\n'
-            for k, v in value2.items():
-                msg += '%s:%.3f ' % (k, v)
-        if iter == total_iter - 1:
-            msg += '\n##########################################'
+        """utils/visualizer.py:66-80: console + log file."""
+        msg = format_log(epoch, iter, total_iter, value1, value2)
         print(msg)
         self.write_log(msg)
         return msg

@@ -119,6 +119,14 @@ def main():
         _, l = ostep.pose_loss_and_grads(ref, img, heat); opt_ref.step(); lr_.append(float(l))
         l2, _ = net.loss_and_backward(img.cuda(), t(pts).cuda()); opt.step(); ld_.append(float(l2))
     ok('training steps track the oracle', abs(ld_[0] - lr_[0]) / lr_[0] < 1e-2 and ld_[-1] < ld_[0] and all(abs(a - b) / b < 0.25 for a, b in zip(ld_, lr_)), (ld_, lr_))
+    # ---- an overflowed backward pass (inf / NaN in the scaled gradient) must not poison the master weights: step skipped + counted
+    before_p, before_v, skipped0 = net.flat_params.clone(), opt.square_avg.clone(), opt.skipped_steps()
+    net.flat_grads[12345] = float('inf'); net.flat_grads[777] = float('nan')
+    opt.step()
+    ok('non-finite gradient: step skipped and counted', torch.equal(net.flat_params, before_p) and torch.equal(opt.square_avg, before_v)
+       and opt.skipped_steps() == skipped0 + 1, (opt.skipped_steps(), skipped0))
+    l3, _ = net.loss_and_backward(img.cuda(), t(pts).cuda()); opt.step()
+    ok('the next finite step is applied', not torch.equal(net.flat_params, before_p) and opt.skipped_steps() == skipped0 + 1 and bool(torch.isfinite(net.flat_params).all()))
     print('ALL FP16 CHECKS PASSED', flush=True)
 
 

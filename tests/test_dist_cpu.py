@@ -9,11 +9,11 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from oracle import step as ostep
+from tests._rendezvous import file_init_method, set_env
 
 
-def _worker(rank, world, port, out):
-    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    dist.init_process_group('gloo', rank=rank, world_size=world)
+def _worker(rank, world, init, out):
+    dist.init_process_group('gloo', init_method=init, rank=rank, world_size=world)
     from pose_adv_aug_amd.utils.optim import RMSprop
     from pose_adv_aug_amd.stack_hg import broadcast_parameters
     n = 1000
@@ -39,8 +39,7 @@ def _worker(rank, world, port, out):
 def test_flat_gradient_allreduce_world2():
     mgr = mp.Manager()
     out = mgr.dict()
-    port = 29500 + (os.getpid() % 500)
-    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, file_init_method(), out), nprocs=2, join=True)
     p0, g0, s0, b0 = out[0]
     p1, g1, s1, b1 = out[1]
     assert s0 == s1 == 0.5
@@ -53,9 +52,9 @@ def test_flat_gradient_allreduce_world2():
     assert torch.allclose(p0, pref)
 
 
-def _main_worker(rank, world, port, exp_dir, out):
+def _main_worker(rank, world, init, exp_dir, out):
     """stack_hg.main() -- the REAL host control flow -- on 2 gloo ranks with the engine stubbed at the C ABI."""
-    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    set_env(rank, world, init)
     from tests import abi_stub
     fake = abi_stub.install(rank)
     orig_ar, orig_save = dist.all_reduce, torch.save
@@ -93,8 +92,7 @@ def test_training_main_on_two_ranks_with_the_engine_stubbed_at_the_abi(tmp_path)
     are all-reduced (2 x names numbers, at print time only); rank 0 alone writes checkpoints."""
     mgr = mp.Manager()
     out = mgr.dict()
-    port = 29500 + ((os.getpid() + 7) % 500)
-    mp.spawn(_main_worker, args=(2, port, str(tmp_path), out), nprocs=2, join=True)
+    mp.spawn(_main_worker, args=(2, file_init_method(), str(tmp_path), out), nprocs=2, join=True)
     r0, r1 = out[0], out[1]
     assert torch.equal(r0['params'], r1['params']) and torch.equal(r0['buffers'], r1['buffers'])
     for r in (r0, r1):

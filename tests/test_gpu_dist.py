@@ -7,12 +7,13 @@ import pytest
 import torch
 import torch.multiprocessing as mp
 
+from tests._rendezvous import file_init_method, set_env
+
 pytestmark = pytest.mark.gpu
 
 
-def _worker(rank, world, port, out, overlap=False, stacks=1):
-    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0',
-                      POSEADV_DIST_BACKEND='gloo')
+def _worker(rank, world, init, out, overlap=False, stacks=1):
+    set_env(rank, world, init, local_rank=0, POSEADV_DIST_BACKEND='gloo')
     import torch.distributed as dist
     from pose_adv_aug_amd.stack_hg import init_distributed, broadcast_parameters, train_step
     from pose_adv_aug_amd.models.asn_stacked_hg import create_hg
@@ -51,8 +52,7 @@ def test_two_process_data_parallel_step_on_the_engine():
     ctx = mp.get_context('spawn')
     mgr = ctx.Manager()
     out = mgr.dict()
-    port = 29500 + ((os.getpid() + 13) % 500)
-    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, file_init_method(), out), nprocs=2, join=True)
     r0, r1 = out[0], out[1]
     assert torch.equal(r0['start'], r1['start'])                                  # broadcast: rank 0's initialisation everywhere
     assert torch.equal(r0['params'], r1['params']) and torch.equal(r0['grads'], r1['grads'])      # identical replicas, summed gradient
@@ -92,8 +92,7 @@ def test_overlapped_gradient_exchange_gives_the_same_result():
     res = {}
     for overlap in (False, True):
         out = ctx.Manager().dict()
-        port = 29500 + ((os.getpid() + 29 + int(overlap)) % 500)
-        mp.spawn(_worker, args=(2, port, out, overlap, 2), nprocs=2, join=True)
+        mp.spawn(_worker, args=(2, file_init_method(), out, overlap, 2), nprocs=2, join=True)
         res[overlap] = (out[0], out[1])
     a0, a1 = res[False]
     b0, b1 = res[True]
@@ -103,3 +102,72 @@ def test_overlapped_gradient_exchange_gives_the_same_result():
     step = b0['calls'][:per_step]
     assert [c for c in step if c[1]] and len([c for c in step if c[1]]) == 2          # one asynchronous bucket per stack
     assert sum(c[0] for c in step) == b0['nparams']                                    # every gradient exchanged exactly once
+
+
+def _joint_worker(rank, world, init, exp_dir, out):
+    """joint_train_pose_s_r_agent.main() on `world` ranks with the REAL engine (both on the one GPU, gloo collectives)."""
+    set_env(rank, world, init, local_rank=0, POSEADV_DIST_BACKEND='gloo')
+    import torch.distributed as dist
+    from pose_adv_aug_amd import joint_train_pose_s_r_agent as J
+    from pose_adv_aug_amd.models import asn_stacked_hg as M
+    reduces, bins, saves, nets = [], [], [], {}
+    orig_ar, orig_bins, orig_save = dist.all_reduce, J.sample_bins, torch.save
+
+    def all_reduce(t, *a, **k):
+        reduces.append(t.numel())
+        return orig_ar(t, *a, **k)
+
+    def sample_bins(logits, seed, step, slot):
+        probs, idx = orig_bins(logits, seed, step, slot)
+        bins.append((int(step), int(slot), idx.cpu().tolist()))
+        return probs, idx
+
+    def save(obj, path, *a, **k):
+        saves.append(os.path.basename(path))
+        return orig_save(obj, path, *a, **k)
+    dist.all_reduce, J.sample_bins, torch.save = all_reduce, sample_bins, save
+    for name in ('create_hg', 'create_asn'):
+        def wrap(f=getattr(M, name), name=name):
+            def g(*a, **k):
+                nets[name] = f(*a, **k)
+                return nets[name]
+            return g
+        setattr(M, name, wrap())
+    J.main(['--exp_dir', exp_dir, '--exp_id', 'run', '--bs', '2', '--print_freq', '1', '--data_dir', os.path.join(exp_dir, 'nodata'),
+            '--is_train', '1', '--load_prefix_pose', 'lr-0.00025-0.pth.tar', '--load_prefix_sr', 'lr-0.00025-0.pth.tar', '--nEpochs', '2'])
+    torch.cuda.synchronize()
+    hg, asn = nets['create_hg'], nets['create_asn']
+    out[rank] = dict(reduces=reduces, bins=bins, saves=saves, hg=hg.flat_params.cpu(), asn=asn.flat_params.cpu(),
+                     hg_buf=hg.flat_buffers.cpu(), n_hg=hg.flat_params.numel(), n_asn=asn.flat_params.numel())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_joint_stage_main_on_two_ranks(tmp_path):
+    """BASELINE configs[3] is a data-parallel configuration (joint-train-pose-s-r-agent.py:62,90 wrap BOTH nets in DataParallel):
+    main() of the joint stage on 2 ranks.  Both replicas of both nets are broadcast from rank 0 and stay bit-identical; per pose
+    step ONE all-reduce of the pose net's flat gradient, per epoch ONE of the agent's (train_agent_sr: one batch); the ranks draw
+    their own bins from their own shards (seed, step counters shared, logits differ); rank 0 alone writes pose-* / agent-* files."""
+    from pose_adv_aug_amd import stack_hg, pretrain_s_r_agent
+    exp = str(tmp_path)
+    base = ['--exp_dir', exp, '--exp_id', 'run', '--bs', '2', '--print_freq', '1', '--data_dir', str(tmp_path / 'nodata')]
+    stack_hg.main(base + ['--is_train', '1', '--nEpochs', '1'])                         # the two checkpoints stage 3 starts from
+    pretrain_s_r_agent.main(base + ['--is_train', '1', '--nEpochs', '1', '--load_prefix_pose', 'lr-0.00025-0.pth.tar'])
+    torch.cuda.synchronize()
+    ctx = mp.get_context('spawn')
+    out = ctx.Manager().dict()
+    mp.spawn(_joint_worker, args=(2, file_init_method(), exp, out), nprocs=2, join=True)
+    r0, r1 = out[0], out[1]
+    assert torch.equal(r0['hg'], r1['hg']) and torch.equal(r0['asn'], r1['asn'])       # identical replicas of both nets at the end
+    assert not torch.equal(r0['hg_buf'], r1['hg_buf'])                                  # per-rank BatchNorm statistics
+    for r in (r0, r1):
+        big = [n for n in r['reduces'] if n in (r['n_hg'], r['n_asn'])]
+        # every rank has its own 4 synthetic batches: 4 pose steps, then the epoch's single agent update
+        assert big == [r['n_hg']] * 4 + [r['n_asn']], big
+        assert all(n <= 64 or n in (r['n_hg'], r['n_asn']) for n in r['reduces'])       # everything else: the meters' tables
+    steps0 = [(s, sl) for s, sl, _ in r0['bins']]
+    assert steps0 == [(s, sl) for s, sl, _ in r1['bins']] and len(steps0) == 6          # the two odd pose steps (2 draws each) + the agent update (2 draws)
+    assert [b for _, _, b in r0['bins']] != [b for _, _, b in r1['bins']]               # own shards -> own logits -> own bins
+    assert sorted(f for f in r0['saves'] if f.endswith('.pth.tar')) == ['agent-lr-0.00005-1.pth.tar', 'pose-lr-0.00025-1.pth.tar'] and r1['saves'] == []
+    jd = os.path.join(exp, 'run', 'joint-lr-0.00025-0')
+    assert os.path.isfile(os.path.join(jd, 'pose-lr-0.00025-1-preds.mat')) and 'loss_agent_sr' in open(os.path.join(jd, 'train-log.txt')).read()
