@@ -463,3 +463,69 @@ def agent_aug(c, s, width, scale_idx, rot_idx, z_scale, z_rot, u_flip, u_gain):
         c[0] = width - c[0]
     gains = [0.6 + (1.4 - 0.6) * u for u in u_gain]
     return c.numpy().astype(np.float64), float(s[0]), float(r), bool(flip), gains
+
+
+# ---- one whole dataset sample (the composition of the pieces above)
+def _mpii_record(a):
+    """data/mpii_for_mpii.py:86-104 (= data/joint_train_s_r_agent.py:105-121): joints, centre, scale, normaliser of one
+    annotation entry as the torch.FloatTensor quantities of the reference."""
+    pts = torch.tensor(a['joint_self'], dtype=torch.float32)[:, 0:2].clone()
+    c = torch.tensor(a['objpos'], dtype=torch.float32)
+    s = torch.tensor([a['scale_provided']], dtype=torch.float32)
+    assert a['dataset'] == 'MPII'
+    c[1] = c[1] + 15 * s[0]
+    s = s * 1.25
+    return pts, c, s, a['normalizer'] * 0.6
+
+
+def _img_heatmap(frame_u8, c, s, r, pts, flip, gains, inp_res, out_res, quirk):
+    """gen_img_heatmap (data/joint_train_s_r_agent.py:186-205) = data/mpii_for_mpii.py:137-152: crop, joints to heat-map
+    coordinates, unannotated joints (x <= 0 or y <= 0 in the image) to 0, Gaussian maps.  c, pts: AFTER the mirror."""
+    from . import crop as ocrop
+    img = ocrop.source_image(frame_u8, flip, gains)
+    inp = ocrop.crop(img, c.numpy(), s.numpy(), r, inp_res, 200, quirk)
+    inp = np.ascontiguousarray(inp.transpose(2, 0, 1)).astype(np.float32) / np.float32(255)
+    pts_aug = transform_pts(pts.numpy(), c.numpy(), s.numpy(), r, out_res, 200)
+    gone = ((pts[:, 0] <= 0) | (pts[:, 1] <= 0)).numpy()
+    pts_aug[gone, :] = 0
+    heat, _ = pts2heatmap(pts_aug, [out_res, out_res], sigma=1)
+    return inp, heat.astype(np.float32)
+
+
+def mpii_getitem(frame_u8, a, draws=None, is_train=True, inp_res=256, out_res=64, quirk=True):
+    """MPII.__getitem__ (data/mpii_for_mpii.py:83-163) for one annotation entry `a` and its decoded frame, with the
+    np.random draws of the call passed in (draws[7]: randn, randn, then five random_sample() -- tests/inputs.legacy_draws).
+    Returns (inp [3][res][res] fp32, heatmap [16][64][64] fp32, c [2], s [1], r [1], pts [16][2], normalizer)."""
+    pts, c, s, normalizer = _mpii_record(a)
+    r, flip, gains = 0, False, (1., 1., 1.)
+    width = frame_u8.shape[1]
+    if is_train:
+        c_np, s_f, r, flip, gains = regular_aug(c.numpy(), float(s[0]), width, draws[0], draws[1], draws[2], draws[3], draws[4:7])
+        c, s = torch.from_numpy(c_np.astype(np.float32)), torch.tensor([s_f], dtype=torch.float32)
+        if flip:
+            pts = torch.from_numpy(shufflelr(pts.numpy(), width)).float()
+    inp, heat = _img_heatmap(frame_u8, c, s, r, pts, flip, gains, inp_res, out_res, quirk)
+    return inp, heat, c.numpy(), s.numpy(), np.array([r], dtype=np.float32), pts.numpy(), normalizer
+
+
+def agent_getitem(frame_u8, a, scale_idx, rot_idx, draws, separate_s_r=False, inp_res=256, out_res=64, quirk=True):
+    """AGENT.__getitem__ with the bins given (data/joint_train_s_r_agent.py:98-177).  separate_s_r False: ONE crop at
+    (agent scale, agent rotation) behind flip + colour -> the 7-tuple; True: [scale-only crop, rotation-only crop] (no
+    flip, no colour; draws[0:2] only) -> two 7-tuples."""
+    pts, c, s, normalizer = _mpii_record(a)
+    width = frame_u8.shape[1]
+    if not separate_s_r:
+        c_np, s_f, r, flip, gains = agent_aug(c.numpy(), float(s[0]), width, scale_idx, rot_idx, draws[0], draws[1], draws[2], draws[3:6])
+        c2, s2 = torch.from_numpy(c_np.astype(np.float32)), torch.tensor([s_f], dtype=torch.float32)
+        if flip:
+            pts = torch.from_numpy(shufflelr(pts.numpy(), width)).float()
+        inp, heat = _img_heatmap(frame_u8, c2, s2, r, pts, flip, gains, inp_res, out_res, quirk)
+        return inp, heat, c2.numpy(), s2.numpy(), np.array([r], dtype=np.float32), pts.numpy(), normalizer
+    f = small_gaussian(SCALE_MEANS[scale_idx], 0.05, draws[0])
+    r_aug = small_gaussian(ROT_MEANS[rot_idx], 5, draws[1])
+    s_aug = s * (2 ** f)
+    out = []
+    for ss, rr in ((s_aug, 0), (s, r_aug)):
+        inp, heat = _img_heatmap(frame_u8, c, ss, rr, pts, False, (1., 1., 1.), inp_res, out_res, quirk)
+        out.append((inp, heat, c.numpy(), ss.numpy(), np.array([rr], dtype=np.float32), pts.numpy(), normalizer))
+    return out

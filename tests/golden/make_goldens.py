@@ -398,10 +398,91 @@ def gen_crop(R):
     print('crop.npz', len(out), 'arrays', os.path.getsize(os.path.join(OUT, 'crop.npz')) // 1024, 'KB')
 
 
+def gen_dataset(R):
+    """Missing piece of round 2: ONE WHOLE dataset sample, JSON -> (inp, heatmap, c, s, r, pts, normalizer), through the
+    reference's own MPII.__getitem__ (data/mpii_for_mpii.py:83-163, train and val) and AGENT.__getitem__
+    (data/joint_train_s_r_agent.py:98-177, bins given / separate_s_r) with np.random seeded, on the 3-person set of
+    tests/inputs.py written to /tmp as JSON + PNG.  Pins the COMPOSITION: the call order of the draws, `c.x = W - c.x`
+    before the crop, shufflelr before TransformPts, the `pts <= 0` zeroing, heat maps from the transformed joints.
+    torchvision / matplotlib are imported (never used) by the reference's data / utils modules and are absent here: empty
+    stand-in modules satisfy the import; scipy.misc.imread = PIL open + convert('RGB') (scipy 0.19 pilutil.imread)."""
+    import types
+    import scipy.misc
+    from PIL import Image
+    from tests import inputs
+    for name in ('torchvision', 'torchvision.transforms', 'matplotlib', 'matplotlib.pyplot'):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules['torchvision'].transforms = sys.modules['torchvision.transforms']
+    sys.modules['matplotlib'].pyplot = sys.modules['matplotlib.pyplot']
+    scipy.misc.imread = lambda path, mode='RGB': np.array(Image.open(path).convert(mode))
+    sys.path.insert(0, TMP)
+    from data import mpii_for_mpii as D
+    from data import joint_train_s_r_agent as A
+    folder = '/tmp/ref3_goldens_dataset'
+    if os.path.isdir(folder):
+        shutil.rmtree(folder)
+    jpath, frames, anno = inputs.write_dataset(folder)
+    out = {'frame_sums': np.array([int(f.astype(np.int64).sum()) for f in frames])}
+
+    def pack(tag, inp, heat, c, s, r, pts, normalizer):
+        b = np.rint(inp.numpy() * 255.0).astype(np.uint8)                    # the crop's bytes (im_to_torch divided by 255)
+        assert np.array_equal((b.astype(np.float32) / 255).astype(np.float32), inp.numpy()), tag
+        out[tag + '_inp_sub'] = b[:, 1::4, 2::4].copy()
+        out[tag + '_inp_sums'] = np.array([b[k].astype(np.int64).sum() for k in range(3)] + [(b[k].astype(np.int64) ** 2).sum() for k in range(3)])
+        out[tag + '_heat'] = heat.numpy()
+        out[tag + '_c'] = np.asarray(c.numpy(), dtype=np.float32)
+        out[tag + '_s'] = np.asarray(s.numpy(), dtype=np.float32)
+        out[tag + '_r'] = np.asarray(r.numpy(), dtype=np.float32)
+        out[tag + '_pts'] = np.asarray(pts.numpy(), dtype=np.float32)
+        out[tag + '_normalizer'] = np.float64(normalizer)
+        return b
+
+    train = D.MPII(jpath, folder, is_train=True)
+    val = D.MPII(jpath, folder, is_train=False)
+    assert len(train) == 2 and len(val) == 1
+    seeds = [11, 12, 13, 14, 15, 16]
+    flips, rots = [], []
+    for index in (0, 1):
+        for seed in seeds:
+            np.random.seed(seed)
+            inp, heat, c, s, r, pts, normalizer = train[index]
+            d = inputs.legacy_draws(seed)
+            flips.append(d[3] <= 0.5); rots.append(float(r[0]) != 0)
+            b = pack('train%d_seed%d' % (index, seed), inp, heat, c, s, r, pts, normalizer)
+            if index == 0 and seed == seeds[0]:
+                out['train0_seed%d_inp_full' % seed] = b
+    assert any(flips) and not all(flips) and any(rots) and not all(rots), (flips, rots)
+    inp, heat, c, s, r, pts, normalizer, index = val[0]
+    assert index == 0
+    pack('val0', inp, heat, c, s, r, pts, normalizer)
+    # the agent's dataset: bins given (separate_s_r False: flip + colour as in the regular law) ...
+    ag = A.AGENT(jpath, folder, separate_s_r=False)
+    ag.img_index_list, ag.scale_index_list, ag.rotation_index_list = [1, 0], [5, 1], [0, 6]
+    for k in (0, 1):
+        np.random.seed(21 + k)
+        inp, heat, c, s, r, pts, normalizer, idx = ag[k]
+        assert idx == ag.img_index_list[k]
+        pack('agent%d' % k, inp, heat, c, s, r, pts, normalizer)
+    out['agent_img_index'] = np.array(ag.img_index_list); out['agent_scale_index'] = np.array(ag.scale_index_list)
+    out['agent_rot_index'] = np.array(ag.rotation_index_list)
+    # ... and separate_s_r (scale-only crop, rotation-only crop; no flip, no colour), bins given
+    ag2 = A.AGENT(jpath, folder, separate_s_r=True)
+    ag2.img_index_list, ag2.scale_index_list, ag2.rotation_index_list = [0], [6], [2]
+    np.random.seed(31)
+    img_list, heat_list, c_list, s_list, r_list, pts_list, norm_list, idx = ag2[0]
+    for k, name in enumerate(('sep_scale', 'sep_rot')):
+        pack(name, img_list[k], heat_list[k], c_list[k], s_list[k], r_list[k], pts_list[k], norm_list[k])
+    np.savez_compressed(os.path.join(OUT, 'dataset.npz'), **out)
+    print('dataset.npz', len(out), 'arrays', os.path.getsize(os.path.join(OUT, 'dataset.npz')) // 1024, 'KB; flips', flips, 'rotated', rots)
+
+
 if __name__ == '__main__':
     R = load_ref()
     if len(sys.argv) > 1 and sys.argv[1] == 'crop':
         gen_crop(R)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'dataset':
+        gen_dataset(R)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'nets':
         gen_nets(R)
@@ -410,3 +491,4 @@ if __name__ == '__main__':
     gen_nets(R)
     gen_dropout(R)
     gen_crop(R)
+    gen_dataset(R)

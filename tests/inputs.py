@@ -104,3 +104,50 @@ WARP_CASES = [
     ('smooth',  (300.0, 500.0), 2.0, 0.0, 0, (1.0, 1.0, 1.0), False),      # no pure black / white in the crop: the byte-scaling quirk
     ('smooth',  (300.0, 500.0), 3.3, -20.0, 0, (1.0, 1.0, 1.0), False),    # the quirk after the pre-downscale
 ]
+
+
+# ---- a 3-person MPII-format set (JSON + image files) for the whole-sample golden (tests/golden/dataset.npz)
+DATASET_FRAMES = (('smooth', 540, 960), ('checker', 480, 640), ('smooth', 600, 800))
+
+
+def dataset_people():
+    """(frames uint8, annotation list in the JSON format data/mpii_for_mpii.py:28-42 reads).  Person 0, 1: training split,
+    person 2: validation.  Joints around the person's centre at the person's scale; one joint of person 0 is unannotated
+    (0, 0) and one of person 1 lies left of the frame (x < 0): both take the `pts <= 0` branch of :144-147."""
+    frames = [warp_frame(kind, H, W) for kind, H, W in DATASET_FRAMES]
+    g = rng(4711)
+    anno = []
+    for i, (f, (cx, cy, sc)) in enumerate(zip(frames, ((470.0, 250.0, 1.9), (300.5, 228.25, 1.35), (410.0, 310.0, 3.1)))):
+        joints = np.stack([cx + g.normal(0, 1, 16) * 40 * sc, cy + g.normal(0, 1, 16) * 55 * sc, np.ones(16)], 1)
+        joints = np.round(joints, 2)
+        _mark_squares(f, int(cx) - 40, int(cy) + 10)          # pure black + pure white inside every crop window of this person
+        if i == 0:
+            joints[6] = 0.0
+        if i == 1:
+            joints[3, 0] = -12.5
+        anno.append({'dataset': 'MPII', 'isValidation': 1.0 if i == 2 else 0.0, 'img_paths': 'person%d.png' % i,
+                     'objpos': [cx, cy], 'scale_provided': sc, 'joint_self': joints.tolist(), 'normalizer': 60.0 * sc + 0.5 * i})
+    return frames, anno
+
+
+def write_dataset(folder):
+    """Write the set as <folder>/mpii-hr-lsp-normalizer.json + PNG files (lossless: every decoder returns the same bytes)."""
+    import json
+    import os
+    from PIL import Image
+    frames, anno = dataset_people()
+    os.makedirs(folder, exist_ok=True)
+    for a, f in zip(anno, frames):
+        Image.fromarray(f).save(os.path.join(folder, a['img_paths']))
+    path = os.path.join(folder, 'mpii-hr-lsp-normalizer.json')
+    with open(path, 'w') as fd:
+        json.dump(anno, fd)
+    return path, frames, anno
+
+
+def legacy_draws(seed):
+    """The np.random draws of ONE __getitem__ in the reference's call order, as the raw numbers pa_sample_aug_given takes:
+    randn (scale), randn (rotation), random_sample x 5 (rotation forced to 0, flip, three gains) -- RandomState.uniform(lo, hi) is
+    lo + (hi - lo) * random_sample(), so a second RandomState with the same seed yields the same stream."""
+    st = np.random.RandomState(seed)
+    return np.array([st.randn(), st.randn()] + [st.random_sample() for _ in range(5)], dtype=np.float64)

@@ -186,3 +186,46 @@ def test_every_node_of_the_training_graph_matches_locally():
         total = contrib['xin%d' % i] + (a_x.grad if inner else 0)
         node_grad('xin%d' % i, total, pending_bn=(i == 0))
     assert not errs, '%d local mismatches, first: %s' % (len(errs), errs[:15])
+
+
+def test_blocks_of_every_resolution_match_locally_at_the_benchmark_size():
+    """BASELINE configs[1] at FULL size (2-stack, chan 256, B = 24): one residual block per map size of stack 0 -- skip1 (64x64),
+    skip2 (32x32), skip3 (16x16), skip4 (8x8), neck (4x4) -- checked in place like the small net above: forward of conv1 / conv2 /
+    conv3 (1e-2), every parameter gradient and the two inner masked gradients (4e-2, cosine 0.999).  This pins the template
+    instances only the large grid reaches (row-tile 1x1 kernels looping over channel blocks with >= 512 tiles, XCD-contiguous
+    3x3 tile ranges, 1536-row BatchNorm statistics) INSIDE the fused training graph, streams and all."""
+    torch.set_num_threads(max(16, torch.get_num_threads()))
+    bf16_emul.ROUND_GRADS = True
+    stacks, B, res, chan = 2, 24, 256, 256
+    ref, net = _hg_pair(stacks, chan, B, res, seed=11)
+    img = t(inputs.images(41, B, res))
+    pts = inputs.heat_pts(42, B, res=res // 4)
+    ref.train(); net.train()
+    net.loss_and_backward(img.cuda(), t(pts).cuda())
+    P = Probe(net)
+    hip_grads = {n: g.cpu() for n, g in net.named_grads()}
+    errs = []
+    hg = ref.hg[0]
+    sites = [(hg.skip1[0], 'hg.0.skip1.0.', 'xin0', 'hg0.skip1'), (hg.skip2[0], 'hg.0.skip2.0.', 'hg0.down1', 'hg0.skip2'),
+             (hg.skip3[0], 'hg.0.skip3.0.', 'hg0.down2', 'hg0.skip3'), (hg.skip4[0], 'hg.0.skip4.0.', 'hg0.down3', 'hg0.skip4'),
+             (hg.neck[0], 'hg.0.neck.0.', 'hg0.down4', 'hg0.neck')]
+    sizes = []
+    for blk, prefix, in_name, out_name in sites:
+        a_in = _leaf(P.act(in_name))
+        sizes.append(a_in.shape[-1])
+        tap = {}
+        a3 = emul_residual(blk, a_in, tap, out_name)
+        for k in ('.x1', '.x2', ''):
+            _close(errs, 'fwd ' + out_name + k, P.act(out_name + k), tap[out_name + k].detach(), FWD_TOL)
+        blk.zero_grad()
+        a3.backward(P.grad(out_name))
+        for n, p in blk.named_parameters():
+            full = prefix + n
+            if n.startswith('conv') and n.endswith('bias'):
+                continue                                  # bias in front of a BatchNorm: exactly zero in the engine, rounding noise in autograd
+            _close(errs, 'grad ' + full, hip_grads[full], p.grad, GRAD_TOL, GRAD_COS)
+        for k in ('.x1', '.x2'):
+            inner = tap[out_name + k]
+            _close(errs, 'dz ' + out_name + k, P.grad(out_name + k), inner.grad * (inner.detach() > 0).float(), GRAD_TOL, GRAD_COS)
+    assert sizes == [64, 32, 16, 8, 4]
+    assert not errs, '%d local mismatches, first: %s' % (len(errs), errs[:15])

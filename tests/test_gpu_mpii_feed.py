@@ -1,5 +1,6 @@
 """Real-data feed: MPII-format JSON + image files -> DeviceBatch with per-sample frame sizes."""
 import json
+import os
 
 import numpy as np
 import pytest
@@ -125,3 +126,80 @@ def test_abandoned_passes_return_their_frame_slots(tmp_path):
     first = [next(iter(feed)).index for _ in range(12)]          # 12 abandoned passes with 4 slots
     assert first == [[0]] * 12
     assert [b.index for b in feed] == [[0], [1], [2], [3]]
+
+
+def _engine_sample(ds, index, mode, draws7, si=None, ri=None):
+    """one person through the product path: JSON + PNG -> MPII.load_batch -> law with the given draws -> device crop, joints,
+    heat maps.  Returns (crop bytes [3][256][256], heat [16][64][64], c, s, r, grnd pts, normalizer, params row)."""
+    from pose_adv_aug_amd._lib import lib, check, ptr, stream
+    from pose_adv_aug_amd.data import Augmenter
+    from pose_adv_aug_amd.pylib import HumanAug, HumanPts
+    batch = ds.load_batch([index])
+    aug = Augmenter(seed=0)
+    if mode is None:                                   # validation: the un-augmented crop
+        data = aug.standard(batch)
+    else:
+        dd = torch.from_numpy(np.asarray(draws7, dtype=np.float64).reshape(1, 7)).cuda()
+        dsi = None if si is None else torch.tensor([si], dtype=torch.int32).cuda()
+        dri = None if ri is None else torch.tensor([ri], dtype=torch.int32).cuda()
+        check(lib().pa_sample_aug_given(ptr(batch.meta), ptr(dsi), ptr(dri), mode, ptr(dd), 1, ptr(batch.params), stream()))
+        data = aug._finish(batch)
+    _, _, u8 = HumanAug.crop_batch(batch.frames, batch.params, res=256, want_nhwc4=False, want_u8=True, sizes=batch.sizes)
+    heat = HumanPts.pts2heatmap_batch(data['pts'], 64, 64)
+    return (u8[0].permute(2, 0, 1).cpu().numpy(), heat[0].cpu().numpy(), data['c'][0].cpu().numpy(), float(data['s'][0]), float(data['r'][0]),
+            data['grnd_pts'][0].cpu().numpy(), float(data['normalizer'][0]), data['img4'][0].float().cpu().numpy())
+
+
+def test_whole_samples_equal_the_reference_dataset_golden(tmp_path):
+    """tests/golden/dataset.npz holds what the REFERENCE's MPII.__getitem__ / AGENT.__getitem__ return for seeded np.random
+    draws (data/mpii_for_mpii.py:83-163, data/joint_train_s_r_agent.py:98-177; tests/golden/make_goldens.py gen_dataset).  The
+    product path -- mpii_for_mpii.MPII from the same JSON + PNG files, the same draws through pa_sample_aug_given, pa_crop,
+    pa_transform_pts, the Gaussian maps -- gives the same 7-tuple: heat maps bit for bit, c / s / r / joints / normaliser exactly,
+    crop bytes exactly whenever scipy's per-image byte stretch is the identity (a black and a white pixel inside the crop:
+    SURVEY.md Appendix A.13; otherwise the device equals the oracle without that accident, which test_oracle_golden pins)."""
+    from oracle import pylib as opl
+    from pose_adv_aug_amd.mpii_for_mpii import MPII
+    G = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'dataset.npz'))
+    path, frames, anno = inputs.write_dataset(str(tmp_path))
+    tr = MPII(path, str(tmp_path), is_train=True, log=lambda *_: None)
+    va = MPII(path, str(tmp_path), is_train=False, log=lambda *_: None)
+    exact_crops = 0
+
+    def check_sample(tag, got, frame, oracle_sample):
+        nonlocal exact_crops
+        u8, heat, c, s, r, pts, normalizer, img4 = got
+        assert np.array_equal(heat, G[tag + '_heat']), tag                                   # heat maps bit for bit
+        assert np.array_equal(c.astype(np.float32), G[tag + '_c']) and np.float32(s) == G[tag + '_s'].reshape(-1)[0], tag
+        assert np.float32(r) == G[tag + '_r'].reshape(-1)[0] and np.array_equal(pts.astype(np.float32), G[tag + '_pts']), tag
+        assert abs(normalizer - float(G[tag + '_normalizer'])) <= 1e-6 * float(G[tag + '_normalizer']), tag
+        plain = np.rint(oracle_sample(False)[0] * 255).astype(np.uint8)                     # the oracle without scipy's stretch
+        assert np.array_equal(u8, plain), tag                                               # ... is what the device computes, byte for byte
+        sums = np.array([u8[k].astype(np.int64).sum() for k in range(3)] + [(u8[k].astype(np.int64) ** 2).sum() for k in range(3)])
+        if np.array_equal(u8[:, 1::4, 2::4], G[tag + '_inp_sub']) and np.array_equal(sums, G[tag + '_inp_sums']):
+            exact_crops += 1                                                                # equals the reference's own bytes
+        else:                                                                               # only where the stretch was NOT the identity
+            stretched = np.rint(oracle_sample(True)[0] * 255).astype(np.uint8)
+            assert not np.array_equal(stretched, plain), tag
+
+    n = 0
+    for index in (0, 1):
+        for seed in (11, 12, 13, 14, 15, 16):
+            d = inputs.legacy_draws(seed)
+            check_sample('train%d_seed%d' % (index, seed), _engine_sample(tr, index, 0, d), frames[index],
+                         lambda q, i=index, d=d: opl.mpii_getitem(frames[i], anno[i], d, True, quirk=q))
+            n += 1
+    check_sample('val0', _engine_sample(va, 0, None, None), frames[2], lambda q: opl.mpii_getitem(frames[2], anno[2], None, False, quirk=q))
+    for k in (0, 1):
+        st = np.random.RandomState(21 + k)
+        a = np.array([st.randn(), st.randn()] + [st.random_sample() for _ in range(4)])
+        d7 = np.array([a[0], a[1], 0.5, a[2], a[3], a[4], a[5]])                             # (slot 2, "rotation forced to 0", is not drawn by the agent's law)
+        i, si, ri = int(G['agent_img_index'][k]), int(G['agent_scale_index'][k]), int(G['agent_rot_index'][k])
+        check_sample('agent%d' % k, _engine_sample(tr, i, 1, d7, si, ri), frames[i],
+                     lambda q, i=i, si=si, ri=ri, a=a: opl.agent_getitem(frames[i], anno[i], si, ri, a, quirk=q))
+    st = np.random.RandomState(31)
+    a = np.array([st.randn(), st.randn(), 0, 0, 0, 0])
+    d7 = np.array([a[0], a[1], 0.5, 0.9, 0.5, 0.5, 0.5])
+    for mode, name, k in ((2, 'sep_scale', 0), (3, 'sep_rot', 1)):
+        check_sample(name, _engine_sample(tr, 0, mode, d7, 6, 2), frames[0],
+                     lambda q, k=k, a=a: opl.agent_getitem(frames[0], anno[0], 6, 2, a, separate_s_r=True, quirk=q)[k])
+    assert exact_crops >= 8, exact_crops                   # most crops carry a black and a white pixel: the reference's own bytes

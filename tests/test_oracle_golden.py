@@ -308,3 +308,46 @@ def test_augmentation_law_restatements():
     assert opl.regular_aug([1, 1], 1.0, 10.0, 0.0, 1.0, 0.6, 0.51, [0, 0, 0])[2:4] == (0.0, False)
     c, s, r, flip, _ = opl.agent_aug([100.0, 50.0], 2.0, 1280.0, 0, 6, -5.0, 5.0, 0.9, [0, 0, 0])
     assert abs(np.log2(s / 2.0) - (-0.6 - 0.05 + 1e-3)) < 1e-6 and r == 65.0 and not flip
+
+
+def _agent_draws(seed):
+    """np.random call order of AGENT.__getitem__ with bins given: randn (scale), randn (rotation), random (flip), 3 gains"""
+    st = np.random.RandomState(seed)
+    return np.array([st.randn(), st.randn()] + [st.random_sample() for _ in range(4)], dtype=np.float64)
+
+
+def _check_sample(D, tag, got):
+    inp, heat, c, s, r, pts, normalizer = got
+    b = np.rint(inp * 255.0).astype(np.uint8)
+    assert np.array_equal(b[:, 1::4, 2::4], D[tag + '_inp_sub']), tag
+    sums = np.array([b[k].astype(np.int64).sum() for k in range(3)] + [(b[k].astype(np.int64) ** 2).sum() for k in range(3)])
+    assert np.array_equal(sums, D[tag + '_inp_sums']), tag
+    assert np.array_equal(heat, D[tag + '_heat']), tag                       # bit-exact heat maps
+    assert np.array_equal(np.asarray(c, np.float32), D[tag + '_c']) and np.array_equal(np.asarray(s, np.float32).reshape(-1), D[tag + '_s'].reshape(-1)), tag
+    assert np.array_equal(np.asarray(r, np.float32).reshape(-1), D[tag + '_r'].reshape(-1)), tag
+    assert np.array_equal(np.asarray(pts, np.float32), D[tag + '_pts']) and float(normalizer) == float(D[tag + '_normalizer']), tag
+
+
+def test_whole_dataset_samples_equal_the_reference():
+    """tests/golden/dataset.npz = the reference's MPII.__getitem__ (data/mpii_for_mpii.py:83-163; train with np.random seeded,
+    and val) and AGENT.__getitem__ (data/joint_train_s_r_agent.py:98-177; bins given, with and without separate_s_r) on the
+    3-person JSON + PNG set of tests/inputs.py: the oracle's composition reproduces every sample -- crop bytes, heat maps,
+    c, s, r, joints, normaliser -- exactly."""
+    D = load('dataset.npz')
+    frames, anno = inputs.dataset_people()
+    assert np.array_equal(np.array([int(f.astype(np.int64).sum()) for f in frames]), D['frame_sums'])
+    train = [0, 1]
+    for index in (0, 1):
+        for seed in (11, 12, 13, 14, 15, 16):
+            got = opl.mpii_getitem(frames[train[index]], anno[train[index]], inputs.legacy_draws(seed), is_train=True)
+            _check_sample(D, 'train%d_seed%d' % (index, seed), got)
+    _check_sample(D, 'val0', opl.mpii_getitem(frames[2], anno[2], None, is_train=False))
+    full = np.rint(opl.mpii_getitem(frames[0], anno[0], inputs.legacy_draws(11), is_train=True)[0] * 255).astype(np.uint8)
+    assert np.array_equal(full, D['train0_seed11_inp_full'])
+    for k in (0, 1):
+        i = int(D['agent_img_index'][k])
+        got = opl.agent_getitem(frames[train[i]], anno[train[i]], int(D['agent_scale_index'][k]), int(D['agent_rot_index'][k]), _agent_draws(21 + k))
+        _check_sample(D, 'agent%d' % k, got)
+    sep = opl.agent_getitem(frames[0], anno[0], 6, 2, _agent_draws(31), separate_s_r=True)
+    _check_sample(D, 'sep_scale', sep[0])
+    _check_sample(D, 'sep_rot', sep[1])
