@@ -178,6 +178,7 @@ static int row_bm(int Cin) {
 bool pa_conv1x1_tile_supported(const PaConvArgs& a) {
     if (a.taps != 1 || (a.Cin != 64 && a.Cin != 128 && a.Cin != 256) || a.Cout % 64 != 0) return false;
     const int M = a.B * a.H * a.W;
+    if ((size_t)M * (size_t)(a.Cin > a.Cout ? a.Cin : a.Cout) >= ((size_t)1 << 31)) return false;      // 32-bit element offsets in the epilogue
     return (M + row_bm(a.Cin) - 1) / row_bm(a.Cin) >= 192;          // smaller problems: generic kernel with 64x64 tiles
 }
 

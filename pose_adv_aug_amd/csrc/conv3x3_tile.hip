@@ -276,6 +276,7 @@ bool pa_conv3x3_tile_supported(const PaConvArgs& a) {
     static int nosmall = -1;
     if (nosmall < 0) nosmall = pa_getenv("PA_CONV3_NOSMALL") ? 1 : 0;
     if (a.taps != 9 || (a.Cin != 64 && a.Cin != 128) || a.Cout % 64 != 0) return false;
+    if ((size_t)a.B * a.H * a.W * (size_t)(a.Cin > a.Cout ? a.Cin : a.Cout) >= ((size_t)1 << 31)) return false;      // 32-bit element offsets in the epilogue
     return (a.H % 8 == 0 && a.W % 16 == 0) || (!nosmall && small_map(a));
 }
 

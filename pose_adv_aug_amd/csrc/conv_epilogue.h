@@ -65,12 +65,12 @@ __device__ __forceinline__ void pa_conv_epilogue(const PaConvArgs& a, f32x4 (&ac
 #pragma unroll
         for (int j = 0; j < 8; ++j) { s1[2 * ch + (j >> 2)][j & 3] = 0.f; s2[2 * ch + (j >> 2)][j & 3] = 0.f; }
         // ---- every operand of the chunk in flight first
-        size_t idx[MI];
+        unsigned idx[MI];                            // 32-bit element offsets: pa_launch_conv admits M * Cout < 2^31 only
         bf16x8 xr[MI], p1[MI], q1[MI], p2[MI], q2[MI];
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
             const int m = pix(mi);
-            idx[mi] = m < 0 ? (size_t)0 : (size_t)m * N + n;     // clamped: unconditional loads, the store is guarded
+            idx[mi] = m < 0 ? 0u : (unsigned)m * (unsigned)N + (unsigned)n;     // clamped: unconditional loads, the store is guarded
             if (a.ep.mode == PA_OUT_BWD) xr[mi] = *reinterpret_cast<const bf16x8*>(a.ep.xref + idx[mi]);
             if (m1 != PA_LD_NONE) p1[mi] = *reinterpret_cast<const bf16x8*>(a.add1.p + idx[mi]);
             if (m1 == PA_LD_LIN2) q1[mi] = *reinterpret_cast<const bf16x8*>(a.add1.q + idx[mi]);
@@ -180,7 +180,7 @@ __device__ __forceinline__ void pa_conv_epilogue_lds(const PaConvArgs& a, f32x4 
             if (m < 0) continue;
             const f32x4 v0 = *reinterpret_cast<const f32x4*>(T + r * BN + (((2 * chunk) ^ (r & 7)) << 2));
             const f32x4 v1 = *reinterpret_cast<const f32x4*>(T + r * BN + (((2 * chunk + 1) ^ (r & 7)) << 2));
-            const size_t idx = (size_t)m * N + n;
+            const unsigned idx = (unsigned)m * (unsigned)N + (unsigned)n;
             float e1[8], e2[8];
             pa_read8(a.add1, idx, n, e1);
             pa_read8(a.add2, idx, n, e2);
@@ -248,7 +248,7 @@ __device__ __forceinline__ void pa_conv_epilogue_lds_bwd(const PaConvArgs& a, f3
 #pragma unroll
     for (int g = 0; g < MI; g += G) {
         // ---- request everything the next G passes need
-        size_t idx[IT];
+        unsigned idx[IT];                            // 32-bit element offsets (the tile launchers admit M * Cout < 2^31 only)
         bool ok[IT];
         bf16x8 xr[IT], p1[IT], q1[IT], p2[IT];
 #pragma unroll
@@ -258,7 +258,7 @@ __device__ __forceinline__ void pa_conv_epilogue_lds_bwd(const PaConvArgs& a, f3
                 const int it = pp * SW + sw, r = sw * RPS + rsub;
                 const int m = pix(r >> 4, g + pp, r & 15);
                 ok[it] = m >= 0;
-                idx[it] = ok[it] ? (size_t)m * N + n : (size_t)0;
+                idx[it] = ok[it] ? (unsigned)m * (unsigned)N + (unsigned)n : 0u;
                 xr[it] = *reinterpret_cast<const bf16x8*>(a.ep.xref + idx[it]);
                 if (m1 != PA_LD_NONE) p1[it] = *reinterpret_cast<const bf16x8*>(a.add1.p + idx[it]);
                 if (m1 == PA_LD_LIN2) q1[it] = *reinterpret_cast<const bf16x8*>(a.add1.q + idx[it]);

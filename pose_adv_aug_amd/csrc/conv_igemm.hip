@@ -229,6 +229,10 @@ int pa_launch_conv(const PaConvArgs& a0, hipStream_t st, int* stat_rows) {
         pa_set_error_msg("pa_launch_conv: channel counts must be multiples of 64 and taps 1 or 9");
         return 1;
     }
+    if ((size_t)a.B * a.H * a.W * (size_t)(a.Cin > a.Cout ? a.Cin : a.Cout) >= ((size_t)1 << 31)) {      // the epilogues index with 32 bits
+        pa_set_error_msg("pa_launch_conv: tensors of 2^31 elements or more are not supported (split the batch)");
+        return 1;
+    }
     static int old3 = -1;
     if (old3 < 0) old3 = pa_getenv("PA_CONV3_OLD") ? 1 : 0;          // experiments: force the generic kernel
     if (!old3 && pa_conv3x3_tile_supported(a)) return pa_launch_conv3x3_tile(a, st, stat_rows);

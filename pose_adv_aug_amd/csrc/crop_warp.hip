@@ -30,6 +30,7 @@ struct CropPlan {
     int pad, rot_mode;     // rot_mode 0 none, 1 general, 2 = 180 deg, 3 = 90 deg, 4 = 270 deg (square window only)
     int dx0, dx1, dy0, dy1;   // part of the downscaled frame the window reads
     int sy0, sy1;          // source rows that part reads
+    int sx0, sx1;          // source columns (in the mirrored frame's coordinates) that part reads
     int flip;
     float gain[3];
     double m[6];           // PIL rotate's inverse affine map
@@ -146,10 +147,14 @@ __global__ void crop_plan_kernel(const double* params, const int* sizes, int Hs,
     P.dy0 = uly < 0 ? 0 : uly; P.dy1 = bry < P.hd ? bry : P.hd;
     if (P.dx1 < P.dx0) P.dx1 = P.dx0;
     if (P.dy1 < P.dy0) P.dy1 = P.dy0;
-    P.sy0 = 0; P.sy1 = 0;
+    P.sy0 = 0; P.sy1 = 0; P.sx0 = 0; P.sx1 = 0;
     if (P.case_b && P.dy1 > P.dy0) {
         const Taps t0 = taps_of(P.dy0, P.hb, P.sy), t1 = taps_of(P.dy1 - 1, P.hb, P.sy);
         P.sy0 = t0.xmin; P.sy1 = t1.xmin + t1.n;
+    }
+    if (P.case_b && P.dx1 > P.dx0) {
+        const Taps t0 = taps_of(P.dx0, P.wb, P.sx), t1 = taps_of(P.dx1 - 1, P.wb, P.sx);
+        P.sx0 = t0.xmin; P.sx1 = t1.xmin + t1.n;
     }
     plans[b] = P;
 }
@@ -173,39 +178,91 @@ __global__ void crop_coeff_kernel(const CropPlan* plans, int res, int* table, in
 }
 
 // ------------------------------------------------------------------------------------------------ pre-downscale
-// horizontal pass: T1[r - sy0][x - dx0] for source rows r in [sy0, sy1), downscaled columns x in [dx0, dx1)
-__global__ void crop_down_h_kernel(const unsigned char* src, int Hs, int Ws, const CropPlan* plans, const int* table, int axis_max,
-                                   uchar4* t1, size_t t1_stride, int t1_pitch) {
+// source pass: S[r - sy0][x - sx0] = the byte image crop() is handed (mirror, byte -> byte map of fp32 / 255 * gain, clamp,
+// toimage) as one uchar4 per pixel, for the source rows / columns the window's part of the downscaled frame reads.  The
+// horizontal pass then loads ONE dword per tap instead of three bytes and three table look-ups (that pass was bound by its
+// vector-memory and LDS instruction count: 110-280 us per batch; now a coalesced stream + register-resident taps).
+__global__ __launch_bounds__(256) void crop_src_kernel(const unsigned char* src, int Hs, int Ws, const CropPlan* plans, uchar4* s4, size_t s4_stride,
+                                                       int s4_pitch) {
     const CropPlan& P = plans[blockIdx.y];
     if (!P.case_b) return;
-    const int ncol = P.dx1 - P.dx0, nrow = P.sy1 - P.sy0;
+    const int ncol = P.sx1 - P.sx0, nrow = P.sy1 - P.sy0;
     const long total = (long)ncol * nrow;
     const unsigned char* img = src + (size_t)blockIdx.y * Hs * Ws * 3;
-    uchar4* out = t1 + (size_t)blockIdx.y * t1_stride;
-    // the byte -> byte map of this sample (fp32 / 255, gain, clamp, toimage: an IEEE division per pixel otherwise), once per block
+    uchar4* out = s4 + (size_t)blockIdx.y * s4_stride;
     __shared__ unsigned char lut[3][256];
     for (int k = threadIdx.x; k < 768; k += blockDim.x) lut[k >> 8][k & 255] = (unsigned char)src_byte((unsigned char)(k & 255), P.gain[k >> 8], true);
     __syncthreads();
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int r = (int)(i / ncol), xc = (int)(i - (long)r * ncol);
-        const int* e = tap_entry(table, blockIdx.y, 0, axis_max, xc);
+        const int r = (int)(i / ncol), x = (int)(i - (long)r * ncol);
+        const int xs = P.sx0 + x;
+        const unsigned char* px = img + ((size_t)(P.sy0 + r) * Ws + (P.flip ? P.wb - 1 - xs : xs)) * 3;
+        out[(size_t)r * s4_pitch + x] = make_uchar4(lut[0][px[0]], lut[1][px[1]], lut[2][px[2]], 0);
+    }
+}
+
+// horizontal pass: T1[r - sy0][x - dx0] for source rows r in [sy0, sy1), downscaled columns x in [dx0, dx1).
+// A thread owns ONE output column (its <= CW_HREG taps live in registers) and walks CW_HROWS rows of it.
+#define CW_HREG 12
+#define CW_HROWS 16
+template <int NT>
+__device__ __forceinline__ void down_h_rows(const uchar4* col, int s4_pitch, uchar4* out, int t1_pitch, int xc, int r0, int nrow, const int* e, int n) {
+    int w[NT];
+#pragma unroll
+    for (int k = 0; k < NT; ++k) w[k] = k < n ? e[2 + k] : 0;
+    // taps beyond n read the following pixels of the row (inside the buffer: it is padded by CW_HREG pixels) with weight 0
+#pragma unroll 2
+    for (int j = 0; j < CW_HROWS; ++j) {
+        const int r = r0 + 4 * j;
+        if (r >= nrow) break;
+        const uchar4* row = col + (size_t)r * s4_pitch;
         int a0 = 1 << (CW_PREC - 1), a1 = a0, a2 = a0;
-        const unsigned char* row = img + (size_t)(P.sy0 + r) * Ws * 3;
-        const int xmin = e[0], n = e[1];
+#pragma unroll
+        for (int k = 0; k < NT; ++k) {
+            const uchar4 px = row[k];
+            a0 += (int)px.x * w[k]; a1 += (int)px.y * w[k]; a2 += (int)px.z * w[k];
+        }
+        out[(size_t)r * t1_pitch + xc] = make_uchar4((unsigned char)clip8(a0), (unsigned char)clip8(a1), (unsigned char)clip8(a2), 0);
+    }
+}
+
+__global__ __launch_bounds__(256) void crop_down_h_kernel(const CropPlan* plans, const int* table, int axis_max, const uchar4* s4, size_t s4_stride,
+                                                          int s4_pitch, uchar4* t1, size_t t1_stride, int t1_pitch, int col_blocks) {
+    const CropPlan& P = plans[blockIdx.y];
+    if (!P.case_b) return;
+    const int ncol = P.dx1 - P.dx0, nrow = P.sy1 - P.sy0;
+    const int cb = blockIdx.x % col_blocks, rb = blockIdx.x / col_blocks;
+    const int xc = cb * 64 + (threadIdx.x & 63);
+    const int r0 = rb * (4 * CW_HROWS) + (threadIdx.x >> 6);
+    if (xc >= ncol || r0 >= nrow) return;
+    const uchar4* in = s4 + (size_t)blockIdx.y * s4_stride;
+    uchar4* out = t1 + (size_t)blockIdx.y * t1_stride;
+    const int* e = tap_entry(table, blockIdx.y, 0, axis_max, xc);
+    const int xmin = e[0], n = e[1];
+    if (n >= 0 && n <= CW_HREG) {
+        // (a sample's columns have n or n + 1 taps: the branch is uniform for almost every wave)
+        if (n <= 8) down_h_rows<8>(in + (xmin - P.sx0), s4_pitch, out, t1_pitch, xc, r0, nrow, e, n);
+        else down_h_rows<CW_HREG>(in + (xmin - P.sx0), s4_pitch, out, t1_pitch, xc, r0, nrow, e, n);
+        return;
+    }
+    for (int j = 0; j < CW_HROWS; ++j) {               // wide filters (scale factors above 5.5): taps from the table, or computed inline above 11
+        const int r = r0 + 4 * j;
+        if (r >= nrow) break;
+        int a0 = 1 << (CW_PREC - 1), a1 = a0, a2 = a0;
         if (n >= 0) {
+            const uchar4* row = in + (size_t)r * s4_pitch + (xmin - P.sx0);
             for (int k = 0; k < n; ++k) {
-                const int xs = xmin + k;
-                const unsigned char* px = row + (size_t)(P.flip ? P.wb - 1 - xs : xs) * 3;
+                const uchar4 px = row[k];
                 const int w = e[2 + k];
-                a0 += (int)lut[0][px[0]] * w; a1 += (int)lut[1][px[1]] * w; a2 += (int)lut[2][px[2]] * w;
+                a0 += (int)px.x * w; a1 += (int)px.y * w; a2 += (int)px.z * w;
             }
         } else {
             const Taps t = taps_of(P.dx0 + xc, P.wb, P.sx);
+            const uchar4* row = in + (size_t)r * s4_pitch + (t.xmin - P.sx0);
             for (int k = 0; k < t.n; ++k) {
-                const int xs = t.xmin + k;
-                const unsigned char* px = row + (size_t)(P.flip ? P.wb - 1 - xs : xs) * 3;
+                const uchar4 px = row[k];
                 const int w = tap_coeff(t, k);
-                a0 += src_byte(px[0], P.gain[0], true) * w; a1 += src_byte(px[1], P.gain[1], true) * w; a2 += src_byte(px[2], P.gain[2], true) * w;
+                a0 += (int)px.x * w; a1 += (int)px.y * w; a2 += (int)px.z * w;
             }
         }
         out[(size_t)r * t1_pitch + xc] = make_uchar4((unsigned char)clip8(a0), (unsigned char)clip8(a1), (unsigned char)clip8(a2), 0);
@@ -403,10 +460,10 @@ __global__ void crop_resize_v_kernel(const unsigned char* src, int Hs, int Ws, c
 // ------------------------------------------------------------------------------------------------ host
 struct CropLayout {
     int pad_b, nw_b, cw_max;           // worst-case padded window of the pre-downscale case, worst-case un-padded window
-    size_t plans, table, t1, d, u, t2, total; // byte offsets
+    size_t plans, table, s4, t1, d, u, t2, total; // byte offsets
     int axis_max;
-    size_t t1_stride, d_stride, u_stride, t2_stride;   // per-sample strides in pixels
-    int t1_pitch, d_pitch, u_pitch;
+    size_t s4_stride, t1_stride, d_stride, u_stride, t2_stride;   // per-sample strides in pixels
+    int s4_pitch, t1_pitch, d_pitch, u_pitch;
 };
 
 static CropLayout crop_layout(int B, int Hs, int Ws, int res) {
@@ -420,6 +477,8 @@ static CropLayout crop_layout(int B, int Hs, int Ws, int res) {
     L.plans = off; off = align(off + (size_t)B * sizeof(CropPlan));
     L.axis_max = L.nw_b > res ? L.nw_b : res;
     L.table = off; off = align(off + (size_t)B * 4 * L.axis_max * CW_ENTRY * sizeof(int));
+    L.s4_pitch = Ws; L.s4_stride = (size_t)Hs * Ws;                     // (+ CW_HREG pixels behind the last sample: zero-weight taps)
+    L.s4 = off; off = align(off + ((size_t)B * L.s4_stride + CW_HREG) * 4);
     L.t1_pitch = L.nw_b; L.t1_stride = (size_t)Hs * L.t1_pitch;
     L.t1 = off; off = align(off + (size_t)B * L.t1_stride * 4);
     L.d_pitch = L.nw_b; L.d_stride = (size_t)L.nw_b * L.d_pitch;
@@ -440,6 +499,7 @@ int pa_launch_crop(const unsigned char* src, int Hs, int Ws, const int* sizes, c
     char* ws = reinterpret_cast<char*>(workspace);
     CropPlan* plans = reinterpret_cast<CropPlan*>(ws + L.plans);
     int* table = reinterpret_cast<int*>(ws + L.table);
+    uchar4* s4 = reinterpret_cast<uchar4*>(ws + L.s4);
     uchar4* t1 = reinterpret_cast<uchar4*>(ws + L.t1);
     uchar4* d = reinterpret_cast<uchar4*>(ws + L.d);
     uchar4* u = reinterpret_cast<uchar4*>(ws + L.u);
@@ -448,7 +508,10 @@ int pa_launch_crop(const unsigned char* src, int Hs, int Ws, const int* sizes, c
     const int T = 256;
     auto blocks = [&](long n) { long g = (n + T - 1) / T; return (unsigned)(g < 1 ? 1 : (g > 1024 ? 1024 : g)); };
     hipLaunchKernelGGL(crop_coeff_kernel, dim3((L.axis_max + 63) / 64, B, 4), dim3(64), 0, st, plans, res, table, L.axis_max);
-    hipLaunchKernelGGL(crop_down_h_kernel, dim3(blocks((long)Hs * L.nw_b), B), dim3(T), 0, st, src, Hs, Ws, plans, table, L.axis_max, t1, L.t1_stride, L.t1_pitch);
+    hipLaunchKernelGGL(crop_src_kernel, dim3(96, B), dim3(T), 0, st, src, Hs, Ws, plans, s4, L.s4_stride, L.s4_pitch);
+    const int col_blocks = (L.axis_max + 63) / 64, row_blocks = (Hs + 4 * CW_HROWS - 1) / (4 * CW_HROWS);
+    hipLaunchKernelGGL(crop_down_h_kernel, dim3(col_blocks * row_blocks, B), dim3(T), 0, st, plans, table, L.axis_max, s4, L.s4_stride, L.s4_pitch,
+                       t1, L.t1_stride, L.t1_pitch, col_blocks);
     hipLaunchKernelGGL(crop_down_v_kernel, dim3(blocks((long)L.nw_b * L.nw_b), B), dim3(T), 0, st, plans, table, L.axis_max, t1, L.t1_stride, L.t1_pitch,
                        d, L.d_stride, L.d_pitch);
     hipLaunchKernelGGL(crop_rotate_kernel, dim3(blocks((long)L.cw_max * L.cw_max / 2), B), dim3(T), 0, st, src, Hs, Ws, plans, d, L.d_stride, L.d_pitch,

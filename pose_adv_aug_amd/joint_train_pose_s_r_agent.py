@@ -24,6 +24,13 @@ from .utils.util import DeviceMeters
 METER_NAMES = ('loss_hg_regular', 'loss_hg_sr', 'loss_hg', 'pckhs_regular', 'pckhs_sr', 'pckh')      # :197-205, :300-305
 
 
+def _bin_seed(seed, augmenter):
+    """the categorical draws of a rank come from ITS OWN stream (the augmenter's seed carries the rank): with one common
+    stream every rank would reuse the same uniforms for its shard, and the global batch's draws would not be independent
+    like the np.random.choice calls of the reference's single process (:252-271)"""
+    return (int(seed) * 1000003 + int(augmenter.seed)) & 0x7fffffffffffffff
+
+
 def sample_bins(logits, seed, step, slot):
     """softmax + np.random.choice(K, p) per sample (:252-271) on the device.  Returns (probs [B][K], idx int32 [B])."""
     B, K = logits.shape
@@ -51,8 +58,8 @@ def train_hg_step(i, hg, optimizer_hg, agent_sr, augmenter, batch, seed=0):
         return 'regular', loss, pckh
     std = augmenter.standard(batch)                                  # img_std (:247)
     ls, lr = hg(asn=agent_sr, img4=std['img4'], is_half_hg=True, is_aug=True)       # (:250)
-    _, si = sample_bins(ls, seed, i, 0)
-    _, ri = sample_bins(lr, seed, i, 1)
+    _, si = sample_bins(ls, _bin_seed(seed, augmenter), i, 0)
+    _, ri = sample_bins(lr, _bin_seed(seed, augmenter), i, 1)
     loss, pckh = pose_step(hg, optimizer_hg, augmenter.agent(batch, si, ri, mode=1))     # load_batch_data(separate_s_r=False)
     return 'agent', loss, pckh
 
@@ -114,8 +121,8 @@ def train_agent_sr(batch, hg, agent_sr, optimizer_sr, augmenter, epoch_sr, seed=
     regular = separated_s_r_pckh(hg, d_s, d_r)                       # :331-336
     std = augmenter.standard(batch, want)
     ls, lr = hg(asn=agent_sr, img4=std['img4'], is_half_hg=True, is_aug=True)       # grads only into the agent (:342)
-    ps, si = sample_bins(ls, seed, epoch_sr, 0)
-    pr, ri = sample_bins(lr, seed, epoch_sr, 1)
+    ps, si = sample_bins(ls, _bin_seed(seed, augmenter), epoch_sr, 0)
+    pr, ri = sample_bins(lr, _bin_seed(seed, augmenter), epoch_sr, 1)
     a_s = augmenter.agent(batch, si, ri, mode=2, want_nchw=want)     # agent scale bin, no rotation
     a_r = augmenter.agent(batch, si, ri, mode=3, want_nchw=want)     # agent rotation bin, annotated scale
     agent = separated_s_r_pckh(hg, a_s, a_r)                         # :372-374
