@@ -25,7 +25,8 @@ def test_three_stages_chain_and_the_joint_stage_resumes(tmp_path):
     # stage 2 (pretrain-s-r-agent.py): distributions + agent checkpoint with an ASNTrainHistory under <sr_dir>-<pose checkpoint>/
     pretrain_s_r_agent.main(base + ['--is_train', '1', '--nEpochs', '1', '--load_prefix_pose', 'lr-0.00025-0.pth.tar'])
     sr = os.path.join(root, 'sr-dir-lr-0.00025-0')
-    assert sorted(f for f in os.listdir(sr) if f.endswith('.txt')) == ['train_rotations.txt', 'train_scales.txt', 'val_rotations.txt', 'val_scales.txt']
+    assert sorted(f for f in os.listdir(sr) if f.endswith('.txt')) == ['train_rotations.txt', 'train_scales.txt', 'training-summary.txt', 'val_rotations.txt', 'val_scales.txt']
+    assert open(os.path.join(sr, 'training-summary.txt')).read().splitlines()[0] == 'Epoch\tLR\tTrain Loss\tVal Loss\t'        # pretrain-s-r-agent.py:120-122
     ck = torch.load(os.path.join(sr, 'lr-0.00025-0.pth.tar'), map_location='cpu', weights_only=False)
     assert 'lowest_loss' in ck['train_history'] and ck['train_history']['epoch'][-1]['epoch'] == 0          # what stage 3 loads (joint-...:97-106)
     assert all(k.startswith('module.') for k in ck['state_dict'])
