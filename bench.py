@@ -29,7 +29,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 PROF_NAMES = ['conv_fwd_1x1', 'conv_fwd_3x3', 'conv_dgrad_1x1', 'conv_dgrad_3x3', 'conv_wgrad_1x1', 'conv_wgrad_3x3',
-              'stem_fwd_7x7', 'stem_wgrad_7x7']
+              'stem_fwd_7x7', 'stem_wgrad_7x7', 'lowres_fused_fwd']
 HBM_PEAK = 8.0e12          # B/s   (MI355X_MICROARCH.md)
 MFMA_PEAK = 2.5e15         # FLOP/s dense bf16
 
@@ -205,7 +205,7 @@ def main():
         _lib.check(_lib.lib().pa_net_set_multi_stream(h, 0))
         _lib.check(_lib.lib().pa_net_profile_begin(h))
         run(args.steps)
-        rep = (C.c_double * 32)()
+        rep = (C.c_double * 64)()
         _lib.check(_lib.lib().pa_net_profile_report(h, rep))
         _lib.check(_lib.lib().pa_net_set_multi_stream(h, 1))
         if rank == 0 and os.environ.get('PA_BENCH_SEQ_OUT'):            # for tools/trace_classes.py (rocprofv3 runs of this command)

@@ -273,6 +273,10 @@ int pa_hg_accuracy(pa_net* net, int stack, const int32_t* idxs, int nidx, float*
 int pa_hg_pckh(pa_net* net, int stack, const float* center, const float* scale, const float* rot, const float* gt_pts,
                const float* norm, const int32_t* idxs, int nidx, float* acc, float* person, float* scratch);
 
+/* Tuning aid for the fused low-resolution launch (csrc/lowres_fused.hip; it has no reference counterpart): `counters` = 24 int64 in
+ * device memory (zeroed by the caller) that workgroup 0 adds the shader-clock cycles of its phases to -- [level 16/8/4][phase:
+ * constants, staging, MFMA + epilogue, publish, barrier wait, collect + finalize, pool / upsample-add, drain]; NULL switches it off. */
+int pa_net_lowres_timing(pa_net* net, long long* counters);
 /* Per-launch HIP-event timing of the MFMA kernels on the net's stream (bench.py's `roofline`).
  * begin: start recording; report: synchronise, fill out[8][4] = {total ms, launches, algorithmic
  * bytes, flops} for the classes 0 fwd 1x1, 1 fwd 3x3, 2 dgrad 1x1, 3 dgrad 3x3, 4 wgrad 1x1,
