@@ -140,6 +140,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-parity', action='store_true')
+    ap.add_argument('--fused-lowres', type=int, default=0, help='1: the sub-hourglass below 32 x 32 as one persistent launch per stack (experiment, DESIGN.md)')
     args = ap.parse_args()
 
     from pose_adv_aug_amd import _lib
@@ -158,6 +159,7 @@ def main():
     net = create_hg(args.stacks, 1, 16, args.chan, res=res, default_batch=B)
     net.reset_parameters(seed=0)
     net.use_graph = bool(args.graph)
+    net.fused_lowres = bool(args.fused_lowres)
     broadcast_parameters(net)
     opt = RMSprop(net, lr=2.5e-4, alpha=0.99, eps=1e-8, overlap=bool(args.overlap) and (world > 1 or os.environ.get('POSEADV_FORCE_DIST') == '1'))
     aug = Augmenter(seed=100 + rank, inp_res=res, out_res=res // 4)

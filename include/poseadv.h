@@ -277,6 +277,10 @@ int pa_hg_pckh(pa_net* net, int stack, const float* center, const float* scale, 
  * device memory (zeroed by the caller) that workgroup 0 adds the shader-clock cycles of its phases to -- [level 16/8/4][phase:
  * constants, staging, MFMA + epilogue, publish, barrier wait, collect + finalize, pool / upsample-add, drain]; NULL switches it off. */
 int pa_net_lowres_timing(pa_net* net, long long* counters);
+/* 1: the sub-hourglass below 32 x 32 of every stack (models/asn_stacked_hg.py:139-157, :192-203 at 16 x 16, 8 x 8, 4 x 4) runs as ONE
+ * persistent launch in the training-mode forward pass of the pose net (one workgroup per image, BatchNorm statistics exchanged at
+ * in-kernel barriers); 0 (default): the chain of per-layer launches.  Same results up to summation order. */
+int pa_net_set_fused_lowres(pa_net* net, int on);
 /* Per-launch HIP-event timing of the MFMA kernels on the net's stream (bench.py's `roofline`).
  * begin: start recording; report: synchronise, fill out[8][4] = {total ms, launches, algorithmic
  * bytes, flops} for the classes 0 fwd 1x1, 1 fwd 3x3, 2 dgrad 1x1, 3 dgrad 3x3, 4 wgrad 1x1,

@@ -126,6 +126,7 @@ _PROTOS = {
     'pa_net_profile_begin': (_i, [_vp]),
     'pa_net_profile_report': (_i, [_vp, C.POINTER(C.c_double)]),
     'pa_net_lowres_timing': (_i, [_vp, _vp]),
+    'pa_net_set_fused_lowres': (_i, [_vp, _i]),
     'pa_net_profile_classes': (_i, [_vp, C.POINTER(C.c_int32), _i]),
     'pa_net_set_multi_stream': (_i, [_vp, _i]),
     'pa_hg_debug_tensor': (_i, [_vp, C.c_char_p, _i, _vp, C.POINTER(_i)]),

@@ -100,17 +100,20 @@ struct LrOp {
     const float* bias;         // [Cout] fp32
     bf16* out;                 // [B][H * W][Cout]
     int has_bn;                // training-mode BatchNorm behind the convolution: statistics + finalize inside the launch
+    int src_lds, dst_lds;      // conv: the input is the raw tensor the previous convolution left in LDS buffer src_lds (-1: global memory);
+                               // the raw output also stays in LDS buffer dst_lds (-1: global memory only)
     LrBn bn;
 };
 struct LrLaunch {
-    float2* rows;              // [2][B][256] partial statistics rows (scratch)
-    unsigned* counter;         // barrier counter, ZERO at launch
+    float2* rows;              // [2][B][256] 16-byte granules {sum, tag, sum of squares, tag}: partial statistics rows (scratch, 2 MB)
+    unsigned launch_id;        // unique per launch that shares `rows` (tags of an earlier launch must never match)
+    unsigned* counter;         // (unused)
     float batch;               // B
     float momentum, eps;
     int update_running;
     long long* timing;         // tuning aid (normally null): 24 cycle counters, see lowres_fused.hip
 };
-int pa_launch_lowres_fwd(const LrOp* ops_dev, int nops, const LrLaunch& L, int B, hipStream_t st);
+int pa_launch_lowres_fwd(const LrOp* ops_dev, int nops, const LrLaunch& L, int B, int chan, hipStream_t st);
 
 // ---- optimizer / weight preparation
 int pa_launch_rmsprop(float* p, const float* g, float* v, size_t n, float lr, float alpha, float eps, float gscale, hipStream_t st);

@@ -142,8 +142,9 @@ struct Net {
     // fused low-resolution sub-hourglass (forward): partial-statistics rows [2][256][256] float2, per-stack barrier counters in
     // the region begin_step zeroes (behind the loss words)
     float2* lr_rows = nullptr;
+    unsigned lr_launches = 0;                   // tag of the fused launches' statistics granules
     long long* lr_timing = nullptr;             // tuning aid: 24 cycle counters of the fused kernel's phases (pa_net_lowres_timing)
-    bool fused_low = true;
+    bool fused_low = false;                     // opt-in (pa_net_set_fused_lowres): measured break-even with the launch chain, DESIGN.md
     bool fused_low_ok() const { return fused_low && !is_agent && train_bn && !drop_mask && (chan == 256 || chan == 128) && res == 256 && B >= 1 && B <= 256 && lr_rows != nullptr; }
     // run state
     hipStream_t st = nullptr;

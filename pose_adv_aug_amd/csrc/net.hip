@@ -230,7 +230,7 @@ size_t Net::layout_all(char* base) {
         if (i == 0) xin[0] = res3.x3;
         if (i + 1 < stacks) xin[i + 1] = new_act(a, B, H4, H4, chan, nullptr, true);
     }
-    lr_rows = a.get<float2>((size_t)2 * 256 * 256);
+    lr_rows = a.get<float2>((size_t)2 * 256 * 256 * 2);        // 16-byte granules
     for (int i = 0; i < stacks; ++i) {
         Hourglass& h = hg[i];
         h.index = i; h.lr_ops = a.get<LrOp>(64);
@@ -253,8 +253,9 @@ void Hourglass::build_lowres_program(Net& n, std::vector<LrOp>& prog) const {
         o.scale = b.scale; o.shift = b.shift; o.mean = b.mean; o.invstd = b.invstd;
         return o;
     };
-    auto conv = [&](const ConvLayer& c, const Act& in, const Act* add, const Act& out, const BNLayer& bn) {
+    auto conv = [&](const ConvLayer& c, const Act& in, const Act* add, const Act& out, const BNLayer& bn, int src_lds, int dst_lds) {
         LrOp o; memset(&o, 0, sizeof o);
+        o.src_lds = src_lds; o.dst_lds = dst_lds;
         o.type = LR_CONV; o.H = out.H; o.W = out.W; o.Cin = c.pcin; o.Cout = c.pcout; o.taps = c.taps();
         tensor(in, o.in, o.in_k0, o.in_k1);
         if (add) tensor(*add, o.add, o.add_k0, o.add_k1);
@@ -262,20 +263,20 @@ void Hourglass::build_lowres_program(Net& n, std::vector<LrOp>& prog) const {
         prog.push_back(o);
     };
     auto block = [&](const Residual& r, const Act& in) {
-        conv(r.c1, in, nullptr, r.x1, r.b1);
-        conv(r.c2, r.x1, nullptr, r.x2, r.b2);
-        conv(r.c3, r.x2, &in, r.x3, r.b3);
+        conv(r.c1, in, nullptr, r.x1, r.b1, -1, 1);       // x1 stays in LDS buffer V
+        conv(r.c2, r.x1, nullptr, r.x2, r.b2, 1, 0);      // ... x2 in U
+        conv(r.c3, r.x2, &in, r.x3, r.b3, 0, -1);
     };
     auto pool = [&](const Act& in, const Act& out) {
         LrOp o; memset(&o, 0, sizeof o);
         o.type = LR_POOL; o.H = out.H; o.W = out.W; o.Cin = o.Cout = out.C; o.taps = 1;
-        tensor(in, o.in, o.in_k0, o.in_k1); o.out = out.raw;
+        tensor(in, o.in, o.in_k0, o.in_k1); o.out = out.raw; o.src_lds = o.dst_lds = -1;
         prog.push_back(o);
     };
     auto upadd = [&](const Act& low, const Act& sk, const Act& out) {
         LrOp o; memset(&o, 0, sizeof o);
         o.type = LR_UPADD; o.H = out.H; o.W = out.W; o.Cin = o.Cout = out.C; o.taps = 1;
-        tensor(low, o.in, o.in_k0, o.in_k1); tensor(sk, o.add, o.add_k0, o.add_k1); o.out = out.raw;
+        tensor(low, o.in, o.in_k0, o.in_k1); tensor(sk, o.add, o.add_k0, o.add_k1); o.out = out.raw; o.src_lds = o.dst_lds = -1;
         prog.push_back(o);
     };
     // (the first pooling, 32 x 32 -> 16 x 16, reads 0.5 MB per image: it stays a launch of its own on the whole chip)
@@ -289,6 +290,7 @@ void Hourglass::build_lowres_program(Net& n, std::vector<LrOp>& prog) const {
 int Hourglass::lowres_fwd(Net& n) {
     LrLaunch L;
     L.rows = n.lr_rows;
+    L.launch_id = ++n.lr_launches;
     L.counter = reinterpret_cast<unsigned*>(n.loss_dev) + 32 + index;      // zeroed by begin_step
     L.batch = (float)n.B; L.momentum = n.momentum; L.eps = n.eps; L.update_running = n.bn_update;
     L.timing = n.lr_timing;
@@ -301,7 +303,7 @@ int Hourglass::lowres_fwd(Net& n) {
         flops += 2.0 * M * (C * Cm + Cm * 9 * Cm + Cm * C);
     }
     ProfEntry* pe = n.prof.begin(PA_PROF_LOWRES_FWD, bytes, flops, n.st);
-    const int rc = pa_launch_lowres_fwd(lr_ops, n_lr_ops, L, n.B, n.st);
+    const int rc = pa_launch_lowres_fwd(lr_ops, n_lr_ops, L, n.B, n.chan, n.st);
     n.prof.end(pe, n.st);
     return rc;
 }

@@ -62,11 +62,15 @@ def _leaf(x):
     return x.clone().requires_grad_(True)
 
 
-def test_every_node_of_the_training_graph_matches_locally():
+@pytest.mark.parametrize('fused', [False, True])
+def test_every_node_of_the_training_graph_matches_locally(fused):
+    """fused: the sub-hourglass below 32 x 32 as ONE persistent launch (csrc/lowres_fused.hip) instead of ~45 launches per stack:
+    the same nodes, the same tolerances."""
     torch.set_num_threads(8)
     bf16_emul.ROUND_GRADS = True        # the engine stages gradient operands in bf16 (standard mixed precision)
     stacks, B, res, chan = 2, 2, 256, 128
     ref, net = _hg_pair(stacks, chan, B, res, seed=7)
+    net.fused_lowres = fused
     img = t(inputs.images(8, B, res))
     pts = inputs.heat_pts(9, B, res=res // 4)
     heat_t = t(inputs.heatmaps_from_pts(pts, res=res // 4))
@@ -188,7 +192,8 @@ def test_every_node_of_the_training_graph_matches_locally():
     assert not errs, '%d local mismatches, first: %s' % (len(errs), errs[:15])
 
 
-def test_blocks_of_every_resolution_match_locally_at_the_benchmark_size():
+@pytest.mark.parametrize('fused', [False, True])
+def test_blocks_of_every_resolution_match_locally_at_the_benchmark_size(fused):
     """BASELINE configs[1] at FULL size (2-stack, chan 256, B = 24): one residual block per map size of stack 0 -- skip1 (64x64),
     skip2 (32x32), skip3 (16x16), skip4 (8x8), neck (4x4) -- checked in place like the small net above: forward of conv1 / conv2 /
     conv3 (1e-2), every parameter gradient and the two inner masked gradients (4e-2, cosine 0.999).  This pins the template
@@ -198,6 +203,7 @@ def test_blocks_of_every_resolution_match_locally_at_the_benchmark_size():
     bf16_emul.ROUND_GRADS = True
     stacks, B, res, chan = 2, 24, 256, 256
     ref, net = _hg_pair(stacks, chan, B, res, seed=11)
+    net.fused_lowres = fused
     img = t(inputs.images(41, B, res))
     pts = inputs.heat_pts(42, B, res=res // 4)
     ref.train(); net.train()
