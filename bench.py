@@ -288,7 +288,7 @@ def main():
                            'loss': float(loss), 'pckh': float(pckh), 'pckh_origin_res': float(pckh_o)},
                 'pckh_parity': parity, 'roofline': roofline, 'cpu_baseline': cpu}
         print(json.dumps(line))
-    if world > 1:
+    if dist.is_available() and dist.is_initialized():          # (world > 1, or one rank forced through RCCL: POSEADV_FORCE_DIST=1)
         dist.barrier()
         dist.destroy_process_group()
 

@@ -561,7 +561,13 @@ int pa_hg_pckh(pa_net* net, int stack, const float* center, const float* scale, 
 // per-launch HIP-event timing of the MFMA kernels (bench.py roofline): enable, run steps, then report.
 // out[8][4] = {total ms, launches, algorithmic bytes, flops} per class: 0 fwd 1x1, 1 fwd 3x3, 2 dgrad 1x1,
 // 3 dgrad 3x3, 4 wgrad 1x1, 5 wgrad 3x3, 6 stem fwd, 7 stem wgrad.  Reporting synchronises and disables.
-int pa_net_set_fused_lowres(pa_net* net, int on) { net->n.fused_low = on != 0; net->n.release_graph(); return 0; }
+int pa_net_set_fused_lowres(pa_net* net, int on) {
+    Net& n = net->n;
+    n.fused_low = on != 0;
+    n.release_graph();
+    if (n.params) { TRY(n.upload_tables()); TRY(n.prepare_weights()); }      // the packed weight copies exist only while the switch is on
+    return 0;
+}
 int pa_net_lowres_timing(pa_net* net, long long* counters) { net->n.lr_timing = counters; return 0; }
 int pa_net_profile_begin(pa_net* net) { net->n.prof.used = 0; net->n.prof.on = true; return 0; }
 int pa_net_profile_report(pa_net* net, double* out) {

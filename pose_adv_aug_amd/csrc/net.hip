@@ -313,7 +313,7 @@ int Net::upload_tables() {
     prep_max = 0; red_max = 0;
     for (ConvLayer* c : convs) {
         if (immediate_reduce) { c->part = shared_part; c->dbpart = c->db_floats ? shared_db : nullptr; }
-        PaPrepJob p; p.w = params + c->p_w; p.wf = c->wf; p.wb = c->wb; p.wp = c->wp; p.Cout = c->Cout; p.Cin = c->Cin;
+        PaPrepJob p; p.w = params + c->p_w; p.wf = c->wf; p.wb = c->wb; p.wp = fused_low ? c->wp : nullptr; p.Cout = c->Cout; p.Cin = c->Cin;
         p.taps = c->k == 7 ? 49 : c->taps(); p.pad_cout = c->pcout; p.pad_cin = c->pcin;
         pj.push_back(p);
         int pe = c->pcout * (c->k == 7 ? 256 : c->taps() * c->pcin);
@@ -480,6 +480,8 @@ int Net::conv_wgrad(ConvLayer& c, const PaOperand& dy, const PaOperand& x, int B
     if (c.k == 7) wb = 2.0 * B_ * (4.0 * H * W * 4 + (double)H * W * 64) + 4.0 * 64 * 147;
     const int cls = c.k == 7 ? PA_PROF_STEM_WGRAD : (c.k == 3 ? PA_PROF_WGRAD3 : PA_PROF_WGRAD1);
     if (ablate() & 2) return 0;
+    if ((ablate() & 32) && c.k == 1 && (long)B_ * H * W >= 16384) return 0;      // timing bound: what fusing the large 1x1 weight gradients into their data gradients could save at most
+    if ((ablate() & 64) && c.k == 3 && (long)B_ * H * W >= 16384) return 0;
     if (multi_stream && wstream) {        // deferred: flush_wgrads() launches it on the weight-gradient stream
         PendingWgrad p; p.a = a; p.cls = cls; p.bytes = wb; p.flops = wf; p.stem = c.k == 7; p.c = &c;
         pending_wgrads.push_back(p);

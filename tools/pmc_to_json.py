@@ -36,5 +36,5 @@ res = {k: {'hbm_bytes_per_launch': (v['fetch_bytes'] + v['write_bytes']) / max(1
            'fetch_bytes_per_launch_x2': v['fetch_bytes'] / max(1, v['launches']),
            'write_bytes_per_launch': v['write_bytes'] / max(1, v['launches']), 'launches_profiled': v['launches']} for k, v in out.items()}
 res['_source'] = 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (tools/prof_pmc.sh %s); FETCH_SIZE x2 per the gfx950 correction' % tag
-json.dump(res, open('profiles/%s_pmc.json' % tag, 'w'), indent=1, sort_keys=True)
+json.dump(res, open('gpurun_out/%s_pmc.json' % tag, 'w'), indent=1, sort_keys=True)
 print(json.dumps({k: round(v['hbm_bytes_per_launch'] / 1e6, 1) for k, v in res.items() if k[0] != '_'}))

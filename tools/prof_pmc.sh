@@ -4,7 +4,7 @@ TAG=${1:-r1}
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C --kernel-trace --output-format csv -d gpurun_out/pmc_${TAG}_$C -o bench -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline > gpurun_out/pmc_${TAG}_$C.log 2>&1
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d gpurun_out/pmc_${TAG}_$C -o bench -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-parity > gpurun_out/pmc_${TAG}_$C.log 2>&1
   tail -1 gpurun_out/pmc_${TAG}_$C.log | cut -c1-120
 done
 python - $TAG > gpurun_out/pmc_summary_$TAG.txt <<'PY'
