@@ -271,18 +271,26 @@ __device__ __forceinline__ void lr_epilogue(LrSmem& sm, f32x4 (&acc)[NB][PB], co
     const int Cout = op.Cout, P = op.H * op.W, CPP = Cout >> 3;
     const bool add_bn = op.add_k0 != nullptr;
     const bool has_add = op.add != nullptr;
-    g_bf16x4c addp = LR_G(g_bf16x4c, op.add + (size_t)b * P * Cout);
     g_bf16x8 outp = LR_G(g_bf16x8, op.out + (size_t)b * P * Cout);
     // every global operand of the block (biases, shortcut addends) is requested before the first use
     f32x4 bias[NB];
-    bf16x4 av[2][NB];                                 // the addends of pixel fragment j + 1 are in flight while j is finished
-    auto load_add = [&](int j, bf16x4 (&a)[NB]) {
-#pragma unroll
-        for (int i = 0; i < NB; ++i) a[i] = addp[(((pb * PB + j) * 16 + frow) * Cout + (nb * NB + i) * 16 + fq * 4) >> 2];
-    };
 #pragma unroll
     for (int i = 0; i < NB; ++i) bias[i] = *LR_G(g_f32x4c, op.bias + (nb * NB + i) * 16 + fq * 4);
-    if (has_add) load_add(0, av[0]);
+    // shortcut addends: one coalesced 16-byte load per lane and 32-channel pair of a pixel fragment (lane = pixel lane / 4, chunk
+    // lane % 4), turned into the MFMA layout through the wave's tile; the loads of the next pixel fragment are in flight meanwhile
+    constexpr int NP = (NB + 1) / 2;                  // 32-channel pairs per block
+    g_bf16x8c add8 = LR_G(g_bf16x8c, op.add + (size_t)b * P * Cout);
+    bf16x8 ar[2][NP];
+    auto load_add = [&](int j, bf16x8 (&a)[NP]) {
+        const int p0 = (pb * PB + j) * 16;
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            const int n0 = (nb * NB + 2 * k) * 16;
+            if (NB >= 2) a[k] = add8[((p0 + (lane >> 2)) * Cout + n0 + (lane & 3) * 8) >> 3];
+            else a[k] = add8[((p0 + ((lane & 31) >> 1)) * Cout + n0 + (lane & 1) * 8) >> 3];
+        }
+    };
+    if (has_add) load_add(0, ar[0]);
     float s1[NB][4], s2[NB][4];
 #pragma unroll
     for (int i = 0; i < NB; ++i)
@@ -292,9 +300,16 @@ __device__ __forceinline__ void lr_epilogue(LrSmem& sm, f32x4 (&acc)[NB][PB], co
 #pragma unroll
     for (int j = 0; j < PB; ++j) {
         const int p0 = (pb * PB + j) * 16;
-        if (has_add && j + 1 < PB) load_add(j + 1, av[(j + 1) & 1]);
+        if (has_add && j + 1 < PB) load_add(j + 1, ar[(j + 1) & 1]);
 #pragma unroll
         for (int i0 = 0; i0 < NB; i0 += 2) {             // 32 channels (two fragments; one when NB == 1) of 16 pixels at a time
+            bf16x4 av[2];
+            if (has_add) {
+                if (NB >= 2) *reinterpret_cast<bf16x8*>(&tile[lane >> 2][(lane & 3) * 8]) = ar[j & 1][i0 >> 1];
+                else if (lane < 32) *reinterpret_cast<bf16x8*>(&tile[lane >> 1][(lane & 1) * 8]) = ar[j & 1][0];
+#pragma unroll
+                for (int h = 0; h < 2 && i0 + h < NB; ++h) av[h] = *reinterpret_cast<const bf16x4*>(&tile[frow][h * 16 + fq * 4]);
+            }
 #pragma unroll
             for (int h = 0; h < 2 && i0 + h < NB; ++h) {
                 const int i = i0 + h;
@@ -304,7 +319,7 @@ __device__ __forceinline__ void lr_epilogue(LrSmem& sm, f32x4 (&acc)[NB][PB], co
                 for (int q = 0; q < 4; ++q) v[q] = acc[i][j][q] + bias[i][q];
                 if (has_add) {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) v[q] += lr_value((float)av[j & 1][i][q], sm.cad[n + q], add_bn);
+                    for (int q = 0; q < 4; ++q) v[q] += lr_value((float)av[h][q], sm.cad[n + q], add_bn);
                 }
                 bf16x4 o;
 #pragma unroll
@@ -417,6 +432,14 @@ __device__ __forceinline__ void lr_bn_sync(LrSmem& sm, const LrOp& op, const LrL
         lr_store_granule(rows + (size_t)b * 256 + c, u32x4{__float_as_uint(a), tag, __float_as_uint(q), tag});
     }
     tm.mark(4);
+    // the finalize's own operands (gamma, beta; workgroup 0: the running estimates) are requested now, used after the poll
+    g_f32c gamma = LR_G(g_f32c, op.bn.gamma), beta = LR_G(g_f32c, op.bn.beta);
+    g_f32 rmean = LR_G(g_f32, op.bn.rmean), rvar = LR_G(g_f32, op.bn.rvar);
+    float pg = 0.f, pbeta = 0.f, prm = 0.f, prv = 0.f;
+    if (tid < C) {
+        pg = gamma[tid]; pbeta = beta[tid];
+        if (b == 0 && L.update_running) { prm = rmean[tid]; prv = rvar[tid]; }
+    }
     if (op.dst_lds >= 0) lr_writeout(sm.buf[op.dst_lds], op.out, b, P, C);      // x1 / x2 -> HBM for the backward pass, while the rows travel
     __syncthreads();                                               // (the statistics area is reused below)
     // collect: Q threads per channel, each polls + sums every Q-th row in increasing order; then the Q partials in order
@@ -446,18 +469,17 @@ __device__ __forceinline__ void lr_bn_sync(LrSmem& sm, const LrOp& op, const LrL
     }
     __syncthreads();
     tm.mark(5);
-    g_f32c gamma = LR_G(g_f32c, op.bn.gamma), beta = LR_G(g_f32c, op.bn.beta);
     g_f32 scale = LR_G(g_f32, op.bn.scale), shiftp = LR_G(g_f32, op.bn.shift), mean = LR_G(g_f32, op.bn.mean), invstd = LR_G(g_f32, op.bn.invstd);
-    g_f32 rmean = LR_G(g_f32, op.bn.rmean), rvar = LR_G(g_f32, op.bn.rvar);
-    for (int c = tid; c < C; c += LR_THREADS) {
+    if (tid < C) {                                     // (C <= 256 < LR_THREADS: one channel per thread)
+        const int c = tid;
         float S1 = 0.f, S2 = 0.f;
         for (int q = 0; q < Q; ++q) { S1 += part[q * 256 + c].x; S2 += part[q * 256 + c].y; }
         const float cnt = L.batch * (float)P;
         const float mu = S1 / cnt;
         const float var = fmaxf(S2 / cnt - mu * mu, 0.f);
         const float is = rsqrtf(var + L.eps);
-        const float sc = gamma[c] * is;
-        const float sh = beta[c] - mu * sc;
+        const float sc = pg * is;
+        const float sh = pbeta - mu * sc;
         // every workgroup stores the same bits; its own later reads (the shortcut of conv3, later blocks) come back through its own CU
         scale[c] = sc;
         shiftp[c] = sh;
@@ -467,8 +489,8 @@ __device__ __forceinline__ void lr_bn_sync(LrSmem& sm, const LrOp& op, const LrL
             invstd[c] = is;
             if (L.update_running) {
                 const float unb = cnt > 1.f ? var * cnt / (cnt - 1.f) : var;
-                rmean[c] = (1.f - L.momentum) * rmean[c] + L.momentum * mu;
-                rvar[c] = (1.f - L.momentum) * rvar[c] + L.momentum * unb;
+                rmean[c] = (1.f - L.momentum) * prm + L.momentum * mu;
+                rvar[c] = (1.f - L.momentum) * prv + L.momentum * unb;
             }
         }
     }
@@ -568,12 +590,19 @@ __global__ __launch_bounds__(LR_THREADS, 1) void lowres_fwd_kernel(const LrOp* o
 #pragma unroll
             for (int i = 0; i < (int)(sizeof(LrOp) / 4); ++i) d[i] = __builtin_amdgcn_readfirstlane(s[i]);
         }
+#ifdef LR_TIME_BY_TYPE                                     // (harness experiment: rows = conv1 / conv2 / conv3 of the 16 x 16 level only)
+        tm.lvl = op.taps == 9 ? 1 : (op.add ? 2 : 0);
+        tm.on = L.timing != nullptr && b == 0 && threadIdx.x == 0 && op.W >= 16 && op.type == LR_CONV;
+        if (tm.on) tm.t0 = clock64();
+#else
         tm.lvl = op.W >= 16 ? 0 : (op.W >= 8 ? 1 : 2);
+#endif
         // constants of the operands (written by THIS workgroup's own finalize steps, or by earlier launches); the finalize of
         // the previous convolution has left its own in sm.cin already
-        if (op.in_k0 != cin_of) { lr_load_consts(sm.cin, op.in_k0, op.in_k1, op.type == LR_CONV ? op.Cin : op.Cout); cin_of = op.in_k0; }
-        if (op.add) lr_load_consts(sm.cad, op.add_k0, op.add_k1, op.Cout);
-        __syncthreads();
+        bool loaded = false;
+        if (op.in_k0 != cin_of) { lr_load_consts(sm.cin, op.in_k0, op.in_k1, op.type == LR_CONV ? op.Cin : op.Cout); cin_of = op.in_k0; loaded = true; }
+        if (op.add) { lr_load_consts(sm.cad, op.add_k0, op.add_k1, op.Cout); loaded = true; }
+        if (loaded) __syncthreads();
         tm.mark(0);
         if (op.type == LR_POOL) { lr_pool(sm, op, b); tm.mark(7); }
         else if (op.type == LR_UPADD) { lr_upadd(sm, op, b); tm.mark(7); }
