@@ -185,7 +185,9 @@ bool pa_conv1x1_tile_supported(const PaConvArgs& a) {
 int pa_launch_conv1x1_tile(const PaConvArgs& a, hipStream_t st, int* stat_rows) {
     if (!pa_conv1x1_tile_supported(a)) { pa_set_error_msg("pa_launch_conv1x1_tile: unsupported shape"); return 1; }
     const int M = a.B * a.H * a.W;
-    const int bm = row_bm(a.Cin);
+    int bm = row_bm(a.Cin);
+    // the 64-row, 128-channel BatchNorm-backward instance (3 workgroups per CU) has the LDS epilogue only
+    if (a.Cin == 128 && bm == 64 && a.in.mode == PA_LD_LIN2 && a.ep.mode == PA_OUT_BWD && !pa_bwd_epilogue_lds_ok(a)) bm = 128;
     const int tiles = (M + bm - 1) / bm;
     if (stat_rows) *stat_rows = tiles;
     if (a.ep.rows_out) *a.ep.rows_out = tiles;

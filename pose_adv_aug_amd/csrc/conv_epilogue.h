@@ -337,6 +337,12 @@ __device__ __forceinline__ void pa_conv_epilogue_lds_bwd(const PaConvArgs& a, f3
     }
 }
 
+// host side of the dispatch below: can the LDS variant of the BatchNorm-backward epilogue take this launch?
+__host__ __device__ inline bool pa_bwd_epilogue_lds_ok(const PaConvArgs& a) {
+    return a.xcd < 2 && a.bias == nullptr && (a.add1.mode == PA_LD_NONE || a.add1.mode == PA_LD_PLAIN || a.add1.mode == PA_LD_LIN2) &&
+           (a.add2.mode == PA_LD_NONE || a.add2.mode == PA_LD_PLAIN);
+}
+
 // forward epilogues through LDS (coalesced rows), backward epilogue direct; pix(wm, mi, p) as above
 template <int BN, int NI, int MI, bool BWD_LDS = true, bool TAB = false, class PixFn>
 __device__ __forceinline__ void pa_conv_epilogue_auto(const PaConvArgs& a, f32x4 (&acc)[NI][MI], int n0, int wm, int wn,
@@ -344,10 +350,11 @@ __device__ __forceinline__ void pa_conv_epilogue_auto(const PaConvArgs& a, f32x4
     if (a.ep.mode == PA_OUT_BWD) {
         // supported operand modes of the LDS variant: addend 1 plain / LIN2, addend 2 plain, no bias (every data gradient of
         // the networks); anything else takes the direct epilogue
-        const bool lds_ok = BWD_LDS && a.xcd < 2 && a.bias == nullptr && (a.add1.mode == PA_LD_NONE || a.add1.mode == PA_LD_PLAIN || a.add1.mode == PA_LD_LIN2) &&
-                            (a.add2.mode == PA_LD_NONE || a.add2.mode == PA_LD_PLAIN);
+        const bool lds_ok = BWD_LDS && pa_bwd_epilogue_lds_ok(a);
         if (lds_ok) {
             pa_conv_epilogue_lds_bwd<BN, NI, MI, TAB>(a, acc, n0, wm, wn, pix, T, stat_row, ctab);
+        } else if (TAB) {
+            __builtin_trap();       // the 168-register kernels carry no direct epilogue (it spilled): pa_bwd_epilogue_lds_ok() routes such launches elsewhere
         } else {
             const int p = threadIdx.x & 15;
             pa_conv_epilogue<BN, NI, MI>(a, acc, n0, wm, wn, [&](int mi) { return pix(wm, mi, p); }, T, stat_row);

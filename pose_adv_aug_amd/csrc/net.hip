@@ -719,9 +719,11 @@ int Hourglass::bwd(Net& n, const Act& in, const PaOperand& extra0) {
 }
 
 // A/B (tuning builds): a stream restricted to `n` of the 256 CUs, spread evenly (PA_WSTREAM_CUS / PA_SIDE_CUS)
-static hipError_t create_stream_cus(hipStream_t* s, const char* env) {
+// ... or with a queue priority (PA_WSTREAM_PRIO / PA_SIDE_PRIO: the runtime's numeric priority, lower = more urgent)
+static hipError_t create_stream_cus(hipStream_t* s, const char* env, const char* prio_env) {
     const char* e = pa_getenv(env);
     const int n = e ? atoi(e) : 0;
+    if (const char* p = pa_getenv(prio_env)) return hipStreamCreateWithPriority(s, hipStreamNonBlocking, atoi(p));
     if (n <= 0 || n >= 256) return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
     uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int i = 0; i < n; ++i) { const int cu = (int)((long)i * 256 / n); mask[cu >> 5] |= 1u << (cu & 31); }
@@ -737,13 +739,13 @@ int Net::ensure_streams() {
     if (const char* e = pa_getenv("PA_WFLUSH_EVERY")) flush_every = atoi(e) > 0 ? atoi(e) : 1;
     if (const char* e = pa_getenv("PA_WHOLD")) hold_level = atoi(e);
     for (int k = 0; k < 4; ++k) {
-        if (k < n_side) PA_CHECK(create_stream_cus(&side[k], "PA_SIDE_CUS"));
+        if (k < n_side) PA_CHECK(create_stream_cus(&side[k], "PA_SIDE_CUS", "PA_SIDE_PRIO"));
         else side[k] = side[k % n_side];            // levels share streams (in-order per stream: fork/join events keep it correct)
         PA_CHECK(hipEventCreateWithFlags(&ev_fork[k], hipEventDisableTiming));
         PA_CHECK(hipEventCreateWithFlags(&ev_join[k], hipEventDisableTiming));
     }
     if (!pa_getenv("PA_NO_WSTREAM")) {
-        PA_CHECK(create_stream_cus(&wstream, "PA_WSTREAM_CUS"));
+        PA_CHECK(create_stream_cus(&wstream, "PA_WSTREAM_CUS", "PA_WSTREAM_PRIO"));
         wstreams[0] = wstream;
         if (const char* e = pa_getenv("PA_WSTREAMS")) n_w = atoi(e) < 1 ? 1 : (atoi(e) > 4 ? 4 : atoi(e));
         for (int i = 1; i < n_w; ++i) PA_CHECK(hipStreamCreateWithFlags(&wstreams[i], hipStreamNonBlocking));
