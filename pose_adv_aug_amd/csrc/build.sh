@@ -8,7 +8,7 @@ SRCS="conv_igemm conv3x3_tile conv1x1_tile conv_wgrad conv_wgrad_tile lowres_fus
 build_variant() {      # $1 = object directory, $2 = extra flags, $3 = library name
   local dir=$1 flags=$2 lib=$3
   mkdir -p $dir
-  if [ -n "$PA_TUNING" ]; then flags="$flags -DPA_TUNING"; fi
+  if [ -n "$PA_TUNING" ]; then flags="$flags -DPA_TUNING $PA_EXTRA"; fi
   if [ "$(cat $dir/.flags 2>/dev/null)" != "$flags" ]; then rm -f $dir/*.o; echo "$flags" > $dir/.flags; fi
   local objs=""
   for f in $SRCS; do

@@ -11,6 +11,9 @@ static bool nosync() { return false; }
 // PA_ABLATE=<mask> (tuning builds only; results are WRONG, timing bounds only): 1 no slab reductions, 2 no weight-gradient
 // launches, 4 no BatchNorm finalize launches, 8 no 3x3 convolutions, 16 no 1x1 data gradients
 static int ablate() { static int v = -1; if (v < 0) { const char* e = pa_getenv("PA_ABLATE"); v = e ? atoi(e) : 0; } return v; }
+// bits 128 / 256 / 512: forward convolutions + finalize / data gradients + backward finalize / weight gradients of maps up to
+// PA_ABLATE_H (default 8) pixels high are skipped: what the low-resolution stretch costs the step at most (wrong results)
+static int ablate_h() { static int v = -1; if (v < 0) { const char* e = pa_getenv("PA_ABLATE_H"); v = e ? atoi(e) : 8; } return v; }
 #define TRY(x) do { int _r = (x); if (_r) return _r; } while (0)
 
 PaOperand pa_plain(const bf16* p) { PaOperand o; o.p = p; o.q = nullptr; o.k0 = o.k1 = o.k2 = nullptr; o.mode = PA_LD_PLAIN; return o; }
@@ -416,6 +419,7 @@ PaEpilogue Net::final_ep(const Act& a) const {
 int Net::finish_grad(const Act& a) {
     if (!a.bn) return 0;
     if (ablate() & 4) return 0;
+    if ((ablate() & 256) && a.H <= ablate_h()) return 0;
     BNLayer* b = a.bn;
     return pa_launch_bn_bwd_finalize(b->bstats, b->bstat_rows, b->scale, b->mean, b->invstd, b->kA, b->kB, b->kC, grads + b->p_gamma,
                                      grads + b->p_beta, b->C, (float)a.M(), st);
@@ -423,6 +427,7 @@ int Net::finish_grad(const Act& a) {
 
 int Net::finish_grad2(const Act& a, const Act& b) {
     if (ablate() & 4) return 0;
+    if ((ablate() & 256) && a.H <= ablate_h()) return 0;
     if (!a.bn || !b.bn) { TRY(finish_grad(a)); return finish_grad(b); }
     BNLayer *x = a.bn, *y = b.bn;
     return pa_launch_bn_bwd_finalize2(x->bstats, x->bstat_rows, x->scale, x->mean, x->invstd, x->kA, x->kB, x->kC, grads + x->p_gamma, grads + x->p_beta,
@@ -440,6 +445,7 @@ int Net::conv_fwd(ConvLayer& c, const PaOperand& in, int B_, int H, int W, const
     if (bn_after && train_bn) { a.ep.mode = PA_OUT_STATS; a.ep.stats = bn_after->stats; a.ep.rows_out = &bn_after->stat_rows; }
     double wb, wf; conv_work(B_ * H * W, c.k == 7 ? 147 : c.Cin, c.Cout, c.k == 7 ? 1 : c.taps(), false, wb, wf);
     if (c.k == 7) wb = 2.0 * B_ * (4.0 * H * W * 4 + (double)H * W * 64) + 2.0 * 64 * 147;      // image read once (4-ch padded) + output
+    if ((ablate() & 128) && H <= ablate_h()) return 0;
     ProfEntry* pe = prof.begin(c.k == 7 ? PA_PROF_STEM_FWD : (c.k == 3 ? PA_PROF_FWD3 : PA_PROF_FWD1), wb, wf, st);
     int rc = (c.k == 3 && (ablate() & 8)) ? 0 : ((c.k == 7) ? pa_launch_stem_conv(a, st) : pa_launch_conv(a, st));
     prof.end(pe, st);
@@ -466,7 +472,7 @@ int Net::conv_dgrad(ConvLayer& c, const PaOperand& dy, int B_, int H, int W, con
     }
     double wb, wf; conv_work(B_ * H * W, c.Cin, c.Cout, c.taps(), false, wb, wf);
     ProfEntry* pe = prof.begin(c.k == 3 ? PA_PROF_DGRAD3 : PA_PROF_DGRAD1, wb, wf, st);
-    if ((c.k == 3 && (ablate() & 8)) || (c.k == 1 && (ablate() & 16))) { if (a.ep.rows_out) *a.ep.rows_out = 1; prof.end(pe, st); return 0; }
+    if ((c.k == 3 && (ablate() & 8)) || (c.k == 1 && (ablate() & 16)) || ((ablate() & 256) && H <= ablate_h())) { if (a.ep.rows_out) *a.ep.rows_out = 1; prof.end(pe, st); return 0; }
     int rc = pa_launch_conv(a, st);
     prof.end(pe, st);
     return rc;
@@ -482,6 +488,7 @@ int Net::conv_wgrad(ConvLayer& c, const PaOperand& dy, const PaOperand& x, int B
     if (ablate() & 2) return 0;
     if ((ablate() & 32) && c.k == 1 && (long)B_ * H * W >= 16384) return 0;      // timing bound: what fusing the large 1x1 weight gradients into their data gradients could save at most
     if ((ablate() & 64) && c.k == 3 && (long)B_ * H * W >= 16384) return 0;
+    if ((ablate() & 512) && H <= ablate_h()) return 0;
     if (multi_stream && wstream) {        // deferred: flush_wgrads() launches it on the weight-gradient stream
         PendingWgrad p; p.a = a; p.cls = cls; p.bytes = wb; p.flops = wf; p.stem = c.k == 7; p.c = &c;
         pending_wgrads.push_back(p);

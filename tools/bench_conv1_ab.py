@@ -1,5 +1,6 @@
-"""A/B of the weight-stationary 1x1 kernel (csrc/conv1x1_ws.hip) against the row-tile kernel: tuning build, PA_CONV1_WS = 0 / 1 / 2
-in separate processes (the switch is read once).  Shapes: the bottleneck layers of the 2-stack net at 64x64 and 32x32, batch 24."""
+"""A/B of 1x1 kernel variants selected by a tuning-build environment switch read once per process:
+    python tools/bench_conv1_ab.py PA_CONV1_OLD 0 1
+Shapes: the bottleneck layers of the 2-stack net at 64x64 and 32x32, batch 24; warm and cold (640 MB of other traffic between launches)."""
 import os, subprocess, sys
 if len(sys.argv) > 1 and sys.argv[1] == 'child':
     sys.path.insert(0, '.')
@@ -17,6 +18,7 @@ if len(sys.argv) > 1 and sys.argv[1] == 'child':
                 check(L.pa_conv2d_time(mode, v, 24, Cin, Cout, H, H, 1, 30, ptr(ws), C.byref(ms), stream()))
                 print('%s %3d->%3d %2dx%2d var %2d %s  %7.1f us' % ('fwd  ' if mode == 0 else 'dgrad', Cin, Cout, H, H, v & 15, 'cold' if v & 16 else 'warm', ms.value * 1e3), flush=True)
 else:
-    for m in sys.argv[1:] or ('0', '1', '2'):
-        print('--- PA_CONV1_WS=' + m, flush=True)
-        subprocess.run([sys.executable, __file__, 'child'], env=dict(os.environ, PA_CONV1_WS=m), check=True)
+    var = sys.argv[1]
+    for m in sys.argv[2:]:
+        print('--- %s=%s' % (var, m), flush=True)
+        subprocess.run([sys.executable, __file__, 'child'], env=dict(os.environ, **{var: m}), check=True)
