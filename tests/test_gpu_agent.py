@@ -137,7 +137,7 @@ def test_joint_training_steps_run_and_learn():
     from pose_adv_aug_amd.utils.optim import RMSprop
     from pose_adv_aug_amd.data import Augmenter, DeviceBatch
     from pose_adv_aug_amd import joint_train_pose_s_r_agent as J
-    B = 8
+    B = 24                                                      # BASELINE configs[3]: bs 24 per GPU
     hg = create_hg(2, 1, 16, 256, default_batch=B); hg.reset_parameters(seed=1)
     agent = create_asn(256, 256, 7, 7, is_aug=True, default_batch=B); agent.reset_parameters(seed=2)
     assert agent.num_params() == 2577934 and hg.num_params() == 6570784
