@@ -187,12 +187,37 @@ __global__ __launch_bounds__(256) void crop_src_kernel(const unsigned char* src,
     const CropPlan& P = plans[blockIdx.y];
     if (!P.case_b) return;
     const int ncol = P.sx1 - P.sx0, nrow = P.sy1 - P.sy0;
-    const long total = (long)ncol * nrow;
     const unsigned char* img = src + (size_t)blockIdx.y * Hs * Ws * 3;
     uchar4* out = s4 + (size_t)blockIdx.y * s4_stride;
     __shared__ unsigned char lut[3][256];
     for (int k = threadIdx.x; k < 768; k += blockDim.x) lut[k >> 8][k & 255] = (unsigned char)src_byte((unsigned char)(k & 255), P.gain[k >> 8], true);
     __syncthreads();
+    if ((Ws & 3) == 0 && ((size_t)src & 3) == 0) {
+        // an item = 4 consecutive SOURCE pixels at a 4-pixel boundary = three aligned dwords (one byte load per channel kept 192 bytes
+        // per wave in flight: 0.5 TB/s on frames that are not in any cache); the window's source columns are [lo, hi) -- mirrored or not
+        const int lo = P.flip ? P.wb - P.sx1 : P.sx0, hi = lo + ncol;
+        const int g0 = lo >> 2, ng = ((hi - 1) >> 2) - g0 + 1;
+        const unsigned total = (unsigned)ng * (unsigned)nrow;
+        for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+            const unsigned r = i / (unsigned)ng, g = i - r * (unsigned)ng;
+            const int c0 = (g0 + (int)g) << 2;
+            const unsigned* w = reinterpret_cast<const unsigned*>(img + ((size_t)(P.sy0 + (int)r) * Ws + c0) * 3);
+            const unsigned w0 = w[0], w1 = w[1], w2 = w[2];
+            const unsigned char b[12] = {(unsigned char)w0, (unsigned char)(w0 >> 8), (unsigned char)(w0 >> 16), (unsigned char)(w0 >> 24),
+                                         (unsigned char)w1, (unsigned char)(w1 >> 8), (unsigned char)(w1 >> 16), (unsigned char)(w1 >> 24),
+                                         (unsigned char)w2, (unsigned char)(w2 >> 8), (unsigned char)(w2 >> 16), (unsigned char)(w2 >> 24)};
+            uchar4* orow = out + (size_t)r * s4_pitch;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int cs = c0 + k;
+                if (cs < lo || cs >= hi) continue;
+                const int x = (P.flip ? P.wb - 1 - cs : cs) - P.sx0;
+                orow[x] = make_uchar4(lut[0][b[3 * k]], lut[1][b[3 * k + 1]], lut[2][b[3 * k + 2]], 0);
+            }
+        }
+        return;
+    }
+    const long total = (long)ncol * nrow;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int r = (int)(i / ncol), x = (int)(i - (long)r * ncol);
         const int xs = P.sx0 + x;

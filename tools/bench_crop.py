@@ -16,3 +16,12 @@ for _ in range(50):
     HumanAug.crop_batch(batch.frames, batch.params)
 torch.cuda.synchronize()
 print('pa_crop: %.1f us per batch of 24' % ((time.perf_counter() - t0) / 50 * 1e6))
+if len(sys.argv) > 1 and sys.argv[1] == 'cold':        # the frames are not in any cache (as inside the training step): 640 MB of other traffic between calls
+    scratch = torch.empty(640 << 20, dtype=torch.uint8, device='cuda')
+    tot = 0.0
+    for i in range(20):
+        scratch.fill_(i & 1)
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record(); HumanAug.crop_batch(batch.frames, batch.params); e1.record(); e1.synchronize()
+        tot += e0.elapsed_time(e1)
+    print('pa_crop cold: %.1f us per batch of 24' % (tot / 20 * 1e3))
