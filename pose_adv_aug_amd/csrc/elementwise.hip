@@ -830,37 +830,30 @@ __global__ __launch_bounds__(1024) void weight_prep_kernel(const PaPrepJob* jobs
         }
         return;
     }
-    // 32 x 32 (n, c) tiles through LDS.  Read: the tile's 32 source rows are runs of 32 * taps contiguous floats -> consecutive
-    // threads read consecutive addresses.  Write: wf along c and wb along n as bf16 pairs (4-byte stores, 64 contiguous bytes per
-    // (row, tap)).  (Read element-wise per output the strided source fetched 10-20x its bytes; with `taps` floats per thread and
-    // 2-byte stores the pass took 47-65 us of every step's tail.)
-    __shared__ bf16 tile[9][32][34];
-    const int taps = j.taps, run = 32 * taps;
+    // 32 x 32 (n, c) tiles: the fp32 source is read once, in contiguous runs (taps floats per thread); wf is written along c,
+    // wb along n through an LDS transpose (read element-wise per output the strided source fetched 10-20x its bytes)
+    __shared__ bf16 tile[9][32][33];
+    const int tn = threadIdx.x >> 5, tc = threadIdx.x & 31;
     const int tiles_c = j.pad_cin / 32, ntiles = (j.pad_cout / 32) * tiles_c;
     for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
         const int n0 = (t / tiles_c) * 32, c0 = (t % tiles_c) * 32;
-        for (int e = threadIdx.x; e < 32 * run; e += blockDim.x) {
-            const int nl = e / run, rem = e - nl * run;
-            const int cl = rem / taps, tap = rem - cl * taps;
-            const int n = n0 + nl, c = c0 + cl;
-            const bf16 v = (bf16)((n < j.Cout && c < j.Cin) ? j.w[((size_t)n * j.Cin + c0) * taps + rem] : 0.f);
-            tile[tap][nl][cl] = v;
+        const int n = n0 + tn, c = c0 + tc;
+        const bool ok = n < j.Cout && c < j.Cin;
+        const float* src = j.w + ((size_t)n * j.Cin + c) * j.taps;
+        for (int tap = 0; tap < j.taps; ++tap) {
+            const bf16 v = (bf16)(ok ? src[tap] : 0.f);
+            j.wf[((size_t)n * j.taps + tap) * j.pad_cin + c] = v;
             if (j.wp) {                                                 // lane = (k % 32) / 8 * 16 + n % 16 of fragment (n / 16, k / 32), k = tap * Cin + c
-                const int k = tap * j.pad_cin + c, S = taps * j.pad_cin >> 5;
+                const int k = tap * j.pad_cin + c, S = j.taps * j.pad_cin >> 5;
                 j.wp[((((size_t)(n >> 4) * S + (k >> 5)) * 64 + ((k & 31) >> 3) * 16 + (n & 15)) << 3) + (k & 7)] = v;
             }
+            tile[tap][tn][tc] = v;
         }
         __syncthreads();
-        for (int e = threadIdx.x; e < 16 * run; e += blockDim.x) {         // (row, tap, pair): 16 pairs per 32-element run
-            const int pr = e & 15, rt = e >> 4;
-            const int tap = rt % taps, rl = rt / taps;
-            bf16x2 o;
-            o[0] = tile[tap][rl][2 * pr]; o[1] = tile[tap][rl][2 * pr + 1];
-            *reinterpret_cast<bf16x2*>(j.wf + ((size_t)(n0 + rl) * taps + tap) * j.pad_cin + c0 + 2 * pr) = o;
-            if (j.wb) {                                                     // row = input channel c0 + rl, pair along the output channels
-                o[0] = tile[tap][2 * pr][rl]; o[1] = tile[tap][2 * pr + 1][rl];
-                *reinterpret_cast<bf16x2*>(j.wb + ((size_t)(c0 + rl) * taps + (taps - 1 - tap)) * j.pad_cout + n0 + 2 * pr) = o;
-            }
+        if (j.wb) {
+            // thread (tn, tc) now writes channel c0 + tn, output channel n0 + tc
+            for (int tap = 0; tap < j.taps; ++tap)
+                j.wb[((size_t)(c0 + tn) * j.taps + (j.taps - 1 - tap)) * j.pad_cout + n0 + tc] = tile[tap][tc][tn];
         }
         __syncthreads();
     }

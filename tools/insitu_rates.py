@@ -13,7 +13,7 @@ def plain(mb):
 dur = {}
 for l in open('profiles/%s_e_kernel_stats_single_stream.txt' % tag):
     m = re.match(r'\s*([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+(.*)', l)
-    if m: dur[m.group(5).strip()[:60]] = (float(m.group(2)), float(m.group(3)))
+    if m: dur[m.group(5).strip()] = (float(m.group(2)), float(m.group(3)))
 print('# %s: bytes per launch (PMC) / duration alone (single-stream pass) vs the cold rate of a plain elementwise kernel of that size' % tag)
 print('# %-62s %6s %8s %8s %7s %9s %6s' % ('kernel', 'calls', 'avg us', 'MB/call', 'TB/s', 'plain TB/s', 'ratio'))
 tot_t = tot_p = 0.0
@@ -21,9 +21,11 @@ for l in open('profiles/%s_f_pmc_hbm_traffic.txt' % tag):
     m = re.match(r'\s*([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+(.*)', l)
     if not m: continue
     name = m.group(5).strip()
-    key = [k for k in dur if k.startswith(name[:40]) or name.startswith(k[:40])]
+    base = name.split('(')[0].strip()
+    key = [k for k in dur if k.split('(')[0].strip() == base or (len(base) >= 58 and k.startswith(base[:58]))]
     if not key or 'fillBuffer' in name: continue
     calls, avg = dur[key[0]]
+    if abs(calls - float(m.group(4))) > 0.25 * calls: continue       # (launch counts of the two passes differ: not the same set of launches)
     mb = (float(m.group(2)) + float(m.group(3))) / float(m.group(4))
     if mb < 20: continue                        # latency-bound launches: no bandwidth statement
     rate = mb / avg                             # MB/us = TB/s
