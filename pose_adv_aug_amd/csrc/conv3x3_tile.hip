@@ -52,7 +52,7 @@ template <int N> __device__ __forceinline__ void pa_wait_vmcnt() {
     else static_assert(N == 0, "unsupported vmcnt");
 }
 
-template <int CIN, int BN, int LDMODE, int TW = 16, int TH = 8, int SPS = 1>
+template <int CIN, int BN, int LDMODE, int TW = 16, int TH = 8, int SPS = 1, bool PF = false>
 __global__ __launch_bounds__(256, (TW == 16 ? (TH == 4 ? (SPS == 1 ? 3 : 2) : 2) : 1)) void conv3x3_tile_kernel(PaConvArgs a) {
     constexpr int BM = (TW == 16 && TH == 4) ? 64 : 128;
     constexpr int IMG = BM / (TW * TH), PW = TW + 2, PHh = TH + 2, HP = IMG * PHh * PW;   // 180 / 108 / 200 / 288 halo pixels
@@ -106,6 +106,7 @@ __global__ __launch_bounds__(256, (TW == 16 ? (TH == 4 ? (SPS == 1 ? 3 : 2) : 2)
     };
     issue_w(0); issue_w(1);
     if (NBUF == 4) issue_w(2);
+    if (PF) issue_w(NBUF - 1);
 
     // ---- halo staging (single pass over the input, transform applied here)
     {
@@ -193,6 +194,58 @@ __global__ __launch_bounds__(256, (TW == 16 ? (TH == 4 ? (SPS == 1 ? 3 : 2) : 2)
         boff[ni] = row * 32 + ((fchk ^ ((-(row >> 2)) & 3)) << 3);
     }
 
+    if constexpr (PF) {
+        // SOFTWARE-PIPELINED K loop (SPS == 1): the fragments of slice st + 1 are read from LDS into a second register set while
+        // the MFMAs of slice st (read one step earlier) issue -- the plain loop below starts every step with a ds_read round trip
+        // in front of its 16 MFMAs.  Barrier of step st: slice st + 1 has landed for every wave (its DMA was issued three steps
+        // earlier; two younger slices may stay in flight), and every wave holds slice st's fragments in registers (lgkmcnt(0)),
+        // so buffer st % NBUF is free for slice st + NBUF.
+        static_assert(!PF || (SPS == 1 && NBUF == 4 && GPT % 2 == 0), "pipelined K loop: one slice per step, ring of 4, even steps per tap");
+        bf16x8 fa[2][MI], fw[2][NI];
+        int aoff[MI];
+        auto tap_offsets = [&](int tap) {
+            const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+            const int toff = dy * PW + dx;
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                const int p = pbase[mi] + toff;
+                aoff[mi] = p * CIN + ((fchk ^ halo_sw<CPP>(p)) << 3);
+            }
+        };
+        tap_offsets(0);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) fa[0][mi] = *reinterpret_cast<const bf16x8*>(halo + aoff[mi]);
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) fw[0][ni] = *reinterpret_cast<const bf16x8*>(wbuf + boff[ni]);
+        for (int tap = 0; tap < 9; ++tap) {
+#pragma unroll
+            for (int g = 0; g < GPT; ++g) {
+                const int st = tap * GPT + g;
+                constexpr int dummy = 0; (void)dummy;
+                const int cur = g & 1, nxt = cur ^ 1;                  // (GPT is even: the register set of a step is a compile-time index)
+                if (st + 1 < NST) {
+                    const int younger = NST - 2 - st;               // slices issued after st + 1
+                    if (younger >= 2) pa_wait_vmcnt<2 * NIW>();
+                    else if (younger == 1) pa_wait_vmcnt<NIW>();
+                    else pa_wait_vmcnt<0>();
+                    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                    if (st + NBUF < NST) issue_w(st + NBUF);
+                    if (g == GPT - 1) tap_offsets(tap + 1);
+                    const int sub = (g + 1) % GPT;
+                    const bf16* Bs = wbuf + ((st + 1) % NBUF) * (BN * 32);
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi) fa[nxt][mi] = *reinterpret_cast<const bf16x8*>(halo + (aoff[mi] ^ ((sub * 4) << 3)));
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) fw[nxt][ni] = *reinterpret_cast<const bf16x8*>(Bs + boff[ni]);
+                }
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi)
+                        acc[ni][mi] = PA_MFMA_16x16x32(fw[cur][ni], fa[cur][mi], acc[ni][mi]);
+            }
+        }
+    } else
     // K loop: step `st` is consumed while steps st+1 (, st+2) are in flight and step st+NBUF-1 is issued right after the
     // barrier into the buffer that was read in step st-1.  Counted vmcnt + raw s_barrier: __syncthreads() would drain
     // the LDS-DMA queue (vmcnt(0)) and expose one L2 round trip per slice, which is what bounded the first version
@@ -248,25 +301,35 @@ __global__ __launch_bounds__(256, (TW == 16 ? (TH == 4 ? (SPS == 1 ? 3 : 2) : 2)
                                      reinterpret_cast<float*>(lds), (int)blockIdx.x);
 }
 
-template <int CIN, int BN, int TW, int TH, int SPS>
+template <int CIN, int BN, int TW, int TH, int SPS, bool PF>
 static void launch_tile_ld(const PaConvArgs& a, dim3 grid, hipStream_t st) {
     switch (a.in.mode) {
-        case PA_LD_PLAIN: hipLaunchKernelGGL((conv3x3_tile_kernel<CIN, BN, PA_LD_PLAIN, TW, TH, SPS>), grid, dim3(256), 0, st, a); break;
-        case PA_LD_BNRELU: hipLaunchKernelGGL((conv3x3_tile_kernel<CIN, BN, PA_LD_BNRELU, TW, TH, SPS>), grid, dim3(256), 0, st, a); break;
-        default: hipLaunchKernelGGL((conv3x3_tile_kernel<CIN, BN, PA_LD_LIN2, TW, TH, SPS>), grid, dim3(256), 0, st, a); break;
+        case PA_LD_PLAIN: hipLaunchKernelGGL((conv3x3_tile_kernel<CIN, BN, PA_LD_PLAIN, TW, TH, SPS, PF>), grid, dim3(256), 0, st, a); break;
+        case PA_LD_BNRELU: hipLaunchKernelGGL((conv3x3_tile_kernel<CIN, BN, PA_LD_BNRELU, TW, TH, SPS, PF>), grid, dim3(256), 0, st, a); break;
+        default: hipLaunchKernelGGL((conv3x3_tile_kernel<CIN, BN, PA_LD_LIN2, TW, TH, SPS, PF>), grid, dim3(256), 0, st, a); break;
     }
 }
 
 // SPS: slices per K-loop step of the latency-bound variants (128 input channels): a whole tap for the 8x8 / 4x4 maps, half a
 // tap for the 16 x 4 tiles; 1 everywhere else (the 16 x 8 tiles of the big maps are throughput-bound and need their LDS for 2
-// workgroups per CU)
+// workgroups per CU).  The 16 x 8 tiles run the software-pipelined K loop (PA_CONV3_PF=0: the plain one).
 template <int TW, int TH, int SPS>
 static void launch_tile_shape(const PaConvArgs& a, dim3 grid, bool bigN, hipStream_t st) {
     if constexpr (TW != 16) {                      // the small maps always run 64-channel halves (bigN is false for them)
-        if (a.Cin == 128) launch_tile_ld<128, 64, TW, TH, SPS>(a, grid, st); else launch_tile_ld<64, 64, TW, TH, 1>(a, grid, st);
+        if (a.Cin == 128) launch_tile_ld<128, 64, TW, TH, SPS, false>(a, grid, st); else launch_tile_ld<64, 64, TW, TH, 1, false>(a, grid, st);
+    } else if constexpr (TH == 8 && SPS == 1) {
+        static int pf = -1;
+        if (pf < 0) { const char* e = pa_getenv("PA_CONV3_PF"); pf = e ? atoi(e) : 1; }
+        if (pf) {
+            if (a.Cin == 128) { if (bigN) launch_tile_ld<128, 128, TW, TH, 1, true>(a, grid, st); else launch_tile_ld<128, 64, TW, TH, 1, true>(a, grid, st); }
+            else { if (bigN) launch_tile_ld<64, 128, TW, TH, 1, true>(a, grid, st); else launch_tile_ld<64, 64, TW, TH, 1, true>(a, grid, st); }
+        } else {
+            if (a.Cin == 128) { if (bigN) launch_tile_ld<128, 128, TW, TH, 1, false>(a, grid, st); else launch_tile_ld<128, 64, TW, TH, 1, false>(a, grid, st); }
+            else { if (bigN) launch_tile_ld<64, 128, TW, TH, 1, false>(a, grid, st); else launch_tile_ld<64, 64, TW, TH, 1, false>(a, grid, st); }
+        }
     } else {
-        if (a.Cin == 128) { if (bigN) launch_tile_ld<128, 128, TW, TH, SPS>(a, grid, st); else launch_tile_ld<128, 64, TW, TH, SPS>(a, grid, st); }
-        else { if (bigN) launch_tile_ld<64, 128, TW, TH, 1>(a, grid, st); else launch_tile_ld<64, 64, TW, TH, 1>(a, grid, st); }
+        if (a.Cin == 128) { if (bigN) launch_tile_ld<128, 128, TW, TH, SPS, false>(a, grid, st); else launch_tile_ld<128, 64, TW, TH, SPS, false>(a, grid, st); }
+        else { if (bigN) launch_tile_ld<64, 128, TW, TH, 1, false>(a, grid, st); else launch_tile_ld<64, 64, TW, TH, 1, false>(a, grid, st); }
     }
 }
 
