@@ -22,5 +22,11 @@ build_variant() {      # $1 = object directory, $2 = extra flags, $3 = library n
   hipcc --offload-arch=gfx950 -shared -fPIC $objs -o ../$lib
   echo "built $(cd .. && pwd)/$lib"
 }
-build_variant ../build "" libposeadv_hip.so
-build_variant ../build_fp16 "-DPA_FP16" libposeadv_hip_fp16.so
+# the two variants side by side (the longest translation unit of one overlaps the short ones of the other)
+build_variant ../build "" libposeadv_hip.so &
+P1=$!
+build_variant ../build_fp16 "-DPA_FP16" libposeadv_hip_fp16.so &
+P2=$!
+wait $P1; R1=$?
+wait $P2; R2=$?
+[ $R1 -eq 0 ] && [ $R2 -eq 0 ]
