@@ -91,7 +91,7 @@ def cpu_baseline(stacks, chan, B, res, budget_s=40.0, steps=5):
 
 def pckh_parity(net, aug, batch, B, res):
     """The "PCKh match" half of BASELINE.json's metric, on the driver's line (outside the timed region; the oracle is the
-    CHECKER here): the engine's in-step metrics (pa_hg_accuracy, pa_hg_pckh) of one more training step against the oracle's
+    CHECKER here): the engine's in-step metrics (pa_hg_accuracy, pa_hg_pckh) of one more training-mode forward pass against the oracle's
     pylib/Evaluation.py:54-97 restatement on the engine's own heat maps, and -- an untrained net on noise frames scores ~0 --
     the same two entry points on target + noise maps (pylib.Evaluation = the C ABI's pa_accuracy / pa_accuracy_origin_res)."""
     import numpy as np
@@ -101,7 +101,7 @@ def pckh_parity(net, aug, batch, B, res):
     from pose_adv_aug_amd.stack_hg import PCK_IDX
     H = res // 4
     data = aug.regular(batch)
-    net.loss_and_backward(img4=data['img4'], pts=data['pts'])
+    net.forward(img4=data['img4'], pts=data['pts'])            # forward only: rank 0 runs this alone, a backward pass may hold collectives (--overlap)
     maps = net.heatmaps(B)[-1].cpu()
     target = pylib.HumanPts.pts2heatmap_batch(data['pts'], H, H).cpu()
     c, s, r = data['c'].cpu().float(), data['s'].cpu().float().view(B, 1), data['r'].cpu().float().view(B, 1)

@@ -171,3 +171,29 @@ def test_joint_stage_main_on_two_ranks(tmp_path):
     assert sorted(f for f in r0['saves'] if f.endswith('.pth.tar')) == ['agent-lr-0.00005-1.pth.tar', 'pose-lr-0.00025-1.pth.tar'] and r1['saves'] == []
     jd = os.path.join(exp, 'run', 'joint-lr-0.00025-0')
     assert os.path.isfile(os.path.join(jd, 'pose-lr-0.00025-1-preds.mat')) and 'loss_agent_sr' in open(os.path.join(jd, 'train-log.txt')).read()
+
+
+@pytest.mark.parametrize('overlap', [0, 1])
+def test_bench_line_from_two_ranks(overlap):
+    """bench.py's own N > 1 path as the driver launches it (torch.distributed.run, one JSON line from rank 0), two ranks on the one
+    GPU of the test box with gloo carrying the exchange -- including the overlapped exchange, whose collectives must not be entered
+    by rank 0 alone in the untimed legs (roofline pass, PCKh parity)."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, POSEADV_DIST_BACKEND='gloo')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT', 'POSEADV_DIST_INIT', 'POSEADV_FORCE_DIST'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+                        '--master-port', str(port), os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1',
+                        '--no-cpu-baseline', '--overlap', str(overlap)], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]                      # rank 0 alone prints
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['steps'] == 3 and d['scaling'] == 'weak' and d['value'] > 0
+    assert d['config']['global_batch'] == 48 and d['config']['parallelism'] == ('dp2+overlapped-exchange' if overlap else 'dp2')
+    assert d['pckh_parity']['match'] is True and d['roofline']['frac'] > 0 and d['cpu_baseline'] is None
