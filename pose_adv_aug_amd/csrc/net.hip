@@ -922,6 +922,8 @@ int Net::train_step_graph(bool train) {
     TRY(ensure_streams());
     const int key = (train ? 1 : 0) | (multi_stream ? 2 : 0);
     if (drop_mask || prof.on) { pa_set_error_msg("train_step_graph: not with the occlusion branch / the launch profiler"); return 1; }
+    // (a replayed launch would carry the launch number of the capture: its barrier tags would match the previous replay's granules)
+    if (fused_low) { pa_set_error_msg("train_step_graph: not with the fused low-resolution launch (pa_net_set_fused_lowres)"); return 1; }
     if (!step_exec || step_key != key) {
         release_graph();
         // the caller's stream may be the legacy default stream, which cannot capture: capture on a stream of our own

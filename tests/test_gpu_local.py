@@ -235,3 +235,22 @@ def test_blocks_of_every_resolution_match_locally_at_the_benchmark_size(fused):
             _close(errs, 'dz ' + out_name + k, P.grad(out_name + k), inner.grad * (inner.detach() > 0).float(), GRAD_TOL, GRAD_COS)
     assert sizes == [64, 32, 16, 8, 4]
     assert not errs, '%d local mismatches, first: %s' % (len(errs), errs[:15])
+
+
+def test_graph_replay_refuses_the_fused_low_resolution_launch():
+    """A captured fused launch would replay with the launch number of the capture (its barrier tags would match the granules of
+    the previous replay): pa_hg_train_step(use_graph=1) must fail loudly while pa_net_set_fused_lowres is on."""
+    from pose_adv_aug_amd._lib import PoseAdvError
+    from pose_adv_aug_amd.models.asn_stacked_hg import create_hg
+    from pose_adv_aug_amd.utils.optim import RMSprop
+    from pose_adv_aug_amd.data import Augmenter, DeviceBatch
+    from pose_adv_aug_amd.stack_hg import train_step
+    B = 2
+    net = create_hg(1, 1, 16, 128, default_batch=B); net.reset_parameters(seed=3); net.train()
+    net.fused_lowres = True
+    net.use_graph = True
+    with pytest.raises(PoseAdvError, match='fused low-resolution'):
+        train_step(net, RMSprop(net, lr=2.5e-4), Augmenter(seed=9), DeviceBatch.synthetic(B, seed=40))
+    net.use_graph = False
+    loss, _, _ = train_step(net, RMSprop(net, lr=2.5e-4), Augmenter(seed=9), DeviceBatch.synthetic(B, seed=40))
+    assert np.isfinite(float(loss))
