@@ -172,9 +172,9 @@ def test_agent_update_matches_the_oracle_restatement(override):
     """train_agent_sr (joint-train-pose-s-r-agent.py:317-422) as ONE unit against oracle/step.py:train_agent_sr: the engine
     records its crops (device crop, parity-pinned in test_gpu_crop.py), the sampled bins and every intermediate; the oracle
     replays the same batch with the same bins.  Asserted: the softmax outputs (2e-2), the four per-person PCKh vectors
-    (computed by each side on ITS OWN heat maps: mean |diff| <= 0.1), the reward-shaped targets -- engine vs the oracle's
-    gen_groundtruth on the engine's own (probabilities, bins, PCKh) to 1e-6 and vs the full oracle to 3e-2 --, the KL loss
-    (formula: 1e-5 on the engine's operands; end to end: 5 %), and the direction of the RMSprop step of the two Linear
+    (computed by each side on ITS OWN heat maps: mean |diff| <= 0.05, one flipped joint of 4 x 13; observed 0 - 0.02), the reward-shaped targets -- engine vs the oracle's
+    gen_groundtruth on the engine's own (probabilities, bins, PCKh) to 1e-6 and vs the full oracle to 2e-2 (observed 1.2e-2) --, the KL loss
+    (formula: 1e-5 on the engine's operands; end to end: 3.5 %, observed 1.9 %), and the direction of the RMSprop step of the two Linear
     heads (first step = -lr * 10 * sign(g): cosine of the parameter deltas >= 0.9).  override=True feeds both sides the
     same non-trivial PCKh vectors so that BOTH branches of the reward shaping and its clamp run."""
     from pose_adv_aug_amd.utils.optim import RMSprop
@@ -202,17 +202,17 @@ def test_agent_update_matches_the_oracle_restatement(override):
                              si, ri, pckh_override=ov)
     for k in range(2):
         assert float((tr['probs'][k].cpu() - o['probs'][k]).abs().max()) < 2e-2
-        assert float((tr['pckh_regular'][k].cpu() - o['pckh_regular'][k]).abs().mean()) <= 0.1
-        assert float((tr['pckh_agent'][k].cpu() - o['pckh_agent'][k]).abs().mean()) <= 0.1
+        assert float((tr['pckh_regular'][k].cpu() - o['pckh_regular'][k]).abs().mean()) <= 0.05
+        assert float((tr['pckh_agent'][k].cpu() - o['pckh_agent'][k]).abs().mean()) <= 0.05
         mine = opl.gen_groundtruth(tr['probs'][k].cpu(), (si, ri)[k].view(-1, 1), tr['pckh_regular'][k].cpu(), tr['pckh_agent'][k].cpu())
         assert float((tr['targets'][k].cpu() - mine).abs().max()) < 1e-6
         assert abs(float(mine.sum()) - B) < 1e-5
         if override:
-            assert float((tr['targets'][k].cpu() - o['targets'][k]).abs().max()) < 3e-2
+            assert float((tr['targets'][k].cpu() - o['targets'][k]).abs().max()) < 2e-2
     l_formula = float(ostep.agent_kl_loss(tr['logits'][0].cpu(), tr['logits'][1].cpu(), tr['targets'][0].cpu(), tr['targets'][1].cpu()))
     assert abs(float(loss) - l_formula) < 1e-5 + 1e-4 * abs(l_formula), (float(loss), l_formula)
     if override:
-        assert abs(float(loss) - float(o['loss'])) < 5e-2 * abs(float(o['loss'])) + 1e-4, (float(loss), float(o['loss']))
+        assert abs(float(loss) - float(o['loss'])) < 3.5e-2 * abs(float(o['loss'])) + 1e-4, (float(loss), float(o['loss']))
         rsd = ragent.state_dict()
         for name in ('fc_scale.weight', 'fc_rotation.weight'):
             d_dev = (agent.state_dict()[name].cpu() - before[name].cpu()).flatten()
