@@ -7,7 +7,8 @@ stress case: --stacks 8 --res 384 --bs 16 --dtype fp16):
     backward  ->  ONE all-reduce of the flat gradient (RCCL, N > 1)  ->  fused RMSprop + bf16 weight
     re-pack  ->  PCKh (heat-map space and original resolution) on the device
 
-    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, or plain -- bench.py then
+                                                          starts its N ranks itself, self_launch())
 
 Prints ONE JSON line on rank 0 (contract in the task description).  `roofline` comes from HIP events
 recorded around every launch of the MFMA kernels on the engine's own stream during a second pass of K
@@ -77,8 +78,16 @@ def cpu_baseline(stacks, chan, B, res, budget_s=40.0, steps=5):
     """The CPU oracle timed on this box's host cores: the benchmark's own configuration and the
     reference's CPU-runnable plumbing case C1 (1-stack, B = 2), >= 5 timed steps each after a warm-up."""
     # PyTorch's CPU convolutions stop scaling (and collapse when oversubscribed) well before the core count of a GPU
-    # host: 32 threads is the measured sweet spot; both the threads used and the cores present are reported.
-    threads = min(32, os.cpu_count() or 1)
+    # host: the thread count is the best point of the committed sweep (profiles/cpu_thread_sweep.json, tools/cpu_thread_sweep.py,
+    # same host class), 32 without one; both the threads used and the cores present are reported.
+    threads = 32
+    try:
+        sw = json.load(open(os.path.join(ROOT, 'profiles', 'cpu_thread_sweep.json')))
+        if sw.get('host_cores') == os.cpu_count():
+            threads = int(sw['best_threads'])
+    except (OSError, ValueError, KeyError):
+        pass
+    threads = min(threads, os.cpu_count() or 1)
     torch.set_num_threads(threads)
     v, b, dt = _time_oracle(stacks, chan, B, res, steps, budget_s)
     v1, b1, dt1 = _time_oracle(1, chan, 2, res, steps, 10.0)
@@ -124,11 +133,93 @@ def pckh_parity(net, aug, batch, B, res):
             'per_joint_values_compared': int(sum(len(x) for x in (e_acc, e_pck, e2_acc, e2_pck)))}
 
 
+def cold_rate(dev, mb=(25, 50, 100)):
+    """What a plain streaming kernel reaches on tensors it has not touched for a few hundred MB of traffic (tools/bw_probe_cold.py's
+    protocol: `a + b -> c` on bf16 tensors of the step's sizes, 640 MB of other traffic between launches, one event pair per launch).
+    Returns TB/s at the median size and the per-size table."""
+    flush = torch.empty(640 << 20, dtype=torch.uint8, device=dev)
+    out = {}
+    for m in mb:
+        n = (m << 20) // 2
+        a, b, c = (torch.empty(n, dtype=torch.bfloat16, device=dev).normal_() for _ in range(3))
+        ts = []
+        for _ in range(7):
+            flush.add_(1)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); torch.add(a, b, out=c); e1.record()
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1) * 1e-3)
+        ts.sort()
+        out[m] = 3.0 * (m << 20) / ts[len(ts) // 2] / 1e12
+    sizes = sorted(out)
+    return out[sizes[len(sizes) // 2]], {('%dMB' % k): round(v, 2) for k, v in out.items()}
+
+
+def design_floor(net, opt, B, res, h):
+    """`roofline.floor`: the bytes THIS fused design moves per step (engine launch table, pa_net_design_bytes: activations, both
+    operands of the BatchNorm-backward loads, reference tensors, stored dz tensors, fp32 slabs written + read back, weights; plus the
+    optimizer, the weight re-pack and the crop counted here from their sizes) at the cold streaming rate measured in this run =>
+    the step time this set of fusions cannot go below on this box; algorithmic bytes beside it."""
+    from pose_adv_aug_amd import _lib
+    rw = (C.c_double * 2)()
+    _lib.check(_lib.lib().pa_net_design_bytes(h, rw))
+    npar = int(net.flat_params.numel())
+    extra_rd = 3 * 4.0 * npar + 4.0 * npar + B * 3.0 * 720 * 1280 * 0.35       # RMSprop p, g, v; re-pack source; crop window (~35 % of a frame)
+    extra_wr = 2 * 4.0 * npar + 2 * 2.0 * npar + B * (res * res * 4 * 2.0 + 3.3e6 * 0.3)
+    total = rw[0] + rw[1] + extra_rd + extra_wr
+    rate, table = cold_rate(net.flat_params.device)
+    return {'design_bytes_per_step': round(total), 'design_read': round(rw[0] + extra_rd), 'design_write': round(rw[1] + extra_wr),
+            'algorithmic_bytes_per_step': round(380.5e6 * B) if res == 256 else None,
+            'cold_rate_TBps': round(rate, 2), 'cold_rate_table_TBps': table, 'floor_ms': round(total / (rate * 1e12) * 1e3, 3),
+            'floor_ms_at_8TBps': round(total / 8e12 * 1e3, 3),
+            'note': 'floor_ms = design bytes / cold streaming rate of a plain a+b->c kernel at the median tensor size (measured in this run)'}
+
+
+def self_launch(n):
+    """Start ranks 0..n-1 of this command (same argv) and wait for them: RANK / LOCAL_RANK / WORLD_SIZE in the environment,
+    rendezvous through a file store (POSEADV_DIST_INIT=file://...), HSA_ENABLE_IPC_MODE_LEGACY=0 kept for RCCL's dmabuf IPC.
+    The children inherit stdout / stderr, so rank 0's JSON line is this command's output.  Returns the worst exit code; a rank
+    that dies takes the others down instead of leaving them in a collective."""
+    import subprocess
+    import tempfile
+    store = tempfile.NamedTemporaryFile(prefix='poseadv_bench_store_', delete=False)
+    store.close()
+    os.unlink(store.name)                                    # FileStore creates it
+    env = dict(os.environ, WORLD_SIZE=str(n), POSEADV_DIST_INIT='file://' + store.name, POSEADV_SELF_LAUNCHED='1')
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('MASTER_ADDR', '127.0.0.1')
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
+                              env=dict(env, RANK=str(r), LOCAL_RANK=str(r))) for r in range(n)]
+    rc = 0
+    try:
+        pending = list(procs)
+        while pending:
+            for p in list(pending):
+                try:
+                    code = p.wait(timeout=0.5)
+                except subprocess.TimeoutExpired:
+                    continue
+                pending.remove(p)
+                if code != 0:
+                    rc = rc or code
+                    for q in pending:                        # exact PIDs we started, nothing else
+                        q.terminate()
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        try:
+            os.unlink(store.name)
+        except OSError:
+            pass
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=30)
-    ap.add_argument('--warmup', type=int, default=8)
+    ap.add_argument('--steps', type=int, default=100, help='timed steps (SURVEY.md section 8d protocol: 20 warm-up + 100 timed)')
+    ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--bs', type=int, default=24, help='per-GPU batch (BASELINE config: 24)')
     ap.add_argument('--stacks', type=int, default=2)
     ap.add_argument('--chan', type=int, default=256)
@@ -140,8 +231,17 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-parity', action='store_true')
+    ap.add_argument('--no-traffic', action='store_true', help='do not start the rocprofv3 child passes (PMC HBM traffic, kernel trace) of this command; '
+                    'by default they run at N = 1 when rocprofv3 is on PATH, and the recorded profiles/ numbers are quoted otherwise')
+    ap.add_argument('--no-floor', action='store_true', help='skip the design-bytes / cold-rate floor of the roofline object')
+    ap.add_argument('--keep-profiles', action='store_true', help='keep the child passes\' rocprofv3 output under gpurun_out/')
     ap.add_argument('--fused-lowres', type=int, default=0, help='1: the sub-hourglass below 32 x 32 as one persistent launch per stack (experiment, DESIGN.md)')
     args = ap.parse_args()
+
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # plain `python bench.py --gpus N`: launch the N ranks ourselves (one process per GPU, FileStore rendezvous -- no TCP port),
+        # exactly what `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` starts; rank 0 prints the line
+        raise SystemExit(self_launch(args.gpus))
 
     from pose_adv_aug_amd import _lib
     _lib.set_dtype(args.dtype)
@@ -175,7 +275,7 @@ def main():
 
     ahead = AugmentAhead(aug)
 
-    def run(n):
+    def run(n, mark=None):
         """n steps of stack_hg.train's loop body: the NEXT batch's augmentation (law + crop + joints, all inside the timed
         region) is enqueued one step ahead on its own stream, like the reference's DataLoader workers"""
         out = None
@@ -184,6 +284,8 @@ def main():
             data = ahead.take()
             ahead.start(batches[(i + 1) % len(batches)] if i + 1 < n else None)
             out = train_step(net, opt, aug, batches[i % len(batches)], data=data)
+            if mark is not None:
+                mark(i)
         return out
 
     run(args.warmup)
@@ -198,6 +300,16 @@ def main():
     dt = float(tmax[0])
     value = world * B * args.steps / dt
 
+    # median of per-step event intervals, in a pass of its own: an event record between two kernels of a queue
+    # costs that queue a bubble, so it stays out of the timed region that `value` comes from
+    nm = min(args.steps, 50)
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(nm + 1)]
+    evs[0].record()
+    run(nm, mark=lambda i: evs[i + 1].record())
+    sync()
+    per_step = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(nm))
+    median_ms = per_step[nm // 2]
+
     roofline = None
     if not args.no_roofline:
         h = net._net(B)
@@ -208,7 +320,7 @@ def main():
         _lib.check(_lib.lib().pa_net_profile_begin(h))
         run(args.steps)
         rep = (C.c_double * 64)()
-        _lib.check(_lib.lib().pa_net_profile_report(h, rep))
+        _lib.check(_lib.lib().pa_net_profile_report(h, rep, 16, None))
         _lib.check(_lib.lib().pa_net_set_multi_stream(h, 1))
         if rank == 0 and os.environ.get('PA_BENCH_SEQ_OUT'):            # for tools/trace_classes.py (rocprofv3 runs of this command)
             n = _lib.lib().pa_net_profile_classes(h, None, 0)
@@ -230,33 +342,55 @@ def main():
         else:
             ach, peak, unit = dom['bytes'] / secs / 1e9, HBM_PEAK / 1e9, 'GB/s'
         conv_ms = sum(r['ms_total'] for r in rows) / args.steps
-        # HBM bytes per launch of that kernel class from the PMC counters (FETCH_SIZE x2 + WRITE_SIZE, collected in
-        # separate rocprofv3 --pmc passes by tools/prof_pmc.sh and committed under profiles/); null if not collected
-        # (recorded numbers carry their source; they belong to the 2-stack bf16 benchmark configuration only)
+        # HBM bytes per launch of that kernel class from the PMC counters (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc
+        # passes) and its trace-grade duration (rocprofv3 --kernel-trace matched launch by launch with the engine's class sequence):
+        # MEASURED IN THIS RUN by child passes of this very command (tools/inrun_prof.py) when rocprofv3 is on PATH (rank 0, N = 1);
+        # otherwise the numbers committed under profiles/ are quoted, tagged as recorded.
         traffic, trace = None, None
         is_c2 = (args.stacks, args.chan, res, B, args.dtype) == (2, 256, 256, 24, 'bf16')
-        for name in ('round3_pmc.json', 'round2_pmc.json'):
-            pmc_path = os.path.join(ROOT, 'profiles', name)
-            if is_c2 and os.path.isfile(pmc_path):
-                pmc = json.load(open(pmc_path))
-                if dom['kernel'] in pmc:
-                    traffic = {'hbm_bytes_per_launch': round(pmc[dom['kernel']]['hbm_bytes_per_launch'], 1),
-                               'source': 'profiles/%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE passes of this command, recorded; not measured in this run)' % name}
+        wl = ['--bs', str(B), '--stacks', str(args.stacks), '--chan', str(args.chan), '--res', str(res), '--dtype', args.dtype,
+              '--fused-lowres', str(args.fused_lowres)]
+        measured_pmc = measured_tr = None
+        if rank == 0 and world == 1 and not args.no_traffic:
+            sys.path.insert(0, os.path.join(ROOT, 'tools'))
+            import inrun_prof
+            torch.cuda.synchronize()
+            measured_pmc = inrun_prof.measure_traffic(wl, keep=args.keep_profiles)
+            measured_tr = inrun_prof.measure_trace(wl, keep=args.keep_profiles)
+        if measured_pmc and dom['kernel'] in measured_pmc['classes']:
+            c = measured_pmc['classes'][dom['kernel']]
+            traffic = {'hbm_bytes_per_launch': round(c['hbm_bytes_per_launch'], 1), 'launches_profiled': c['launches_profiled'],
+                       'whole_step': {'fetch_bytes_x2': round(measured_pmc['fetch_bytes_per_step_x2']), 'write_bytes': round(measured_pmc['write_bytes_per_step'])},
+                       'source': 'measured in this run: rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) and --pmc WRITE_SIZE child passes of this command, 4 steps each'}
+        else:
+            for name in ('round4_pmc.json', 'round3_pmc.json', 'round2_pmc.json'):
+                pmc_path = os.path.join(ROOT, 'profiles', name)
+                if is_c2 and os.path.isfile(pmc_path):
+                    pmc = json.load(open(pmc_path))
+                    if dom['kernel'] in pmc:
+                        traffic = {'hbm_bytes_per_launch': round(pmc[dom['kernel']]['hbm_bytes_per_launch'], 1),
+                                   'source': 'profiles/%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE passes of this command, recorded; not measured in this run)' % name}
+                        break
+        tr, tr_src = None, None
+        if measured_tr and dom['kernel'] in measured_tr:
+            tr, tr_src = measured_tr[dom['kernel']], 'measured in this run: rocprofv3 --kernel-trace child pass of this command (single-stream roofline leg, 5 steps)'
+        else:
+            for name in ('round4_trace_classes.json', 'round3_trace_classes.json', 'round2_trace_classes.json'):
+                tr_path = os.path.join(ROOT, 'profiles', name)
+                if is_c2 and os.path.isfile(tr_path):
+                    tr, tr_src = json.load(open(tr_path)).get(dom['kernel']), 'profiles/%s (recorded; not measured in this run)' % name
                     break
-        # the same class from the committed rocprofv3 --kernel-trace of this command (tools/trace_classes.py): kernel
-        # durations without the event-to-event gaps; `frac` stays the live (event) number, `trace.frac` is quoted beside it
-        for name in ('round3_trace_classes.json', 'round2_trace_classes.json'):
-            tr_path = os.path.join(ROOT, 'profiles', name)
-            if not (is_c2 and os.path.isfile(tr_path)):
-                continue
-            tr = json.load(open(tr_path)).get(dom['kernel'])
-            if tr:
-                t_ach = (dom['flops'] if bound == 'mfma' else dom['bytes']) / dom['launches'] / (tr['avg_us'] * 1e-6) / (1e12 if bound == 'mfma' else 1e9)
-                trace = {'avg_kernel_us': tr['avg_us'], 'launches_per_step': tr['launches_per_step'], 'achieved': round(t_ach, 2),
-                         'frac': round(t_ach / peak, 4), 'source': 'profiles/%s (recorded; not measured in this run)' % name}
-            break
+        if tr:
+            t_ach = (dom['flops'] if bound == 'mfma' else dom['bytes']) / dom['launches'] / (tr['avg_us'] * 1e-6) / (1e12 if bound == 'mfma' else 1e9)
+            trace = {'avg_kernel_us': tr['avg_us'], 'launches_per_step': tr['launches_per_step'], 'achieved': round(t_ach, 2),
+                     'frac': round(t_ach / peak, 4), 'source': tr_src}
+            if measured_tr:
+                trace['classes_us'] = {k: v['avg_us'] for k, v in measured_tr.items()}
+        floor = None
+        if not args.no_floor:
+            floor = design_floor(net, opt, B, res, h)
         roofline = {'bound': bound, 'achieved': round(ach, 2), 'peak': peak, 'unit': unit, 'frac': round(ach / peak, 4),
-                    'traffic': traffic, 'trace': trace, 'kernel': dom['kernel'], 'avg_launch_us': round(dom['avg_us'], 2),
+                    'traffic': traffic, 'trace': trace, 'floor': floor, 'kernel': dom['kernel'], 'avg_launch_us': round(dom['avg_us'], 2),
                     'launches_per_step': dom['launches'] // args.steps,
                     'alg_bytes_per_launch': dom['bytes'] / dom['launches'], 'alg_flops_per_launch': dom['flops'] / dom['launches'],
                     'mfma_kernels_ms_per_step': round(conv_ms, 3),
@@ -278,7 +412,7 @@ def main():
     if rank == 0:
         line = {'metric': 'images/sec, %d-stack HG %dx%d bs=%d per GPU, full training step' % (args.stacks, res, res, B), 'value': round(value, 2),
                 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-                'ms_per_step': round(1e3 * dt / args.steps, 3), 'higher_is_better': True, 'scaling': 'weak',
+                'ms_per_step': round(1e3 * dt / args.steps, 3), 'ms_per_step_median': round(median_ms, 3), 'higher_is_better': True, 'scaling': 'weak',
                 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
                 'config': {'workload': '%s%d-stack hourglass chan %d, bs=%d/GPU, %dx%d MPII-shape synthetic frames '
                                        '(720x1280 uint8 resident in HBM), on-device HumanAug warp, heat-map MSE, RMSprop, PCKh'

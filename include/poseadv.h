@@ -282,14 +282,29 @@ int pa_net_lowres_timing(pa_net* net, long long* counters);
  * in-kernel barriers); 0 (default): the chain of per-layer launches.  Same results up to summation order. */
 int pa_net_set_fused_lowres(pa_net* net, int on);
 /* Per-launch HIP-event timing of the MFMA kernels on the net's stream (bench.py's `roofline`).
- * begin: start recording; report: synchronise, fill out[8][4] = {total ms, launches, algorithmic
- * bytes, flops} for the classes 0 fwd 1x1, 1 fwd 3x3, 2 dgrad 1x1, 3 dgrad 3x3, 4 wgrad 1x1,
- * 5 wgrad 3x3, 6 stem fwd, 7 stem wgrad, and stop recording.  out is a HOST array. */
+ * begin: start recording; report: synchronise, stop recording and fill out_host[c][4] = {total ms, launches, algorithmic
+ * bytes, flops} for the classes c = 0 fwd 1x1, 1 fwd 3x3, 2 dgrad 1x1, 3 dgrad 3x3, 4 wgrad 1x1, 5 wgrad 3x3, 6 stem fwd,
+ * 7 stem wgrad, 8 fused low-resolution forward launch (pa_net_set_fused_lowres).  out_host is a HOST array of `cap_classes`
+ * rows; classes beyond the capacity are dropped (never written).  Returns the library's number of classes (PA_PROF_CLASSES = 9
+ * today) through *n_classes when it is not NULL. */
+#define PA_PROF_CLASSES 9
 int pa_net_profile_begin(pa_net* net);
-int pa_net_profile_report(pa_net* net, double* out_host);
-/* class (0..7 as above) of every timed launch of the last reported pass, in launch order: returns their number and fills
+int pa_net_profile_report(pa_net* net, double* out_host, int cap_classes, int* n_classes);
+/* class (0..8 as above) of every timed launch of the last reported pass, in launch order: returns their number and fills
  * out_host[0..min(cap, n)) (HOST array).  tools/trace_classes.py matches a rocprofv3 kernel trace of the same pass with it. */
 int pa_net_profile_classes(const pa_net* net, int32_t* out_host, int cap);
+/* Bytes THIS design moves per step, from the engine's own launch table (bench.py's `roofline.design_bytes_per_step`): every operand
+ * a launch of the last forward + backward pass reads or writes, counted once per launch at its storage width -- activations, the
+ * second operand of a BatchNorm-backward load, reference tensors of the masked epilogues, shortcut addends, stored dz tensors, fp32
+ * weight-gradient slabs written and read back, weights; halo re-reads and cache hits are NOT modelled (it is a floor for this set
+ * of fusions, above the "every activation once" figure of SURVEY.md section 8d).  out_host[0] = bytes read, [1] = bytes written. */
+int pa_net_design_bytes(const pa_net* net, double* out_host);
+/* Micro-benchmark of ONE convolution launch (tools/bench_conv*.py; no reference counterpart): mode 0 forward, 1 data gradient,
+ * 2 weight gradient; variant bits: 1 input transform (BatchNorm+ReLU / BatchNorm backward on load), 2 statistics / masked epilogue,
+ * 4 one residual addend, 8 (weight gradient) BatchNorm+ReLU on the x operand, 16: cold protocol is the caller's business.  `ws` =
+ * caller-provided device workspace (>= 1 GiB for the benchmark's shapes); *ms_out = average milliseconds per launch over `iters`
+ * launches (HIP events on `stream`). */
+int pa_conv2d_time(int mode, int variant, int B, int Cin, int Cout, int H, int W, int k, int iters, void* ws, float* ms_out, void* stream);
 
 /* The engine enqueues independent branches (hourglass skip blocks, weight gradients) on internal side
  * streams that fork from / join into the caller's stream by events.  on = 0 serialises everything on

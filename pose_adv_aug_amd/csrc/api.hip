@@ -559,8 +559,6 @@ int pa_hg_pckh(pa_net* net, int stack, const float* center, const float* scale, 
 }
 
 // per-launch HIP-event timing of the MFMA kernels (bench.py roofline): enable, run steps, then report.
-// out[8][4] = {total ms, launches, algorithmic bytes, flops} per class: 0 fwd 1x1, 1 fwd 3x3, 2 dgrad 1x1,
-// 3 dgrad 3x3, 4 wgrad 1x1, 5 wgrad 3x3, 6 stem fwd, 7 stem wgrad.  Reporting synchronises and disables.
 int pa_net_set_fused_lowres(pa_net* net, int on) {
     Net& n = net->n;
     n.fused_low = on != 0;
@@ -570,12 +568,18 @@ int pa_net_set_fused_lowres(pa_net* net, int on) {
 }
 int pa_net_lowres_timing(pa_net* net, long long* counters) { net->n.lr_timing = counters; return 0; }
 int pa_net_profile_begin(pa_net* net) { net->n.prof.used = 0; net->n.prof.on = true; return 0; }
-int pa_net_profile_report(pa_net* net, double* out) {
+// out[cap_classes][4] = {total ms, launches, algorithmic bytes, flops} per class (include/poseadv.h).  Reporting synchronises and disables.
+int pa_net_profile_report(pa_net* net, double* out, int cap_classes, int* n_classes) {
     net->n.prof.on = false;
-    int r = net->n.prof.report(out);
-    if (r) pa_set_error("profile report", (hipError_t)r, __FILE__, __LINE__);
-    return r;
+    double full[PA_PROF_NCLS * 4];
+    int r = net->n.prof.report(full);
+    if (r) { pa_set_error("profile report", (hipError_t)r, __FILE__, __LINE__); return r; }
+    for (int c = 0; c < PA_PROF_NCLS && c < cap_classes; ++c)
+        for (int j = 0; j < 4; ++j) out[c * 4 + j] = full[c * 4 + j];
+    if (n_classes) *n_classes = PA_PROF_NCLS;
+    return 0;
 }
+int pa_net_design_bytes(const pa_net* net, double* out) { out[0] = net->n.dbytes_rd; out[1] = net->n.dbytes_wr; return 0; }
 
 int pa_net_profile_classes(const pa_net* net, int32_t* out, int cap) {
     const std::vector<int>& q = net->n.prof.last_seq;

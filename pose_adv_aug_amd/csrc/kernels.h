@@ -107,13 +107,14 @@ struct LrOp {
 struct LrLaunch {
     float2* rows;              // [2][B][256] 16-byte granules {sum, tag, sum of squares, tag}: partial statistics rows (scratch, 2 MB)
     unsigned launch_id;        // unique per launch that shares `rows` (tags of an earlier launch must never match)
-    unsigned* counter;         // (unused)
+    unsigned* counter;         // (unused: the tagged granules are the barrier)
     float batch;               // B
     float momentum, eps;
     int update_running;
     long long* timing;         // tuning aid (normally null): 24 cycle counters, see lowres_fused.hip
 };
 int pa_launch_lowres_fwd(const LrOp* ops_dev, int nops, const LrLaunch& L, int B, int chan, hipStream_t st);
+int pa_lowres_max_batch(int chan);      // workgroups (= images) of the fused launch the current device holds at once; larger batches take the launch chain
 
 // ---- optimizer / weight preparation
 int pa_launch_rmsprop(float* p, const float* g, float* v, size_t n, float lr, float alpha, float eps, float gscale, hipStream_t st);

@@ -9,9 +9,12 @@
 //
 // (9 residual blocks = 27 convolutions, 2 max pools, 2 upsample-adds).  Convolution, pooling and upsampling never cross an
 // image, so all activations stay with their workgroup; ONLY the training-mode BatchNorm statistics couple the images: after
-// each convolution every workgroup publishes its per-channel partial sums (device-scope write-through stores), arrives at a
-// counter barrier (one device-scope atomic per workgroup, relaxed polling by one lane), sums the G partial rows in a fixed
-// order -- every workgroup gets the same bits, run to run -- and finalizes scale / shift itself.
+// each convolution every workgroup publishes its per-channel partial sums as tagged 16-byte granules {sum, tag, sum of squares,
+// tag} (one device-scope write-through store each; tag = launch * 64 + epoch, two row sets alternate), polls the granules of
+// the whole batch with device-scope loads until every tag matches -- the data IS the barrier: no arrival counter, no atomics --
+// sums the G partial rows in a fixed order (every workgroup gets the same bits, run to run) and finalizes scale / shift itself.
+// The exchange needs every workgroup of the launch RESIDENT at once: the launcher refuses a batch larger than what the device
+// can hold (occupancy query x compute units), and a poll that does not complete traps instead of continuing with stale rows.
 //
 // Inside a residual block the two inner tensors never come back from memory: conv1's raw output x1 stays in LDS (buffer V),
 // is normalised IN PLACE once its statistics are final and is conv2's B operand; the same for x2 (buffer U) and conv3.  Both
@@ -454,14 +457,17 @@ __device__ __forceinline__ void lr_bn_sync(LrSmem& sm, const LrOp& op, const LrL
 #pragma unroll
             for (int u = 0; u < 6; ++u) { const int r = r0 + u * Q; p[u] = rows + (size_t)(r < G ? r : r0) * 256 + c; n += r < G; }
             u32x4 g[6];
-            for (unsigned spin = 0; spin < (1u << 22); ++spin) {   // (bounded: a lost workgroup must not hang the device)
+            bool all = false;
+            for (unsigned spin = 0; spin < (1u << 22) && !all; ++spin) {   // (bounded: a lost workgroup must not hang the device)
                 lr_load_granules6(p[0], p[1], p[2], p[3], p[4], p[5], g);
-                bool all = true;
+                all = true;
 #pragma unroll
                 for (int u = 0; u < 6; ++u) all = all && g[u][1] == tag && g[u][3] == tag;
-                if (all) break;
-                __builtin_amdgcn_s_sleep(2);
+                if (!all) __builtin_amdgcn_s_sleep(2);
             }
+            // a row that never arrived (a workgroup of the launch is not resident, or died): abort the launch -- the host sees a HIP
+            // error at its next synchronisation -- rather than finalize statistics from granules of another epoch
+            if (!all) __builtin_trap();
 #pragma unroll
             for (int u = 0; u < 6; ++u) if (u < n) { a += __uint_as_float(g[u][0]); s += __uint_as_float(g[u][2]); }
         }
@@ -622,11 +628,29 @@ __global__ __launch_bounds__(LR_THREADS, 1) void lowres_fwd_kernel(const LrOp* o
     }
 }
 
+// workgroups of the fused kernel the current device can hold at once (0: query failed): the in-kernel statistics exchange polls
+// rows of EVERY workgroup of the launch, so all of them must be co-resident (one per CU: 145 KB of LDS, 512 threads)
+int pa_lowres_max_batch(int chan) {
+    static int cached[2] = {-1, -1};
+    const int i = chan == 256 ? 0 : 1;
+    if (cached[i] >= 0) return cached[i];
+    int dev = 0, per_cu = 0, cus = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (e == hipSuccess)
+        e = chan == 256 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lowres_fwd_kernel<4>, LR_THREADS, 0)
+                        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lowres_fwd_kernel<2>, LR_THREADS, 0);
+    cached[i] = e == hipSuccess ? per_cu * cus : 0;
+    return cached[i];
+}
+
 int pa_launch_lowres_fwd(const LrOp* ops_dev, int nops, const LrLaunch& L, int B, int chan, hipStream_t st) {
-    if (B < 1 || B > 256) { pa_set_error_msg("pa_launch_lowres_fwd: one workgroup per image, 1 <= B <= 256"); return 1; }
+    if (chan != 256 && chan != 128) { pa_set_error_msg("pa_launch_lowres_fwd: chan 128 or 256"); return 1; }
+    // one workgroup per image and ALL of them resident (the BatchNorm exchange polls every row); 256 = rows of the granule buffer
+    const int cap = pa_lowres_max_batch(chan);
+    if (B < 1 || B > 256 || B > cap) { pa_set_error_msg("pa_launch_lowres_fwd: batch exceeds the workgroups this device holds at once (or 256)"); return 1; }
     if (nops > 48) { pa_set_error_msg("pa_launch_lowres_fwd: program too long"); return 1; }
     if (chan == 256) hipLaunchKernelGGL(lowres_fwd_kernel<4>, dim3(B), dim3(LR_THREADS), 0, st, ops_dev, nops, L);
-    else if (chan == 128) hipLaunchKernelGGL(lowres_fwd_kernel<2>, dim3(B), dim3(LR_THREADS), 0, st, ops_dev, nops, L);
-    else { pa_set_error_msg("pa_launch_lowres_fwd: chan 128 or 256"); return 1; }
+    else hipLaunchKernelGGL(lowres_fwd_kernel<2>, dim3(B), dim3(LR_THREADS), 0, st, ops_dev, nops, L);
     return (int)hipGetLastError();
 }

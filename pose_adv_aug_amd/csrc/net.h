@@ -145,7 +145,8 @@ struct Net {
     unsigned lr_launches = 0;                   // tag of the fused launches' statistics granules
     long long* lr_timing = nullptr;             // tuning aid: 24 cycle counters of the fused kernel's phases (pa_net_lowres_timing)
     bool fused_low = false;                     // opt-in (pa_net_set_fused_lowres): measured break-even with the launch chain, DESIGN.md
-    bool fused_low_ok() const { return fused_low && !is_agent && train_bn && !drop_mask && (chan == 256 || chan == 128) && res == 256 && B >= 1 && B <= 256 && lr_rows != nullptr; }
+    // (a batch the device cannot hold as co-resident workgroups takes the launch chain: the in-kernel statistics exchange needs them all at once)
+    bool fused_low_ok() const { return fused_low && !is_agent && train_bn && !drop_mask && (chan == 256 || chan == 128) && res == 256 && B >= 1 && B <= 256 && B <= pa_lowres_max_batch(chan) && lr_rows != nullptr; }
     // run state
     hipStream_t st = nullptr;
     // side streams: the skip branch of hourglass level k runs on side[k] next to the low-resolution path
@@ -184,6 +185,10 @@ struct Net {
     int record_join(int k);                    // mark the end of the work enqueued on side[k]
     int wait_join(int k);                      // st waits for that mark
     Prof prof;
+    // bytes this design moves (pa_net_design_bytes): operands of every launch since begin_step(), counted once per launch
+    double dbytes_rd = 0, dbytes_wr = 0;
+    static double opb(const PaOperand& o, double elems) { return o.mode == PA_LD_NONE ? 0.0 : (o.mode == PA_LD_LIN2 ? 4.0 : 2.0) * elems; }
+    void cnt(double rd, double wr) { dbytes_rd += rd; dbytes_wr += wr; }
     // forward + loss + backward of the training step captured ONCE into a HIP graph (fork / join events of the side and
     // weight-gradient streams become graph edges) and replayed: pa_hg_train_step with use_graph
     hipGraph_t step_graph = nullptr; hipGraphExec_t step_exec = nullptr; int step_key = -1;

@@ -446,6 +446,8 @@ int Net::conv_fwd(ConvLayer& c, const PaOperand& in, int B_, int H, int W, const
     double wb, wf; conv_work(B_ * H * W, c.k == 7 ? 147 : c.Cin, c.Cout, c.k == 7 ? 1 : c.taps(), false, wb, wf);
     if (c.k == 7) wb = 2.0 * B_ * (4.0 * H * W * 4 + (double)H * W * 64) + 2.0 * 64 * 147;      // image read once (4-ch padded) + output
     if ((ablate() & 128) && H <= ablate_h()) return 0;
+    { const double M = (double)B_ * H * W;
+      cnt((c.k == 7 ? 2.0 * B_ * 4.0 * H * W * 4 : opb(in, M * a.Cin)) + opb(add1, M * a.Cout) + opb(add2, M * a.Cout) + 2.0 * a.Cout * a.taps * a.Cin, 2.0 * M * a.Cout); }
     ProfEntry* pe = prof.begin(c.k == 7 ? PA_PROF_STEM_FWD : (c.k == 3 ? PA_PROF_FWD3 : PA_PROF_FWD1), wb, wf, st);
     int rc = (c.k == 3 && (ablate() & 8)) ? 0 : ((c.k == 7) ? pa_launch_stem_conv(a, st) : pa_launch_conv(a, st));
     prof.end(pe, st);
@@ -473,6 +475,9 @@ int Net::conv_dgrad(ConvLayer& c, const PaOperand& dy, int B_, int H, int W, con
     double wb, wf; conv_work(B_ * H * W, c.Cin, c.Cout, c.taps(), false, wb, wf);
     ProfEntry* pe = prof.begin(c.k == 3 ? PA_PROF_DGRAD3 : PA_PROF_DGRAD1, wb, wf, st);
     if ((c.k == 3 && (ablate() & 8)) || (c.k == 1 && (ablate() & 16)) || ((ablate() & 256) && H <= ablate_h())) { if (a.ep.rows_out) *a.ep.rows_out = 1; prof.end(pe, st); return 0; }
+    { const double M = (double)B_ * H * W;
+      cnt(opb(dy, M * a.Cin) + opb(add1, M * a.Cout) + opb(add2, M * a.Cout) + (ep.mode == PA_OUT_BWD ? 2.0 * M * a.Cout : 0.0) + 2.0 * a.Cout * a.taps * a.Cin,
+          2.0 * M * a.Cout + (a.dz_out ? 2.0 * M * a.Cin : 0.0)); }
     int rc = pa_launch_conv(a, st);
     prof.end(pe, st);
     return rc;
@@ -489,6 +494,8 @@ int Net::conv_wgrad(ConvLayer& c, const PaOperand& dy, const PaOperand& x, int B
     if ((ablate() & 32) && c.k == 1 && (long)B_ * H * W >= 16384) return 0;      // timing bound: what fusing the large 1x1 weight gradients into their data gradients could save at most
     if ((ablate() & 64) && c.k == 3 && (long)B_ * H * W >= 16384) return 0;
     if ((ablate() & 512) && H <= ablate_h()) return 0;
+    { const double M = (double)B_ * H * W, slab = 4.0 * (double)c.splits * a.Cout * a.taps * a.Cin;      // slabs written, read back by the reducer, gradient written
+      cnt((c.k == 7 ? 2.0 * B_ * 4.0 * H * W * 4 : opb(x, M * a.Cin)) + opb(dy, M * a.Cout) + slab, slab + 4.0 * a.Cout * a.taps * a.Cin); }
     if (multi_stream && wstream) {        // deferred: flush_wgrads() launches it on the weight-gradient stream
         PendingWgrad p; p.a = a; p.cls = cls; p.bytes = wb; p.flops = wf; p.stem = c.k == 7; p.c = &c;
         pending_wgrads.push_back(p);
@@ -564,6 +571,35 @@ int Net::flush_wgrads() {
     return 0;
 }
 
+// the streaming launches with their operand bytes counted (Net::cnt, pa_net_design_bytes)
+static int c_maxpool_fwd(Net& n, const PaOperand& in, bf16* out, int B, int H, int W, int C, hipStream_t st) {
+    const double e = (double)B * H * W * C; n.cnt(Net::opb(in, e), 2.0 * e / 4);
+    return pa_launch_maxpool_fwd(in, out, B, H, W, C, st);
+}
+static int c_maxpool_bwd(Net& n, const bf16* dout, const PaOperand& in, const PaOperand& add, const PaEpilogue& ep, bf16* din, int B, int H, int W, int C,
+                         hipStream_t st, int* rows = nullptr) {
+    const double e = (double)B * H * W * C; n.cnt(2.0 * e / 4 + Net::opb(in, e) + Net::opb(add, e) + (ep.mode == PA_OUT_BWD ? 2.0 * e : 0.0), 2.0 * e);
+    return pa_launch_maxpool_bwd(dout, in, add, ep, din, B, H, W, C, st, rows);
+}
+static int c_upadd_fwd(Net& n, const PaOperand& low, const PaOperand& skip, bf16* out, int B, int H, int W, int C, hipStream_t st) {
+    const double e = (double)B * H * W * C; n.cnt(Net::opb(low, e / 4) + Net::opb(skip, e), 2.0 * e);
+    return pa_launch_upadd_fwd(low, skip, out, B, H, W, C, st);
+}
+static int c_upadd_bwd(Net& n, const bf16* dout, const PaEpilogue& ep_low, bf16* dlow, const PaEpilogue& ep_skip, bf16* dskip, int B, int H, int W, int C,
+                       hipStream_t st, int* rows = nullptr) {
+    const double e = (double)B * H * W * C;
+    n.cnt(2.0 * e + (ep_low.mode == PA_OUT_BWD ? 2.0 * e / 4 : 0.0) + (ep_skip.mode == PA_OUT_BWD ? 2.0 * e : 0.0), 2.0 * e / 4 + 2.0 * e);
+    return pa_launch_upadd_bwd(dout, ep_low, dlow, ep_skip, dskip, B, H, W, C, st, rows);
+}
+template <class... A> static int c_head_fwd(Net& n, const PaOperand& x, A... rest) {
+    const double M = (double)n.B * (n.res / 4) * (n.res / 4); n.cnt(Net::opb(x, M * n.chan) + 2.0 * 16 * n.chan, M * 16 * 4 + M * 64 * 2);
+    return pa_launch_head_fwd(x, rest...);
+}
+template <class... A> static int c_heat_grad(Net& n, const float* heat, const double* pts, const bf16* din, A... rest) {
+    const double M = (double)n.B * (n.res / 4) * (n.res / 4); n.cnt(M * 16 * 4 + (din ? M * 64 * 2 : 0.0), M * 64 * 2);
+    return pa_launch_heat_grad(heat, pts, din, rest...);
+}
+
 // ------------------------------------------------------------------------------------------------
 // residual block (reference :30-49): x1 = conv1(a), x2 = conv3x3(relu bn1 x1), x3 = conv3(relu bn2 x2) + shortcut
 int Residual::fwd(Net& n, const Act& in) {
@@ -636,7 +672,7 @@ int Hourglass::encode(Net& n, const Act& in, bool fused) {
     const Act* cur = &in;
     for (int k = 0; k < 4; ++k) {
         if (fused && k == 2) {                              // down[1] ... up[1] in one launch (the level-1 skip branch is already forked)
-            TRY(pa_launch_maxpool_fwd(n.op(*cur), pooled[1].raw, cur->B, cur->H, cur->W, cur->C, n.st));
+            TRY(c_maxpool_fwd(n, n.op(*cur), pooled[1].raw, cur->B, cur->H, cur->W, cur->C, n.st));
             return lowres_fwd(n);
         }
         auto skip_branch = [&]() -> int {
@@ -652,7 +688,7 @@ int Hourglass::encode(Net& n, const Act& in, bool fused) {
             TRY(skip_branch());
         }
         if (fused && k == 1) { cur = &down[0].x3; continue; }     // (its pooling and down[1] belong to the fused launch)
-        TRY(pa_launch_maxpool_fwd(n.op(*cur), pooled[k].raw, cur->B, cur->H, cur->W, cur->C, n.st));
+        TRY(c_maxpool_fwd(n, n.op(*cur), pooled[k].raw, cur->B, cur->H, cur->W, cur->C, n.st));
         TRY(down[k].fwd(n, pooled[k]));
         cur = &down[k].x3;
     }
@@ -671,7 +707,7 @@ int Hourglass::decode(Net& n, bool fused) {
         if (fused && k >= 2) continue;
         const Act& m = merged[k];
         if (n.forks(k)) TRY(n.wait_join(k));
-        TRY(pa_launch_upadd_fwd(n.op(up[k].x3), n.op(n.drop_mask ? skipm[k] : skip[k].x3), m.raw, m.B, m.H, m.W, m.C, n.st));
+        TRY(c_upadd_fwd(n, n.op(up[k].x3), n.op(n.drop_mask ? skipm[k] : skip[k].x3), m.raw, m.B, m.H, m.W, m.C, n.st));
         low = &merged[k];
     }
     return 0;
@@ -685,10 +721,10 @@ int Hourglass::bwd(Net& n, const Act& in, const PaOperand& extra0) {
         if (k == n.hold_level) TRY(n.release_held(k));
         const Act& m = merged[k];
         if (n.drop_mask) {              // the skip tensor entered the sum through the cell mask: d skip = mask * d (masked skip)
-            TRY(pa_launch_upadd_bwd(m.grad, n.final_ep(up[k].x3), up[k].x3.grad, ep_plain(), skipm[k].grad, m.B, m.H, m.W, m.C, n.st));
+            TRY(c_upadd_bwd(n, m.grad, n.final_ep(up[k].x3), up[k].x3.grad, ep_plain(), skipm[k].grad, m.B, m.H, m.W, m.C, n.st));
             TRY(pa_launch_cell_mask(pa_plain(skipm[k].grad), n.drop_mask, n.final_ep(skip[k].x3), skip[k].x3.grad, m.B, m.H, m.W, m.C, n.st));
         } else {
-            TRY(pa_launch_upadd_bwd(m.grad, n.final_ep(up[k].x3), up[k].x3.grad, n.final_ep(skip[k].x3), skip[k].x3.grad,
+            TRY(c_upadd_bwd(n, m.grad, n.final_ep(up[k].x3), up[k].x3.grad, n.final_ep(skip[k].x3), skip[k].x3.grad,
                                     m.B, m.H, m.W, m.C, n.st));
         }
         TRY(n.finish_grad2(up[k].x3, skip[k].x3));
@@ -712,7 +748,7 @@ int Hourglass::bwd(Net& n, const Act& in, const PaOperand& extra0) {
     for (int k = 3; k >= 0; --k) {
         TRY(down[k].bwd(n, pooled[k], pa_none(), true));
         const Act& x = (k == 0) ? in : down[k - 1].x3;
-        TRY(pa_launch_maxpool_bwd(pooled[k].grad, n.op(x), (k == 0) ? extra0 : pa_none(), ep_plain(), poolgrad[k],
+        TRY(c_maxpool_bwd(n, pooled[k].grad, n.op(x), (k == 0) ? extra0 : pa_none(), ep_plain(), poolgrad[k],
                                   x.B, x.H, x.W, x.C, n.st));
         if (n.forks(k)) {
             TRY(n.wait_join(k));
@@ -791,6 +827,7 @@ int Net::wait_join(int k) { if (nosync() && (g_nosync & 2)) return 0; PA_CHECK(h
 int Net::prepare_weights() { return pa_launch_weight_prep(prep_jobs, n_prep, prep_max, st); }
 
 int Net::begin_step() {
+    dbytes_rd = dbytes_wr = 0;
     PA_CHECK(hipMemsetAsync(stats_arena, 0, stats_arena_floats * sizeof(float), st));
     return 0;
 }
@@ -818,7 +855,7 @@ int Net::forward_pose(const float* img_nchw, const bf16* img4_in, const double* 
     if (pts && pts != pts_dev) PA_CHECK(hipMemcpyAsync(pts_dev, pts, (size_t)B * classes * 2 * sizeof(double), hipMemcpyDeviceToDevice, st));
     TRY(conv_fwd(stem_conv, pa_plain(image), B, res / 2, res / 2, pa_none(), pa_none(), a0.raw, &stem_bn));
     TRY(res1.fwd(*this, a0));
-    TRY(pa_launch_maxpool_fwd(op(res1.x3), pool0.raw, B, res / 2, res / 2, 128, st));
+    TRY(c_maxpool_fwd(*this, op(res1.x3), pool0.raw, B, res / 2, res / 2, 128, st));
     TRY(res2.fwd(*this, pool0));
     TRY(res3.fwd(*this, res2.x3));
     const int Hh = res / 4;
@@ -828,7 +865,7 @@ int Net::forward_pose(const float* img_nchw, const bf16* img4_in, const double* 
         TRY(hg[i].decode(*this, fused));
         TRY(post[i].fwd(*this, hg[i].out()));
         TRY(conv_fwd(lin[i], op(post[i].x3), B, Hh, Hh, pa_none(), pa_none(), lin_out[i].raw, &lin_bn[i]));
-        TRY(pa_launch_head_fwd(op(lin_out[i]), outc[i].wf, params + outc[i].p_b, heat[i], heat64[i], pts ? pts_dev : nullptr,
+        TRY(c_head_fwd(*this, op(lin_out[i]), outc[i].wf, params + outc[i].p_b, heat[i], heat64[i], pts ? pts_dev : nullptr,
                                pts ? loss_dev + i : nullptr, B, Hh, Hh, chan, st));
         if (i + 1 < stacks) {
             TRY(conv_fwd(forth[i], op(lin_out[i]), B, Hh, Hh, op(xin[i]), pa_none(), forth_tmp[i], nullptr));
@@ -850,7 +887,7 @@ int Net::backward_stack(int i) {
         TRY(conv_dgrad(inc[i], gx, B, Hh, Hh, pa_none(), pa_none(), ep_plain(), dheat_in[i]));
         TRY(conv_wgrad(forth[i], gx, op(lin_out[i]), B, Hh, Hh));
     }
-    TRY(pa_launch_heat_grad(heat[i], pts_dev, inner ? dheat_in[i] : nullptr, dheat64[i], gscale, B, Hh, Hh, st));
+    TRY(c_heat_grad(*this, heat[i], pts_dev, inner ? dheat_in[i] : nullptr, dheat64[i], gscale, B, Hh, Hh, st));
     const PaOperand gh = pa_plain(dheat64[i]);
     TRY(conv_wgrad(outc[i], gh, op(lin_out[i]), B, Hh, Hh));
     if (inner) {
@@ -877,7 +914,7 @@ int Net::backward_stem() {
     TRY(res3.bwd(*this, res2.x3, pa_none(), true));
     TRY(finish_grad(res2.x3));
     TRY(res2.bwd(*this, pool0, pa_none(), true));
-    TRY(pa_launch_maxpool_bwd(pool0.grad, op(res1.x3), pa_none(), final_ep(res1.x3), res1.x3.grad, B, res / 2, res / 2, 128, st));
+    TRY(c_maxpool_bwd(*this, pool0.grad, op(res1.x3), pa_none(), final_ep(res1.x3), res1.x3.grad, B, res / 2, res / 2, 128, st));
     TRY(finish_grad(res1.x3));
     TRY(res1.bwd(*this, a0, pa_none(), true));
     TRY(finish_grad(a0));

@@ -7,13 +7,16 @@ import pytest
 import torch
 import torch.multiprocessing as mp
 
-from tests._rendezvous import file_init_method, set_env
+from tests._rendezvous import engine_rank_env, file_init_method, set_env
 
 pytestmark = pytest.mark.gpu
 
+if os.environ.get('POSEADV_TEST_DIST_BACKEND') == 'nccl' and torch.cuda.device_count() < 2:
+    pytestmark = [pytest.mark.gpu, pytest.mark.skip(reason='two ranks over RCCL need two GPUs (a GPU holds one RCCL rank)')]
+
 
 def _worker(rank, world, init, out, overlap=False, stacks=1):
-    set_env(rank, world, init, local_rank=0, POSEADV_DIST_BACKEND='gloo')
+    set_env(rank, world, init, **engine_rank_env(rank))
     import torch.distributed as dist
     from pose_adv_aug_amd.stack_hg import init_distributed, broadcast_parameters, train_step
     from pose_adv_aug_amd.models.asn_stacked_hg import create_hg
@@ -106,7 +109,7 @@ def test_overlapped_gradient_exchange_gives_the_same_result():
 
 def _joint_worker(rank, world, init, exp_dir, out):
     """joint_train_pose_s_r_agent.main() on `world` ranks with the REAL engine (both on the one GPU, gloo collectives)."""
-    set_env(rank, world, init, local_rank=0, POSEADV_DIST_BACKEND='gloo')
+    set_env(rank, world, init, **engine_rank_env(rank))
     import torch.distributed as dist
     from pose_adv_aug_amd import joint_train_pose_s_r_agent as J
     from pose_adv_aug_amd.models import asn_stacked_hg as M
@@ -184,7 +187,7 @@ def test_bench_line_from_two_ranks(overlap):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
-    env = dict(os.environ, POSEADV_DIST_BACKEND='gloo')
+    env = dict(os.environ, POSEADV_DIST_BACKEND=os.environ.get('POSEADV_TEST_DIST_BACKEND', 'gloo'))
     for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT', 'POSEADV_DIST_INIT', 'POSEADV_FORCE_DIST'):
         env.pop(k, None)
     r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
@@ -197,3 +200,22 @@ def test_bench_line_from_two_ranks(overlap):
     assert d['n_gpus'] == 2 and d['steps'] == 3 and d['scaling'] == 'weak' and d['value'] > 0
     assert d['config']['global_batch'] == 48 and d['config']['parallelism'] == ('dp2+overlapped-exchange' if overlap else 'dp2')
     assert d['pckh_parity']['match'] is True and d['roofline']['frac'] > 0 and d['cpu_baseline'] is None
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` as a PLAIN command (no torch.distributed.run, no WORLD_SIZE in the environment): bench.py starts its
+    two ranks itself over a file-store rendezvous (bench.self_launch) -- what the driver's multi-GPU scaling run invokes."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, POSEADV_DIST_BACKEND=os.environ.get('POSEADV_TEST_DIST_BACKEND', 'gloo'))
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT', 'POSEADV_DIST_INIT', 'POSEADV_FORCE_DIST'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--no-cpu-baseline',
+                        '--no-traffic'], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['config']['global_batch'] == 48 and d['config']['parallelism'] == 'dp2' and d['value'] > 0

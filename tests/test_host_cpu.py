@@ -259,3 +259,18 @@ def test_summary_logger_format_and_resume(tmp_path):
     assert open(p).read().count('\n') == 3
     with pytest.raises(ValueError):
         l2 = Logger(str(tmp_path / 'x.txt')); l2.set_names(['a']); l2.append([1, 2])
+
+
+def test_bench_self_launch_propagates_a_failing_rank():
+    """bench.py --gpus 2 without a launcher starts its own ranks; on this GPU-less box both ranks fail loudly (no CPU fallback) and the
+    launcher returns non-zero instead of hanging or printing a line."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if __import__('torch').cuda.is_available():
+        pytest.skip('GPU present: covered by tests/test_gpu_dist.py::test_bench_launches_its_own_ranks')
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'POSEADV_DIST_INIT')}
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'], cwd=root, env=env,
+                       capture_output=True, text=True, timeout=240)
+    assert r.returncode != 0
+    assert not [l for l in r.stdout.splitlines() if l.startswith('{')]
