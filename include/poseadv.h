@@ -293,6 +293,11 @@ int pa_net_profile_report(pa_net* net, double* out_host, int cap_classes, int* n
 /* class (0..8 as above) of every timed launch of the last reported pass, in launch order: returns their number and fills
  * out_host[0..min(cap, n)) (HOST array).  tools/trace_classes.py matches a rocprofv3 kernel trace of the same pass with it. */
 int pa_net_profile_classes(const pa_net* net, int32_t* out_host, int cap);
+/* BatchNorm finalize (models/asn_stacked_hg.py:19,22,25 in training mode) of a residual block's inner tensors at the low-resolution
+ * levels: with at most `max_rows` partial statistics rows (default and upper limit 128: the 16 x 16 and smaller maps at batch 24) the
+ * consumer convolution computes scale / shift (forward) or the BatchNorm-backward coefficients (backward) in its own prologue instead
+ * of a finalize launch in front of it; 0 = always a launch.  Results are bit-identical either way (one summation order). */
+int pa_net_set_fin_prologue(pa_net* net, int max_rows);
 /* Bytes THIS design moves per step, from the engine's own launch table (bench.py's `roofline.design_bytes_per_step`): every operand
  * a launch of the last forward + backward pass reads or writes, counted once per launch at its storage width -- activations, the
  * second operand of a BatchNorm-backward load, reference tensors of the masked epilogues, shortcut addends, stored dz tensors, fp32

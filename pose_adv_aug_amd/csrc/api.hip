@@ -579,6 +579,11 @@ int pa_net_profile_report(pa_net* net, double* out, int cap_classes, int* n_clas
     if (n_classes) *n_classes = PA_PROF_NCLS;
     return 0;
 }
+int pa_net_set_fin_prologue(pa_net* net, int max_rows) {
+    net->n.fin_rows_max = max_rows < 0 ? 0 : (max_rows > PA_FIN_SMALL_ROWS ? PA_FIN_SMALL_ROWS : max_rows);
+    net->n.release_graph();
+    return 0;
+}
 int pa_net_design_bytes(const pa_net* net, double* out) { out[0] = net->n.dbytes_rd; out[1] = net->n.dbytes_wr; return 0; }
 
 int pa_net_profile_classes(const pa_net* net, int32_t* out, int cap) {

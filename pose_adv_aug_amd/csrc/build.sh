@@ -8,7 +8,7 @@ SRCS="conv_igemm conv3x3_tile conv1x1_tile conv_wgrad conv_wgrad_tile lowres_fus
 build_variant() {      # $1 = object directory, $2 = extra flags, $3 = library name
   local dir=$1 flags=$2 lib=$3
   mkdir -p $dir
-  if [ -n "$PA_TUNING" ]; then flags="$flags -DPA_TUNING $PA_EXTRA"; fi
+  if [ -n "$PA_TUNING" ]; then flags="$flags -DPA_TUNING ${PA_EXTRA:-}"; fi
   if [ "$(cat $dir/.flags 2>/dev/null)" != "$flags" ]; then rm -f $dir/*.o; echo "$flags" > $dir/.flags; fi
   local objs=""
   for f in $SRCS; do
@@ -29,4 +29,6 @@ build_variant ../build_fp16 "-DPA_FP16" libposeadv_hip_fp16.so &
 P2=$!
 wait $P1; R1=$?
 wait $P2; R2=$?
+[ $R1 -eq 0 ] || echo "build.sh: the bf16 variant (libposeadv_hip.so) FAILED (rc $R1)" >&2
+[ $R2 -eq 0 ] || echo "build.sh: the fp16 variant (libposeadv_hip_fp16.so) FAILED (rc $R2)" >&2
 [ $R1 -eq 0 ] && [ $R2 -eq 0 ]

@@ -52,19 +52,28 @@ template <int N> __device__ __forceinline__ void pa_wait_vmcnt() {
     else static_assert(N == 0, "unsupported vmcnt");
 }
 
-template <int CIN, int BN, int LDMODE, int TW = 16, int TH = 8, int SPS = 1, bool PF = false>
-__global__ __launch_bounds__(256, (TW == 16 ? (TH == 4 ? (SPS == 1 ? 3 : 2) : 2) : 1)) void conv3x3_tile_kernel(PaConvArgs a) {
-    constexpr int BM = (TW == 16 && TH == 4) ? 64 : 128;
-    constexpr int IMG = BM / (TW * TH), PW = TW + 2, PHh = TH + 2, HP = IMG * PHh * PW;   // 180 / 108 / 200 / 288 halo pixels
+// TRI (NT = 512 threads, 16 x 8 tiles): THREE pixel tiles per workgroup = 384 pixels = exactly one CU's share of a 24 x 64 x 64 map.
+// The three tiles share ONE weight ring, so the L2 -> LDS weight stream per pixel is a third (it is what bounds the K loop of the
+// 128-pixel kernel: 295 KB per tile against 3.9 us of MFMA work, two workgroups per CU streaming at once), every K step has 24 MFMAs
+// per wave between two barriers instead of 16, and the launch is ONE full round of 256 workgroups instead of 768 on 512 slots.
+// 8 waves = 4 (pixels: 6 fragments of 16 each) x 2 (channels: 4 fragments); LDS 135 KB of halos + a ring of 3 slices: one workgroup
+// per CU, whose memory phases (staging, epilogue) run as chip-wide bursts.
+template <int CIN, int BN, int LDMODE, int TW = 16, int TH = 8, int SPS = 1, bool PF = false, int NT = 256>
+__global__ __launch_bounds__(NT, (NT == 512 ? 1 : (TW == 16 ? (TH == 4 ? (SPS == 1 ? 3 : 2) : 2) : 1))) void conv3x3_tile_kernel(PaConvArgs a) {
+    constexpr bool TRI = NT == 512;
+    constexpr int NW = NT / 64, WM = NW / 2;                             // waves; waves along the pixels (2 along the channels)
+    constexpr int BM = TRI ? 384 : ((TW == 16 && TH == 4) ? 64 : 128);
+    constexpr int IMG = BM / (TW * TH), PW = TW + 2, PHh = TH + 2, HP = IMG * PHh * PW;   // 180 / 108 / 200 / 288 / 540 halo pixels
     constexpr int CPP = CIN / 8;                                         // 16-byte chunks per pixel
-    constexpr int NI = BN / 32, MI = BM / 32;
+    constexpr int NI = BN / 32, MI = BM / (16 * WM);
     constexpr int NSL = CIN / 32;                                        // 32-channel weight slices per tap
-    constexpr int NIT = 9 * NSL, NIW = BN / 64;                          // slices [BN][32]; glds per wave per slice
+    constexpr int NIT = 9 * NSL, NIW = BN / (16 * NW);                   // slices [BN][32]; glds per wave per slice
     constexpr int NST = NIT / SPS, GPT = NSL / SPS;                      // K-loop steps, steps per tap
-    constexpr int NBUF = SPS == 1 ? (BM == 64 ? 3 : 4) : 3;              // ring of NBUF step buffers [SPS][BN][32]
+    constexpr int NBUF = TRI ? 3 : (SPS == 1 ? (BM == 64 ? 3 : 4) : 3);  // ring of NBUF step buffers [SPS][BN][32]
     constexpr int AHEAD = NBUF - 2;                                      // steps still in flight while one is consumed
     static_assert(NSL % SPS == 0, "a step stays inside one tap");
-    constexpr int PSTEP = 256 / CPP;                                     // halo pixels staged per pass
+    static_assert(!TRI || (TW == 16 && TH == 8 && PF && SPS == 1), "three-tile workgroups: 16 x 8 tiles, pipelined K loop");
+    constexpr int PSTEP = NT / CPP;                                      // halo pixels staged per pass
     constexpr int NPASS = (HP + PSTEP - 1) / PSTEP;
     // ONE shared object (a second one makes hipcc drain vmcnt(0) before every ds_read of the pipeline)
     __shared__ __attribute__((aligned(16))) bf16 lds[HP * CIN + NBUF * SPS * BN * 32];
@@ -73,17 +82,37 @@ __global__ __launch_bounds__(256, (TW == 16 ? (TH == 4 ? (SPS == 1 ? 3 : 2) : 2)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave & 1, wn = wave >> 1;
+    const int wm = wave % WM, wn = wave / WM;
     const int tiles_x = a.W / TW, tiles_y = a.H / TH;
     // consecutive workgroups go to different XCDs (round robin), each with its own L2: give every XCD one contiguous range
     // of tiles so that the halo rows / columns shared by neighbouring tiles are found in that L2
     int t = (a.xcd & 1) ? (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int t0 = t * IMG;                            // TRI: first of the workgroup's three consecutive tiles
     const int tx = t % tiles_x; t /= tiles_x;
     const int ty = t % tiles_y;
-    const int b = (t / tiles_y) * IMG;                 // first image of this workgroup
+    const int b = (t / tiles_y) * IMG;                 // first image of this workgroup (small maps: tile = image)
     const int y0 = ty * TH, x0 = tx * TW;
     const int n0 = blockIdx.y * BN;
     const int K = 9 * CIN;
+    // origin of sub-tile `im` of the workgroup: small maps -- image b + im at (0, 0); TRI -- tile t0 + im of the tile grid
+    // (three wave-uniform origins, selected per lane)
+    int ob[3], oy[3], ox[3];
+    if constexpr (TRI) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            int tt = t0 + j;
+            ox[j] = (tt % tiles_x) * TW; tt /= tiles_x;
+            oy[j] = (tt % tiles_y) * TH;
+            ob[j] = tt / tiles_y;
+        }
+    }
+    auto origin = [&](int im, int& bb, int& yy, int& xx) {
+        if constexpr (TRI) {
+            bb = im == 0 ? ob[0] : (im == 1 ? ob[1] : ob[2]);
+            yy = im == 0 ? oy[0] : (im == 1 ? oy[1] : oy[2]);
+            xx = im == 0 ? ox[0] : (im == 1 ? ox[1] : ox[2]);
+        } else { bb = b + im; yy = y0; xx = x0; }
+    };
 
     // ---- weight slices [BN][32] (64-byte rows): wave w streams LDS rows [w*BN/4, (w+1)*BN/4), one instruction =
     // 16 rows x 4 slots.  Slot swizzle wsw(row) = (-(row >> 2)) & 3: conflict-free for ds_read_b128's lane groups
@@ -91,37 +120,55 @@ __global__ __launch_bounds__(256, (TW == 16 ? (TH == 4 ? (SPS == 1 ? 3 : 2) : 2)
     const bf16* wsrc[NIW];
 #pragma unroll
     for (int i = 0; i < NIW; ++i) {
-        const int lr = wave * (BN / 4) + i * 16 + (lane >> 2);
+        const int lr = wave * (BN / NW) + i * 16 + (lane >> 2);
         const int slot = lane & 3;
         wsrc[i] = a.w + (size_t)(n0 + pa_weight_row_of_lds_row<BN, NI>(lr)) * K + ((slot ^ ((-(lr >> 2)) & 3)) << 3);
     }
+    // tap rotation (a.dbg & 8): workgroup i walks the taps in the order rot, rot + 1, ... (mod 9), rot = i % 9 -- every workgroup of a launch
+    // streams the SAME 295 KB of weights; started together they all pull the same slice from the same L2 channels at the same time
+    const int rot = (a.dbg & 8) ? (int)(blockIdx.x % 9) : 0;
+    auto ptap = [&](int ltap) { const int p = ltap + rot; return p >= 9 ? p - 9 : p; };
     auto issue_w = [&](int st) {                       // step st = slices st*SPS .. st*SPS+SPS-1
 #pragma unroll
         for (int j = 0; j < SPS; ++j) {
-            bf16* dst = wbuf + ((st % NBUF) * SPS + j) * (BN * 32) + wave * (BN / 4) * 32;
+            bf16* dst = wbuf + ((st % NBUF) * SPS + j) * (BN * 32) + wave * (BN / NW) * 32;
+            const int it = st * SPS + j, lt = it / NSL;
+            const int pit = ptap(lt) * NSL + (it - lt * NSL);
 #pragma unroll
             for (int i = 0; i < NIW; ++i)
-                __builtin_amdgcn_global_load_lds(PA_GLOBAL_PTR(wsrc[i] + (st * SPS + j) * 32), PA_LDS_PTR(dst + i * 16 * 32), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds(PA_GLOBAL_PTR(wsrc[i] + pit * 32), PA_LDS_PTR(dst + i * 16 * 32), 16, 0, 0);
         }
     };
     issue_w(0); issue_w(1);
     if (NBUF == 4) issue_w(2);
-    if (PF) issue_w(NBUF - 1);
+    if (PF) issue_w(NBUF - 1);                         // (pipelined K loop: the whole ring is in flight during the staging)
 
     // ---- halo staging (single pass over the input, transform applied here)
-    {
+    if (!(a.dbg & 4)) {
         const int chunk = tid % CPP;                 // the same for every pass of a thread (256 % CPP == 0)
         const int c = chunk * 8;
         float k0[8], k1[8], k2[8];
         if (LDMODE != PA_LD_PLAIN) {
+            if (a.fin.rows > 0) {
+                // the input's BatchNorm finalize from the producer's <= 128 partial rows (bn_fin.h) instead of a launch of its own in
+                // front of this kernel; table + scratch sit in the halo region, which nobody writes before the barrier below
+                float* ktab = reinterpret_cast<float*>(halo);
+                pa_bn_fin_prologue<256, CIN>(a.fin, CIN, ktab, ktab + 3 * CIN, blockIdx.x == 0 && blockIdx.y == 0);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                k0[j] = a.in.k0[c + j]; k1[j] = a.in.k1[c + j];
-                if (LDMODE == PA_LD_LIN2) k2[j] = a.in.k2[c + j];
+                for (int j = 0; j < 8; ++j) {
+                    k0[j] = ktab[c + j]; k1[j] = ktab[CIN + c + j];
+                    if (LDMODE == PA_LD_LIN2) k2[j] = ktab[2 * CIN + c + j];
+                }
+                __syncthreads();
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    k0[j] = a.in.k0[c + j]; k1[j] = a.in.k1[c + j];
+                    if (LDMODE == PA_LD_LIN2) k2[j] = a.in.k2[c + j];
+                }
             }
         }
-        const size_t img = (size_t)b * a.H * a.W;
-        constexpr int UN = LDMODE == PA_LD_LIN2 ? 6 : 12;      // loads in flight per thread before the first transform
+        constexpr int UN = LDMODE == PA_LD_LIN2 ? 6 : (TRI ? 9 : 12);      // loads in flight per thread before the first transform
 #pragma unroll
         for (int p0 = 0; p0 < NPASS; p0 += UN) {
             bf16x8 ra[UN], rq[UN];
@@ -133,10 +180,12 @@ __global__ __launch_bounds__(256, (TW == 16 ? (TH == 4 ? (SPS == 1 ? 3 : 2) : 2)
                 const int im = IMG == 1 ? 0 : hp[u] / (PHh * PW);
                 const int hr = hp[u] - im * (PHh * PW);
                 const int hy = hr / PW, hx = hr - hy * PW;
-                const int y = y0 + hy - 1, x = x0 + hx - 1;
-                ok[u] = hp[u] < HP && b + im < a.B && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
+                int bb, yy, xx;
+                origin(im, bb, yy, xx);
+                const int y = yy + hy - 1, x = xx + hx - 1;
+                ok[u] = hp[u] < HP && bb < a.B && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
                 // unconditional (clamped) loads: a branch around a load makes hipcc wait vmcnt(0) per element
-                const size_t idx = ok[u] ? (img + ((size_t)im * a.H + y) * a.W + x) * CIN + c : 0;
+                const size_t idx = ok[u] ? (((size_t)bb * a.H + y) * a.W + x) * CIN + c : 0;
                 ra[u] = *reinterpret_cast<const bf16x8*>(a.in.p + idx);
                 if (LDMODE == PA_LD_LIN2) rq[u] = *reinterpret_cast<const bf16x8*>(a.in.q + idx);
             }
@@ -163,8 +212,10 @@ __global__ __launch_bounds__(256, (TW == 16 ? (TH == 4 ? (SPS == 1 ? 3 : 2) : 2)
                         const int im = IMG == 1 ? 0 : hp[u] / (PHh * PW);
                         const int hr = hp[u] - im * (PHh * PW);
                         const int hy = hr / PW, hx = hr - hy * PW;
+                        int bb, yy, xx;
+                        origin(im, bb, yy, xx);
                         if (hy >= 1 && hy < PHh - 1 && hx >= 1 && hx < PW - 1)
-                            *reinterpret_cast<bf16x8*>(a.dz_out + (img + ((size_t)im * a.H + y0 + hy - 1) * a.W + x0 + hx - 1) * CIN + c) = o;
+                            *reinterpret_cast<bf16x8*>(a.dz_out + (((size_t)bb * a.H + yy + hy - 1) * a.W + xx + hx - 1) * CIN + c) = o;
                     }
                 }
             }
@@ -200,7 +251,7 @@ __global__ __launch_bounds__(256, (TW == 16 ? (TH == 4 ? (SPS == 1 ? 3 : 2) : 2)
         // in front of its 16 MFMAs.  Barrier of step st: slice st + 1 has landed for every wave (its DMA was issued three steps
         // earlier; two younger slices may stay in flight), and every wave holds slice st's fragments in registers (lgkmcnt(0)),
         // so buffer st % NBUF is free for slice st + NBUF.
-        static_assert(!PF || (SPS == 1 && NBUF == 4 && GPT % 2 == 0), "pipelined K loop: one slice per step, ring of 4, even steps per tap");
+        static_assert(!PF || (SPS == 1 && (NBUF == 4 || NBUF == 3) && GPT % 2 == 0), "pipelined K loop: one slice per step, ring of 3 or 4, even steps per tap");
         bf16x8 fa[2][MI], fw[2][NI];
         int aoff[MI];
         auto tap_offsets = [&](int tap) {
@@ -212,25 +263,25 @@ __global__ __launch_bounds__(256, (TW == 16 ? (TH == 4 ? (SPS == 1 ? 3 : 2) : 2)
                 aoff[mi] = p * CIN + ((fchk ^ halo_sw<CPP>(p)) << 3);
             }
         };
-        tap_offsets(0);
+        tap_offsets(ptap(0));
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) fa[0][mi] = *reinterpret_cast<const bf16x8*>(halo + aoff[mi]);
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) fw[0][ni] = *reinterpret_cast<const bf16x8*>(wbuf + boff[ni]);
-        for (int tap = 0; tap < 9; ++tap) {
+        for (int tap = 0; tap < ((a.dbg & 1) ? 0 : 9); ++tap) {
 #pragma unroll
             for (int g = 0; g < GPT; ++g) {
                 const int st = tap * GPT + g;
                 constexpr int dummy = 0; (void)dummy;
                 const int cur = g & 1, nxt = cur ^ 1;                  // (GPT is even: the register set of a step is a compile-time index)
                 if (st + 1 < NST) {
-                    const int younger = NST - 2 - st;               // slices issued after st + 1
-                    if (younger >= 2) pa_wait_vmcnt<2 * NIW>();
-                    else if (younger == 1) pa_wait_vmcnt<NIW>();
+                    const int younger = NST - 2 - st;               // slices issued after st + 1 (at most NBUF - 2 of them are in flight)
+                    if (younger >= 2 && NBUF == 4) pa_wait_vmcnt<2 * NIW>();
+                    else if (younger >= 1) pa_wait_vmcnt<NIW>();
                     else pa_wait_vmcnt<0>();
                     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
                     if (st + NBUF < NST) issue_w(st + NBUF);
-                    if (g == GPT - 1) tap_offsets(tap + 1);
+                    if (g == GPT - 1) tap_offsets(ptap(tap + 1));
                     const int sub = (g + 1) % GPT;
                     const bf16* Bs = wbuf + ((st + 1) % NBUF) * (BN * 32);
 #pragma unroll
@@ -250,8 +301,9 @@ __global__ __launch_bounds__(256, (TW == 16 ? (TH == 4 ? (SPS == 1 ? 3 : 2) : 2)
     // barrier into the buffer that was read in step st-1.  Counted vmcnt + raw s_barrier: __syncthreads() would drain
     // the LDS-DMA queue (vmcnt(0)) and expose one L2 round trip per slice, which is what bounded the first version
     // of this kernel (0.7 us per 64-channel slice = 30 % MFMA utilisation).
-    for (int tap = 0; tap < 9; ++tap) {
-        const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+    for (int tap = 0; tap < ((a.dbg & 1) ? 0 : 9); ++tap) {
+        const int pt = ptap(tap);
+        const int dy = pt / 3 - 1, dx = pt - (pt / 3) * 3 - 1;
         const int toff = dy * PW + dx;
         // element offset of k-chunk `fchk` of the tap-shifted pixel; the other chunks of the pixel are reached by
         // XOR-ing the chunk bits (the swizzle is an XOR on the same bits), so one address per (tap, fragment)
@@ -291,12 +343,23 @@ __global__ __launch_bounds__(256, (TW == 16 ? (TH == 4 ? (SPS == 1 ? 3 : 2) : 2)
         }
     }
     __syncthreads();            // every wave is done with the halo and the ring before the epilogue reuses the LDS
+    if (a.dbg & 2) {            // (timing ablation: no epilogue; the accumulators stay alive)
+        float sacc = 0.f;
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) sacc += acc[ni][mi][0] + acc[ni][mi][1] + acc[ni][mi][2] + acc[ni][mi][3];
+        if (sacc == 123.456f) a.out[tid] = (bf16)sacc;
+        return;
+    }
 
-    pa_conv_epilogue_auto<BN, NI, MI>(a, acc, n0, wm, wn,
+    pa_conv_epilogue_auto<BN, NI, MI, true, false, NT>(a, acc, n0, wm, wn,
                                      [&](int wr, int mi, int p) {
                                          const int l = (wr * MI + mi) * 16 + p;
                                          const int im = l / (TW * TH), r = l - im * (TW * TH);
-                                         return b + im < a.B ? ((b + im) * a.H + y0 + r / TW) * a.W + x0 + r % TW : -1;
+                                         int bb, yy, xx;
+                                         origin(im, bb, yy, xx);
+                                         return bb < a.B ? (bb * a.H + yy + r / TW) * a.W + xx + r % TW : -1;
                                      },
                                      reinterpret_cast<float*>(lds), (int)blockIdx.x);
 }
@@ -364,9 +427,36 @@ int pa_launch_conv3x3_tile(const PaConvArgs& a, hipStream_t st, int* stat_rows) 
     static int xcd = -1;
     if (xcd < 0) xcd = pa_getenv("PA_CONV3_NOXCD") ? 0 : 1;          // +0.3 % on the step (halo re-reads served by the XCD's own L2)
     PaConvArgs b = a;
+    static int dbg = -1;
+    if (dbg < 0) { const char* e = pa_getenv("PA_CONV3_DBG"); dbg = e ? atoi(e) : 0; }      // tuning builds: phase ablation / tap rotation
+    b.dbg = dbg;
     b.xcd = (a.xcd & 2) | ((xcd && !small && tiles % 8 == 0) ? 1 : 0);
     static int sps = -1;
     if (sps < 0) { const char* e = pa_getenv("PA_CONV3_SPS"); sps = e ? atoi(e) : 1; }      // 0: one slice per step everywhere (round 1)
+    // three 16 x 8 tiles per 512-thread workgroup (one shared weight ring) when that is exactly one round of workgroups on the chip:
+    // the 64 x 64 maps of the hourglass at batch 24 (768 tiles = 256 workgroups)
+#ifdef PA_CONV3_TRI_BUILD          // (measured a wash, DESIGN.md round 4: compiled only on request -- PA_EXTRA=-DPA_CONV3_TRI_BUILD)
+    static int tri = -1, cus = 0;
+    if (tri < 0) {
+        const char* e = pa_getenv("PA_CONV3_TRI"); tri = e ? atoi(e) : 0;
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
+    }
+    const int wg3 = tiles128 / 3;
+    if (tri && !small && !half && a.Cin == 128 && bigN && tiles128 % 3 == 0 && wg3 % 8 == 0 && wg3 <= cus && 2 * wg3 > cus &&
+        (a.ep.mode != PA_OUT_BWD || pa_bwd_epilogue_lds_ok(a))) {
+        if (stat_rows) *stat_rows = wg3;
+        if (a.ep.rows_out) *a.ep.rows_out = wg3;
+        b.xcd = (a.xcd & 2) | (xcd ? 1 : 0);
+        dim3 g3(wg3, a.Cout / 128);
+        switch (a.in.mode) {
+            case PA_LD_PLAIN: hipLaunchKernelGGL((conv3x3_tile_kernel<128, 128, PA_LD_PLAIN, 16, 8, 1, true, 512>), g3, dim3(512), 0, st, b); break;
+            case PA_LD_BNRELU: hipLaunchKernelGGL((conv3x3_tile_kernel<128, 128, PA_LD_BNRELU, 16, 8, 1, true, 512>), g3, dim3(512), 0, st, b); break;
+            default: hipLaunchKernelGGL((conv3x3_tile_kernel<128, 128, PA_LD_LIN2, 16, 8, 1, true, 512>), g3, dim3(512), 0, st, b); break;
+        }
+        return (int)hipGetLastError();
+    }
+#endif
     if (half) { if (sps) launch_tile_shape<16, 4, 2>(b, grid, bigN, st); else launch_tile_shape<16, 4, 1>(b, grid, bigN, st); }
     else if (!small) launch_tile_shape<16, 8, 1>(b, grid, bigN, st);
     else if (a.H == 8) { if (sps) launch_tile_shape<8, 8, 4>(b, grid, bigN, st); else launch_tile_shape<8, 8, 1>(b, grid, bigN, st); }

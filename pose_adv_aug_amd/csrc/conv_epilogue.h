@@ -150,12 +150,14 @@ __device__ __forceinline__ void pa_conv_epilogue(const PaConvArgs& a, f32x4 (&ac
 // (one memory round trip per 32-row pass is exposed to all 256 threads by the pass barrier; prefetching the next
 // sweep's operands costs more registers than it hides).  pa_conv_epilogue_auto therefore keeps the direct epilogue
 // for PA_OUT_BWD.
-template <int BN, int NI, int MI, class PixFn>
+// NT = threads of the workgroup: 256 (2 waves along the pixels: 32-row passes) or 512 (4 waves along the pixels: 64-row passes, T >= 64 * BN floats)
+template <int BN, int NI, int MI, int NT = 256, class PixFn>
 __device__ __forceinline__ void pa_conv_epilogue_lds(const PaConvArgs& a, f32x4 (&acc)[NI][MI], int n0, int wm, int wn,
                                                      PixFn pix, float* T, int stat_row) {
     constexpr int CPR = BN / 8;                      // 8-channel chunks per pixel row
-    constexpr int RPS = 256 / CPR;                   // pixel rows per sweep of the 256 threads
-    constexpr int SW = 32 / RPS;                     // sweeps per 32-row pass
+    constexpr int RPS = NT / CPR;                    // pixel rows per sweep of the NT threads
+    constexpr int SW = (NT / 8) / RPS;               // sweeps per pass of NT / 8 rows (16 per wave row)
+    constexpr int NW = NT / 64;
     const int tid = threadIdx.x, lane = tid & 63;
     const int N = a.Cout;
     const int chunk = tid % CPR, rsub = tid / CPR;
@@ -210,9 +212,11 @@ __device__ __forceinline__ void pa_conv_epilogue_lds(const PaConvArgs& a, f32x4 
             for (int j = 0; j < 8; ++j) { T[(wave * BN + chunk * 8 + j) * 2] = s1[j]; T[(wave * BN + chunk * 8 + j) * 2 + 1] = s2[j]; }
         }
         __syncthreads();
-        for (int c = tid; c < BN; c += 256) {
+        for (int c = tid; c < BN; c += NT) {
             f32x2 v = {T[c * 2] + T[(BN + c) * 2] + T[(2 * BN + c) * 2] + T[(3 * BN + c) * 2],
                        T[c * 2 + 1] + T[(BN + c) * 2 + 1] + T[(2 * BN + c) * 2 + 1] + T[(3 * BN + c) * 2 + 1]};
+#pragma unroll
+            for (int w = 4; w < NW; ++w) { v[0] += T[(w * BN + c) * 2]; v[1] += T[(w * BN + c) * 2 + 1]; }
             *reinterpret_cast<f32x2*>(a.ep.stats + ((size_t)stat_row * N + n0 + c) * 2) = v;
         }
     }
@@ -225,14 +229,15 @@ __device__ __forceinline__ void pa_conv_epilogue_lds(const PaConvArgs& a, f32x4 
 // (2) a thread owns the same 8 channels for all its pixels, so the constants live in registers; (3) the second reduction
 // is accumulated as sum(dz * x) and turned into sum(dz * xhat) = invstd * (sum(dz*x) - mean * sum(dz)) once per
 // workgroup row, which removes mean / invstd from the per-element work.
-template <int BN, int NI, int MI, bool TAB, class PixFn>
+template <int BN, int NI, int MI, bool TAB, int NT = 256, class PixFn>
 __device__ __forceinline__ void pa_conv_epilogue_lds_bwd(const PaConvArgs& a, f32x4 (&acc)[NI][MI], int n0, int wm, int wn,
                                                          PixFn pix, float* T, int stat_row, float4* ctab = nullptr) {
     // ctab (optional, 2 * BN float4 of LDS outside T): the per-channel constants live there instead of in 40 registers
     // (entry j * CPR + chunk: conflict-free for the 16 chunks of a wave) -- for the kernels that run 3 workgroups per CU
     constexpr int CPR = BN / 8;
-    constexpr int RPS = 256 / CPR;
-    constexpr int SW = 32 / RPS;
+    constexpr int RPS = NT / CPR;
+    constexpr int SW = (NT / 8) / RPS;
+    constexpr int NW = NT / 64;
     constexpr int G = (MI >= 2 && !TAB) ? 2 : 1;    // passes per operand request (1 for the 168-register kernels)
     constexpr int IT = G * SW;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -266,7 +271,7 @@ __device__ __forceinline__ void pa_conv_epilogue_lds_bwd(const PaConvArgs& a, f3
             }
         if (g == 0) {
             if (TAB) {
-                for (int i = tid; i < BN; i += 256) {
+                for (int i = tid; i < BN; i += NT) {
                     const int e = (i & 7) * CPR + (i >> 3);
                     ctab[e] = make_float4(a.ep.scale[n0 + i], a.ep.shift[n0 + i], 0.f, 0.f);
                     ctab[BN + e] = m1 == PA_LD_LIN2 ? make_float4(a.add1.k0[n0 + i], a.add1.k1[n0 + i], a.add1.k2[n0 + i], 0.f) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -329,9 +334,11 @@ __device__ __forceinline__ void pa_conv_epilogue_lds_bwd(const PaConvArgs& a, f3
         for (int j = 0; j < 8; ++j) { T[(wave * BN + chunk * 8 + j) * 2] = s1[j]; T[(wave * BN + chunk * 8 + j) * 2 + 1] = s2[j]; }
     }
     __syncthreads();
-    for (int c = tid; c < BN; c += 256) {
-        const float a1 = T[c * 2] + T[(BN + c) * 2] + T[(2 * BN + c) * 2] + T[(3 * BN + c) * 2];
-        const float a2 = T[c * 2 + 1] + T[(BN + c) * 2 + 1] + T[(2 * BN + c) * 2 + 1] + T[(3 * BN + c) * 2 + 1];
+    for (int c = tid; c < BN; c += NT) {
+        float a1 = T[c * 2] + T[(BN + c) * 2] + T[(2 * BN + c) * 2] + T[(3 * BN + c) * 2];
+        float a2 = T[c * 2 + 1] + T[(BN + c) * 2 + 1] + T[(2 * BN + c) * 2 + 1] + T[(3 * BN + c) * 2 + 1];
+#pragma unroll
+        for (int w = 4; w < NW; ++w) { a1 += T[(w * BN + c) * 2]; a2 += T[(w * BN + c) * 2 + 1]; }
         f32x2 v = {a1, a.ep.invstd[n0 + c] * (a2 - a.ep.mean[n0 + c] * a1)};
         *reinterpret_cast<f32x2*>(a.ep.stats + ((size_t)stat_row * N + n0 + c) * 2) = v;
     }
@@ -344,7 +351,7 @@ __host__ __device__ inline bool pa_bwd_epilogue_lds_ok(const PaConvArgs& a) {
 }
 
 // forward epilogues through LDS (coalesced rows), backward epilogue direct; pix(wm, mi, p) as above
-template <int BN, int NI, int MI, bool BWD_LDS = true, bool TAB = false, class PixFn>
+template <int BN, int NI, int MI, bool BWD_LDS = true, bool TAB = false, int NT = 256, class PixFn>
 __device__ __forceinline__ void pa_conv_epilogue_auto(const PaConvArgs& a, f32x4 (&acc)[NI][MI], int n0, int wm, int wn,
                                                       PixFn pix, float* T, int stat_row, float4* ctab = nullptr) {
     if (a.ep.mode == PA_OUT_BWD) {
@@ -352,14 +359,14 @@ __device__ __forceinline__ void pa_conv_epilogue_auto(const PaConvArgs& a, f32x4
         // the networks); anything else takes the direct epilogue
         const bool lds_ok = BWD_LDS && pa_bwd_epilogue_lds_ok(a);
         if (lds_ok) {
-            pa_conv_epilogue_lds_bwd<BN, NI, MI, TAB>(a, acc, n0, wm, wn, pix, T, stat_row, ctab);
-        } else if (TAB) {
-            __builtin_trap();       // the 168-register kernels carry no direct epilogue (it spilled): pa_bwd_epilogue_lds_ok() routes such launches elsewhere
+            pa_conv_epilogue_lds_bwd<BN, NI, MI, TAB, NT>(a, acc, n0, wm, wn, pix, T, stat_row, ctab);
+        } else if constexpr (TAB || NT != 256) {
+            __builtin_trap();       // the 168-register / 512-thread kernels carry no direct epilogue: pa_bwd_epilogue_lds_ok() routes such launches elsewhere
         } else {
             const int p = threadIdx.x & 15;
             pa_conv_epilogue<BN, NI, MI>(a, acc, n0, wm, wn, [&](int mi) { return pix(wm, mi, p); }, T, stat_row);
         }
     } else {
-        pa_conv_epilogue_lds<BN, NI, MI>(a, acc, n0, wm, wn, pix, T, stat_row);
+        pa_conv_epilogue_lds<BN, NI, MI, NT>(a, acc, n0, wm, wn, pix, T, stat_row);
     }
 }

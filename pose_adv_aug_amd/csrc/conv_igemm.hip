@@ -29,16 +29,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(PaConvArgs a) {
     constexpr int AI = BM / 32, BI = BN / 32;      // staged 16-byte chunks per thread (A / B tile)
     constexpr int MI = BM / 32, NI = BN / 32;      // 16x16 fragments per wave (wave tile BM/2 x BN/2)
     __shared__ __attribute__((aligned(16))) bf16 lds[(BM + BN) * 64];
-    __shared__ float kst[LDMODE == PA_LD_PLAIN ? 4 : 3 * 512];      // per-channel constants of the input transform
+    __shared__ float kst[LDMODE == PA_LD_PLAIN ? 4 : 3 * 512 + 1024];      // per-channel constants of the input transform (+ the finalize prologue's scratch)
     bf16* As = lds;
     bf16* Bs = lds + BM * 64;
-    if (LDMODE != PA_LD_PLAIN) {
-        for (int c = threadIdx.x; c < a.Cin; c += 256) {
-            kst[c] = a.in.k0[c]; kst[512 + c] = a.in.k1[c];
-            if (LDMODE == PA_LD_LIN2) kst[1024 + c] = a.in.k2[c];
-        }
-    }
-
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave & 1, wn = wave >> 1;
     const int M = a.B * a.H * a.W, HW = a.H * a.W;
@@ -152,6 +145,18 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(PaConvArgs a) {
         for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     gload(0);
+    // per-channel constants of the input transform, behind the first tile's loads (they are in flight meanwhile)
+    if (LDMODE != PA_LD_PLAIN) {
+        if (!STEM && a.fin.rows > 0) {
+            // the input's BatchNorm finalize (forward: scale / shift; backward: kA / kB / kC) from the producer's partial rows, bn_fin.h
+            pa_bn_fin_prologue<256, 512>(a.fin, a.Cin, kst, kst + 3 * 512, blockIdx.x == 0 && blockIdx.y == 0);
+        } else {
+            for (int c = threadIdx.x; c < a.Cin; c += 256) {
+                kst[c] = a.in.k0[c]; kst[512 + c] = a.in.k1[c];
+                if (LDMODE == PA_LD_LIN2) kst[1024 + c] = a.in.k2[c];
+            }
+        }
+    }
     __syncthreads();            // kst visible
     lstore();
     __syncthreads();
@@ -220,6 +225,16 @@ int pa_launch_stem_conv(const PaConvArgs& a, hipStream_t st, int* stat_rows) {
     return (int)hipGetLastError();
 }
 
+// mirrors the dispatch below: the row-tile 1x1 kernel carries no finalize prologue
+bool pa_conv_takes_fin(const PaConvArgs& a) {
+    if (a.in.mode != PA_LD_BNRELU && a.in.mode != PA_LD_LIN2) return false;
+    if (a.Cin > 256) return false;
+    const bool old3 = pa_getenv("PA_CONV3_OLD") != nullptr, old1 = pa_getenv("PA_CONV1_OLD") != nullptr;
+    if (!old3 && pa_conv3x3_tile_supported(a)) return true;
+    if (!old1 && pa_conv1x1_tile_supported(a)) return false;
+    return true;
+}
+
 int pa_launch_conv(const PaConvArgs& a0, hipStream_t st, int* stat_rows) {
     static int bwd_direct = -1;
     if (bwd_direct < 0) bwd_direct = pa_getenv("PA_EPI_BWD_DIRECT") ? 2 : 0;      // A/B: direct BatchNorm-backward epilogue
@@ -238,7 +253,11 @@ int pa_launch_conv(const PaConvArgs& a0, hipStream_t st, int* stat_rows) {
     if (!old3 && pa_conv3x3_tile_supported(a)) return pa_launch_conv3x3_tile(a, st, stat_rows);
     static int old1 = -1;
     if (old1 < 0) old1 = pa_getenv("PA_CONV1_OLD") ? 1 : 0;
-    if (!old1 && pa_conv1x1_tile_supported(a)) return pa_launch_conv1x1_tile(a, st, stat_rows);
+    if (!old1 && pa_conv1x1_tile_supported(a)) {
+        if (a.fin.rows > 0) { pa_set_error_msg("pa_launch_conv: a pending finalize was handed to the row-tile 1x1 kernel (pa_conv_takes_fin)"); return 1; }
+        return pa_launch_conv1x1_tile(a, st, stat_rows);
+    }
+    if (a.fin.rows > 0 && (a.fin.rows > PA_FIN_SMALL_ROWS || a.Cin > 256)) { pa_set_error_msg("pa_launch_conv: finalize prologue needs <= 128 partial rows and <= 256 channels"); return 1; }
     const int M = a.B * a.H * a.W;
     // small problems get the 64-row tile so that the grid still covers the 256 CUs
     const bool bigM = M >= 128 * 256;

@@ -314,7 +314,10 @@ static bool wg_tile_cfg(int B, int H, int W, int Cin, int Cout, int taps, WgTile
     int s = (taps == 9 ? target9 : target1) / types;
     if (s < 1) s = 1;
     if (s > c.ntiles) s = c.ntiles;
-    const int per = (c.ntiles + s - 1) / s;          // tiles per workgroup
+    int per = (c.ntiles + s - 1) / s;                // tiles per workgroup
+    static int minper = -1;
+    if (minper < 0) { const char* e = pa_getenv("PA_WGRAD_MINPER"); minper = e ? atoi(e) : 1; }      // experiment: fewer, longer splits (fewer fp32 slabs) at the low-resolution levels
+    if (per < minper) per = minper;
     c.splits = (c.ntiles + per - 1) / per;           // balanced
     return true;
 }

@@ -5,6 +5,7 @@
 // channel per workgroup.
 #include "common.h"
 #include "kernels.h"
+#include "bn_fin.h"
 
 // ------------------------------------------------------------------------------------------------
 // BatchNorm bookkeeping (reference semantics: torch.nn.BatchNorm2d, eps 1e-5, momentum 0.1,
@@ -16,8 +17,32 @@
 constexpr int FC = 8;
 __device__ __forceinline__ void reduce_partial_rows(const float* part, int rows, int C, int c0, float (*sums)[2]) {
     constexpr int SL = 1024 / FC;
-    __shared__ float red[SL][FC + 1][2];
+    __shared__ __attribute__((aligned(16))) float red[SL][FC + 1][2];
     const int cl = threadIdx.x % FC, sl = threadIdx.x / FC;
+    if (rows <= PA_FIN_SMALL_ROWS) {
+        // the order the consumer-prologue form of the finalize uses too (bn_fin.h): sixteen interleaved chains, stride-halving tree;
+        // here 8 threads per channel pair (4 pairs per workgroup), each with two chains
+        f32x4* part4 = reinterpret_cast<f32x4*>(&red[0][0][0]);          // [8][4]
+        if (threadIdx.x < 32) {
+            const int pr = threadIdx.x & 3, g = threadIdx.x >> 2;
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            part4[g * 4 + pr] = c0 + 2 * pr < C ? pa_fin_partial<8>(part, rows, C, c0 + 2 * pr, g) : z;
+        }
+        __syncthreads();
+        if (threadIdx.x < FC) {
+            const int c = threadIdx.x, half = c & 1;
+            float a[8], b[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { const f32x4 v = part4[i * 4 + (c >> 1)]; a[i] = half ? v[2] : v[0]; b[i] = half ? v[3] : v[1]; }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { a[i] += a[i + 4]; b[i] += b[i + 4]; }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) { a[i] += a[i + 2]; b[i] += b[i + 2]; }
+            sums[c][0] = a[0] + a[1]; sums[c][1] = b[0] + b[1];
+        }
+        __syncthreads();
+        return;
+    }
     float a = 0.f, b = 0.f;
     if (c0 + cl < C) {
 #pragma unroll 8
@@ -58,18 +83,16 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* stats, i
     if (threadIdx.x >= FC) return;
     const int c = c0 + threadIdx.x;
     if (c >= C) return;
-    float mu = sums[threadIdx.x][0] / count;
-    float var = fmaxf(sums[threadIdx.x][1] / count - mu * mu, 0.f);
-    float is = rsqrtf(var + eps);
-    float s = gamma[c] * is;
+    float s, sh, mu, is, var;
+    pa_bn_fwd_consts(sums[threadIdx.x][0], sums[threadIdx.x][1], count, eps, gamma[c], beta[c], s, sh, mu, is, var);
     scale[c] = s;
-    shift[c] = beta[c] - mu * s;
+    shift[c] = sh;
     mean[c] = mu;
     invstd[c] = is;
     if (update_running) {
-        float unb = count > 1.f ? var * count / (count - 1.f) : var;
-        rmean[c] = (1.f - momentum) * rmean[c] + momentum * mu;
-        rvar[c] = (1.f - momentum) * rvar[c] + momentum * unb;
+        float rm = rmean[c], rv = rvar[c];
+        pa_bn_running(mu, var, count, momentum, rm, rv);
+        rmean[c] = rm; rvar[c] = rv;
     }
 }
 
@@ -107,11 +130,9 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* bsta
     const int c = c0 + threadIdx.x;
     if (c >= C) return;
     float S1 = sums[threadIdx.x][0], S2 = sums[threadIdx.x][1];
-    float s = scale[c], is = invstd[c], mu = mean[c];
-    kA[c] = s;
-    float b = -s * is * S2 / count;
-    kB[c] = b;
-    kC[c] = -s * S1 / count - b * mu;
+    float ka, kb, kc;
+    pa_bn_bwd_consts(S1, S2, count, scale[c], invstd[c], mean[c], ka, kb, kc);
+    kA[c] = ka; kB[c] = kb; kC[c] = kc;
     if (dgamma) dgamma[c] = S2;
     if (dbeta) dbeta[c] = S1;
 }
@@ -128,11 +149,9 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize2_kernel(BwdFinArgs a0, B
     const int c = c0 + threadIdx.x;
     if (c >= a.C) return;
     float S1 = sums[threadIdx.x][0], S2 = sums[threadIdx.x][1];
-    float s = a.scale[c], is = a.invstd[c], mu = a.mean[c];
-    a.kA[c] = s;
-    float b = -s * is * S2 / a.count;
-    a.kB[c] = b;
-    a.kC[c] = -s * S1 / a.count - b * mu;
+    float ka, kb, kc;
+    pa_bn_bwd_consts(S1, S2, a.count, a.scale[c], a.invstd[c], a.mean[c], ka, kb, kc);
+    a.kA[c] = ka; a.kB[c] = kb; a.kC[c] = kc;
     if (a.dgamma) a.dgamma[c] = S2;
     if (a.dbeta) a.dbeta[c] = S1;
 }

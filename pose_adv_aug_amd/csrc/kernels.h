@@ -1,6 +1,7 @@
 // Host-side launch interface of the HIP kernels (internal; the public C ABI is include/poseadv.h).
 #pragma once
 #include "common.h"
+#include "bn_fin.h"
 
 struct PaConvArgs {
     PaOperand in;        // [B][H][W][Cin] NHWC bf16
@@ -13,10 +14,14 @@ struct PaConvArgs {
     int B, H, W, Cin, Cout, taps;
     bf16* dz_out;        // optional (1x1 row-tile kernel, LIN2 input): the transformed input tile is also stored here [M][Cin] --
                          // later consumers of the same BatchNorm-backward gradient read ONE tensor instead of recomputing it from two
+    PaBnFin fin;         // pending BatchNorm finalize of `in`, done in the kernel's prologue (fin.rows > 0; only launches pa_conv_takes_fin() admits)
+    int dbg;             // tuning builds only (0 in the release library): conv3x3_tile.hip phase ablation bits 1 / 2 / 4, bit 8 = per-workgroup tap rotation
     int xcd;             // set by the launchers: workgroup i works on tile (i % 8) * (tiles / 8) + i / 8 (one contiguous range per XCD)
 };
 // stat_rows (optional) receives the number of partial-statistics rows the launch writes (= grid.x)
 int pa_launch_conv(const PaConvArgs& a, hipStream_t st, int* stat_rows = nullptr);
+// will pa_launch_conv send this launch to a kernel that carries the finalize prologue (generic kernel, 3x3 tile kernel)?
+bool pa_conv_takes_fin(const PaConvArgs& a);
 // halo-tile 3x3 kernel (conv3x3_tile.hip); pa_launch_conv dispatches to it when the shape is supported
 bool pa_conv3x3_tile_supported(const PaConvArgs& a);
 int pa_launch_conv3x3_tile(const PaConvArgs& a, hipStream_t st, int* stat_rows = nullptr);

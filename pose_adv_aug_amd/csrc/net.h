@@ -37,6 +37,9 @@ struct BNLayer {
     int stat_rows = 0, bstat_rows = 0, max_rows = 0;
     float *scale = nullptr, *shift = nullptr, *mean = nullptr, *invstd = nullptr;
     float *kA = nullptr, *kB = nullptr, *kC = nullptr;
+    // the finalize of the forward statistics / of the backward reductions has NOT been launched: the next consumer of the tensor does it
+    // in its prologue (bn_fin.h; Net::fin_rows_max)
+    bool fin_pending = false, bfin_pending = false;
 };
 
 struct ConvLayer {
@@ -238,10 +241,23 @@ struct Net {
     PaEpilogue final_ep(const Act& a) const;        // epilogue that finishes a gradient for `a`
     int finish_grad(const Act& a);                  // BatchNorm backward finalize (if pending BN)
     int finish_grad2(const Act& a, const Act& b);   // two of them in one launch
+    // pending_in: the BatchNorm of `in` whose finalize may still be pending (done in this launch's prologue then);
+    // defer_after: the caller guarantees that the ONLY next reader of bn_after's constants is a launch that takes a pending finalize
+    // (fin_consumer_ok), so the finalize launch is skipped when the statistics have <= fin_rows_max partial rows
     int conv_fwd(ConvLayer& c, const PaOperand& in, int B, int H, int W, const PaOperand& add1, const PaOperand& add2,
-                 bf16* out, BNLayer* bn_after);
+                 bf16* out, BNLayer* bn_after, BNLayer* pending_in = nullptr, bool defer_after = false);
     int conv_dgrad(ConvLayer& c, const PaOperand& dy, int B, int H, int W, const PaOperand& add1, const PaOperand& add2,
-                   const PaEpilogue& ep, bf16* out, bf16* dz_out = nullptr, bool* dz_done = nullptr);
+                   const PaEpilogue& ep, bf16* out, bf16* dz_out = nullptr, bool* dz_done = nullptr, BNLayer* pending_in = nullptr);
+    // BatchNorm finalize in the consumer's prologue for launches with at most this many partial rows (the 16 x 16 and smaller levels;
+    // 0 = always a launch of its own).  Same bits either way (bn_fin.h)
+    int fin_rows_max = PA_FIN_SMALL_ROWS;
+    int fin_mask = 7;       // which finalizes may ride in a consumer: 1 forward x1 / x2, 2 backward x2, 4 backward x3 (PA_FIN_MASK in tuning builds)
+    bool fin_consumer_ok(const ConvLayer& c, int B, int H, int W, bool dgrad) const;
+    PaBnFin fin_fwd(const BNLayer& b, int M) const;
+    PaBnFin fin_bwd(const BNLayer& b, int M) const;
+    int finish_grad_or_defer(const Act& a, bool defer);
+    int finish_grad2_or_defer(const Act& a, bool defer_a, const Act& b, bool defer_b);
+    bool x3_fin_ok(const Residual& r, const Act& in) const;     // can r.x3's backward finalize ride in conv3's data gradient?
     int conv_wgrad(ConvLayer& c, const PaOperand& dy, const PaOperand& x, int B, int H, int W);
 
     int prepare_weights();

@@ -425,6 +425,25 @@ int Net::finish_grad(const Act& a) {
                                      grads + b->p_beta, b->C, (float)a.M(), st);
 }
 
+// defer: the only next reader of a's BatchNorm-backward constants is a data-gradient launch that takes the pending finalize
+int Net::finish_grad_or_defer(const Act& a, bool defer) {
+    if (a.bn && defer && a.bn->bstat_rows > 0 && a.bn->bstat_rows <= fin_rows_max) { a.bn->bfin_pending = true; return 0; }
+    return finish_grad(a);
+}
+
+int Net::finish_grad2_or_defer(const Act& a, bool defer_a, const Act& b, bool defer_b) {
+    const bool da = a.bn && defer_a && a.bn->bstat_rows > 0 && a.bn->bstat_rows <= fin_rows_max;
+    const bool db = b.bn && defer_b && b.bn->bstat_rows > 0 && b.bn->bstat_rows <= fin_rows_max;
+    if (da && db) { a.bn->bfin_pending = true; b.bn->bfin_pending = true; return 0; }
+    if (da) { a.bn->bfin_pending = true; return finish_grad(b); }
+    if (db) { b.bn->bfin_pending = true; return finish_grad(a); }
+    return finish_grad2(a, b);
+}
+
+// the first reader of x3's BatchNorm-backward constants is conv3's data gradient (Residual::bwd_a), launched on whatever stream runs the
+// block's backward pass; its weight gradient and the shortcut addend come later
+bool Net::x3_fin_ok(const Residual& r, const Act& in) const { return (fin_mask & 4) && !drop_mask && fin_consumer_ok(r.c3, in.B, in.H, in.W, true); }
+
 int Net::finish_grad2(const Act& a, const Act& b) {
     if (ablate() & 4) return 0;
     if ((ablate() & 256) && a.H <= ablate_h()) return 0;
@@ -436,9 +455,37 @@ int Net::finish_grad2(const Act& a, const Act& b) {
                                       y->C, (float)b.M(), st);
 }
 
-int Net::conv_fwd(ConvLayer& c, const PaOperand& in, int B_, int H, int W, const PaOperand& add1, const PaOperand& add2,
-                  bf16* out, BNLayer* bn_after) {
+bool Net::fin_consumer_ok(const ConvLayer& c, int B_, int H, int W, bool dgrad) const {
+    if (fin_rows_max <= 0 || !train_bn || c.k == 7) return false;
+    if ((long)B_ * H * W > 64L * PA_FIN_SMALL_ROWS) return false;          // (no producer tiling leaves <= 128 rows above that)
     PaConvArgs a; memset(&a, 0, sizeof a);
+    a.B = B_; a.H = H; a.W = W; a.taps = c.taps();
+    a.Cin = dgrad ? c.pcout : c.pcin; a.Cout = dgrad ? c.pcin : c.pcout;
+    a.in.mode = dgrad ? PA_LD_LIN2 : PA_LD_BNRELU;
+    return pa_conv_takes_fin(a);
+}
+
+PaBnFin Net::fin_fwd(const BNLayer& b, int M) const {
+    PaBnFin f; memset(&f, 0, sizeof f);
+    f.stats = b.stats; f.rows = b.stat_rows; f.bwd = 0; f.count = (float)M;
+    f.gamma = params + b.p_gamma; f.beta = params + b.p_beta; f.rmean = buffers + b.b_rmean; f.rvar = buffers + b.b_rvar;
+    f.scale = b.scale; f.shift = b.shift; f.mean = b.mean; f.invstd = b.invstd;
+    f.momentum = momentum; f.eps = eps; f.update_running = bn_update;
+    return f;
+}
+
+PaBnFin Net::fin_bwd(const BNLayer& b, int M) const {
+    PaBnFin f; memset(&f, 0, sizeof f);
+    f.stats = b.bstats; f.rows = b.bstat_rows; f.bwd = 1; f.count = (float)M;
+    f.scale = b.scale; f.mean = b.mean; f.invstd = b.invstd;
+    f.kA = b.kA; f.kB = b.kB; f.kC = b.kC; f.dgamma = grads + b.p_gamma; f.dbeta = grads + b.p_beta;
+    return f;
+}
+
+int Net::conv_fwd(ConvLayer& c, const PaOperand& in, int B_, int H, int W, const PaOperand& add1, const PaOperand& add2,
+                  bf16* out, BNLayer* bn_after, BNLayer* pending_in, bool defer_after) {
+    PaConvArgs a; memset(&a, 0, sizeof a);
+    if (pending_in && pending_in->fin_pending) { a.fin = fin_fwd(*pending_in, B_ * H * W); pending_in->fin_pending = false; }
     a.in = in; a.w = c.wf; a.bias = params + c.p_b; a.add1 = add1; a.add2 = add2; a.out = out;
     a.B = B_; a.H = H; a.W = W; a.Cin = c.pcin; a.Cout = c.pcout; a.taps = c.k == 7 ? 1 : c.taps();
     a.ep = ep_plain();
@@ -452,6 +499,7 @@ int Net::conv_fwd(ConvLayer& c, const PaOperand& in, int B_, int H, int W, const
     int rc = (c.k == 3 && (ablate() & 8)) ? 0 : ((c.k == 7) ? pa_launch_stem_conv(a, st) : pa_launch_conv(a, st));
     prof.end(pe, st);
     TRY(rc);
+    if (bn_after && train_bn && defer_after && bn_after->stat_rows > 0 && bn_after->stat_rows <= fin_rows_max) { bn_after->fin_pending = true; return 0; }
     if (bn_after && train_bn && !(ablate() & 4))
         TRY(pa_launch_bn_finalize(bn_after->stats, bn_after->stat_rows, params + bn_after->p_gamma, params + bn_after->p_beta,
                                   buffers + bn_after->b_rmean, buffers + bn_after->b_rvar, bn_after->scale, bn_after->shift,
@@ -460,8 +508,9 @@ int Net::conv_fwd(ConvLayer& c, const PaOperand& in, int B_, int H, int W, const
 }
 
 int Net::conv_dgrad(ConvLayer& c, const PaOperand& dy, int B_, int H, int W, const PaOperand& add1, const PaOperand& add2,
-                    const PaEpilogue& ep, bf16* out, bf16* dz_out, bool* dz_done) {
+                    const PaEpilogue& ep, bf16* out, bf16* dz_out, bool* dz_done, BNLayer* pending_in) {
     PaConvArgs a; memset(&a, 0, sizeof a);
+    if (pending_in && pending_in->bfin_pending) { a.fin = fin_bwd(*pending_in, B_ * H * W); pending_in->bfin_pending = false; }
     a.in = dy; a.w = c.wb; a.bias = nullptr; a.add1 = add1; a.add2 = add2; a.out = out; a.ep = ep;
     a.B = B_; a.H = H; a.W = W; a.Cin = c.pcout; a.Cout = c.pcin; a.taps = c.taps();
     if (dz_done) *dz_done = false;
@@ -604,13 +653,15 @@ template <class... A> static int c_heat_grad(Net& n, const float* heat, const do
 // residual block (reference :30-49): x1 = conv1(a), x2 = conv3x3(relu bn1 x1), x3 = conv3(relu bn2 x2) + shortcut
 int Residual::fwd(Net& n, const Act& in) {
     const int B = in.B, H = in.H, W = in.W;
-    TRY(n.conv_fwd(c1, n.op(in), B, H, W, pa_none(), pa_none(), x1.raw, &b1));
-    TRY(n.conv_fwd(c2, n.op(x1), B, H, W, pa_none(), pa_none(), x2.raw, &b2));
+    // x1 / x2 have ONE reader each (conv2 / conv3): at the low-resolution levels their BatchNorm finalize runs in that reader's prologue
+    const bool d1 = (n.fin_mask & 1) && n.fin_consumer_ok(c2, B, H, W, false), d2 = (n.fin_mask & 1) && n.fin_consumer_ok(c3, B, H, W, false);
+    TRY(n.conv_fwd(c1, n.op(in), B, H, W, pa_none(), pa_none(), x1.raw, &b1, nullptr, d1));
+    TRY(n.conv_fwd(c2, n.op(x1), B, H, W, pa_none(), pa_none(), x2.raw, &b2, &b1, d2));
     if (has_adapter) {
         TRY(n.conv_fwd(ad, n.op(in), B, H, W, pa_none(), pa_none(), adout, nullptr));
-        TRY(n.conv_fwd(c3, n.op(x2), B, H, W, pa_plain(adout), pa_none(), x3.raw, &b3));
+        TRY(n.conv_fwd(c3, n.op(x2), B, H, W, pa_plain(adout), pa_none(), x3.raw, &b3, &b2));
     } else {
-        TRY(n.conv_fwd(c3, n.op(x2), B, H, W, n.op(in), pa_none(), x3.raw, &b3));
+        TRY(n.conv_fwd(c3, n.op(x2), B, H, W, n.op(in), pa_none(), x3.raw, &b3, &b2));
     }
     return 0;
 }
@@ -622,17 +673,22 @@ int Residual::bwd_a(Net& n, const Act& in) {
     const int B = in.B, H = in.H, W = in.W;
     // conv3's data gradient goes first: its kernel also stores dz3 = BatchNorm-backward(x3.grad, x3.raw), and the weight
     // gradients / the shortcut addend after it read that one tensor instead of recomputing it from two
+    // (x3.bn: its finalize may be pending -- then this launch does it in its prologue, Net::x3_fin_ok)
     PaOperand g3 = n.gradop(x3);
     dz3_valid = false;
-    TRY(n.conv_dgrad(c3, g3, B, H, W, pa_none(), pa_none(), n.final_ep(x2), x2.grad, dz3, &dz3_valid));
+    TRY(n.conv_dgrad(c3, g3, B, H, W, pa_none(), pa_none(), n.final_ep(x2), x2.grad, dz3, &dz3_valid, x3.bn));
     if (dz3_valid) g3 = pa_plain(dz3);
     TRY(n.conv_wgrad(c3, g3, n.op(x2), B, H, W));
-    TRY(n.finish_grad(x2));
+    // (x2's BatchNorm-backward constants are first read by conv2's data gradient, which can compute them in its prologue; conv2's
+    // weight gradient, on the weight-gradient stream, is launched behind it)
+    TRY(n.finish_grad_or_defer(x2, (n.fin_mask & 2) && n.fin_consumer_ok(c2, B, H, W, true)));
     PaOperand g2 = n.gradop(x2);
     bool dz2_valid = false;
-    TRY(n.conv_dgrad(c2, g2, B, H, W, pa_none(), pa_none(), n.final_ep(x1), x1.grad, dz2, &dz2_valid));
+    TRY(n.conv_dgrad(c2, g2, B, H, W, pa_none(), pa_none(), n.final_ep(x1), x1.grad, dz2, &dz2_valid, x2.bn));
     if (dz2_valid) g2 = pa_plain(dz2);
     TRY(n.conv_wgrad(c2, g2, n.op(x1), B, H, W));
+    // (x1's constants have two first readers -- conv1's weight gradient on the weight-gradient stream and conv1's data gradient in bwd_b:
+    // queueing the weight gradient behind a data gradient that finalizes in its prologue measured +0.05 ms, round 4 -- a launch stays)
     TRY(n.finish_grad(x1));
     const PaOperand g1 = n.gradop(x1);
     TRY(n.conv_wgrad(c1, g1, n.op(in), B, H, W));
@@ -727,7 +783,11 @@ int Hourglass::bwd(Net& n, const Act& in, const PaOperand& extra0) {
             TRY(c_upadd_bwd(n, m.grad, n.final_ep(up[k].x3), up[k].x3.grad, n.final_ep(skip[k].x3), skip[k].x3.grad,
                                     m.B, m.H, m.W, m.C, n.st));
         }
-        TRY(n.finish_grad2(up[k].x3, skip[k].x3));
+        {
+            const Act& upin_ = (k == 3) ? (n.drop_mask ? neckm : neck.x3) : merged[k + 1];
+            const Act& skin_ = (k == 0) ? in : down[k - 1].x3;
+            TRY(n.finish_grad2_or_defer(up[k].x3, n.x3_fin_ok(up[k], upin_), skip[k].x3, n.x3_fin_ok(skip[k], skin_)));
+        }
         if (n.forks(k)) {          // parameter / inner gradients of the skip block next to the deeper levels
             const Act& x = (k == 0) ? in : down[k - 1].x3;
             TRY(n.fork_to(k));
@@ -742,9 +802,9 @@ int Hourglass::bwd(Net& n, const Act& in, const PaOperand& extra0) {
         TRY(pa_launch_cell_mask(pa_plain(neckm.grad), n.drop_mask, n.final_ep(x), x.grad, x.B, x.H, x.W, x.C, n.st));
     }
     TRY(n.release_held(4));
-    TRY(n.finish_grad(neck.x3));
+    TRY(n.finish_grad_or_defer(neck.x3, n.x3_fin_ok(neck, down[3].x3)));
     TRY(neck.bwd(n, down[3].x3, pa_none(), true));
-    TRY(n.finish_grad(down[3].x3));
+    TRY(n.finish_grad_or_defer(down[3].x3, n.x3_fin_ok(down[3], pooled[3])));
     for (int k = 3; k >= 0; --k) {
         TRY(down[k].bwd(n, pooled[k], pa_none(), true));
         const Act& x = (k == 0) ? in : down[k - 1].x3;
@@ -756,7 +816,8 @@ int Hourglass::bwd(Net& n, const Act& in, const PaOperand& extra0) {
         } else {
             TRY(skip[k].bwd(n, x, pa_plain(poolgrad[k]), true));
         }
-        TRY(n.finish_grad(x));
+        if (k >= 1) TRY(n.finish_grad_or_defer(x, n.x3_fin_ok(down[k - 1], pooled[k - 1])));      // x = down[k-1].x3: read next by down[k-1]'s backward pass
+        else TRY(n.finish_grad(x));
     }
     return 0;
 }
@@ -775,6 +836,8 @@ static hipError_t create_stream_cus(hipStream_t* s, const char* env, const char*
 
 int Net::ensure_streams() {
     if (streams_ready) return 0;
+    if (const char* e = pa_getenv("PA_FIN_MASK")) fin_mask = atoi(e);
+    if (const char* e = pa_getenv("PA_FIN_PROLOGUE")) fin_rows_max = atoi(e) > PA_FIN_SMALL_ROWS ? PA_FIN_SMALL_ROWS : atoi(e);
     if (pa_getenv("PA_SINGLE_STREAM")) { multi_stream = false; streams_ready = true; return 0; }
     if (const char* e = pa_getenv("PA_FORK_LEVELS")) fork_mask = atoi(e);
     if (const char* e = pa_getenv("PA_SIDE_STREAMS")) n_side = atoi(e) < 1 ? 1 : (atoi(e) > 4 ? 4 : atoi(e));

@@ -146,15 +146,32 @@ def main(argv=None):
     # the feeds are STREAMED every pass (an MPII split resident in HBM would be 60-130 GB of padded frames): the collection
     # pass walks each split once in dataset order (row i of a text file = person i, collect-scale-ditri.py:123-255), the
     # training passes look a person's distribution up by its dataset index (data/pretrain_s_r_agent.py:127-128)
+    from .data import num_samples
     train_feed, val_feed = make_feeds(opt)
-    ordered_train, _ = make_feeds(opt, shuffle_train=False, log=lambda m: None)
+    ordered = {}                                          # the dataset-order train feed (a second JSON parse + decoder pool): only when a file has to be collected
+
+    def feed_of(split):
+        if split == 'val':
+            return val_feed
+        if 'train' not in ordered:
+            ordered['train'] = make_feeds(opt, shuffle_train=False, log=lambda m: None)[0]
+        return ordered['train']
     distri = {}
-    for split, feed in (('train', ordered_train), ('val', val_feed)):
+    for split in ('train', 'val'):
+        people = num_samples(train_feed if split == 'train' else val_feed)
         for kind, fname in (('scale', '%s_scales.txt' % split), ('rotation', '%s_rotations.txt' % split)):
             path = os.path.join(sr_dir, fname)
-            if not os.path.isfile(path):
-                collect_data(feed, hg, aug, kind, path)
-            distri[(split, kind)] = read_grnd_distri_from_txt(path)
+            rows = read_grnd_distri_from_txt(path) if os.path.isfile(path) else None
+            if rows is None or len(rows) != people:       # missing, or cut short by an interrupted collection (it appends): collect again
+                tmp = path + '.collecting'
+                if os.path.isfile(tmp):
+                    os.remove(tmp)
+                collect_data(feed_of(split), hg, aug, kind, tmp)
+                os.replace(tmp, path)                     # the file appears only when it is complete
+                rows = read_grnd_distri_from_txt(path)
+                if len(rows) != people:
+                    raise RuntimeError('%s: %d distribution rows for %d people' % (path, len(rows), people))
+            distri[(split, kind)] = rows
     summary = sr_dir + '/' + 'training-summary.txt'
     resumed = opt.load_prefix_sr != '' and os.path.isfile(summary)
     logger = Logger(summary, title='training-summary', resume=resumed)                      # :120-122

@@ -237,6 +237,70 @@ def test_blocks_of_every_resolution_match_locally_at_the_benchmark_size(fused):
     assert not errs, '%d local mismatches, first: %s' % (len(errs), errs[:15])
 
 
+def test_stem_second_stack_and_head_layers_match_locally_at_the_benchmark_size():
+    """The rest of BASELINE configs[1] at FULL size (2-stack, chan 256, B = 24), in place like the test above: the stem's residual1
+    (64 -> 128 channels with the adapter, 128 x 128 maps: the 64-channel 3x3 / 1x1 instances), residual3 (128 -> 256 with the adapter at
+    64 x 64), stack 1's skip1 and post_res (the second stack's template instances and buffers), and the head of stack 0: linear.0 (+ its
+    BatchNorm), out_conv.0, forth_conv.0, in_conv.0 and the re-injected input of stack 1 -- forward 1e-2, every parameter gradient and
+    the node gradients 4e-2 / cosine 0.999 (models/asn_stacked_hg.py:283-289, 292-334)."""
+    torch.set_num_threads(max(16, torch.get_num_threads()))
+    bf16_emul.ROUND_GRADS = True
+    stacks, B, res, chan = 2, 24, 256, 256
+    ref, net = _hg_pair(stacks, chan, B, res, seed=12)
+    img = t(inputs.images(43, B, res))
+    pts = inputs.heat_pts(44, B, res=res // 4)
+    heat_t = t(inputs.heatmaps_from_pts(pts, res=res // 4))
+    ref.train(); net.train()
+    loss, outs = net.loss_and_backward(img.cuda(), t(pts).cuda(), want_outputs=True)
+    P = Probe(net)
+    hip_grads = {n: g.cpu() for n, g in net.named_grads()}
+    errs = []
+
+    def param_grads(prefix, module):
+        for n, p in module.named_parameters():
+            if (n.startswith('conv') or n.startswith('adapter')) and n.endswith('bias'):
+                continue                                  # bias in front of a BatchNorm: exactly zero in the engine, rounding noise in autograd
+            _close(errs, 'grad ' + prefix + n, hip_grads[prefix + n], p.grad, GRAD_TOL, GRAD_COS)
+
+    sites = [(ref.residual1, 'residual1.', 'stem', 'res1'), (ref.residual3, 'residual3.', 'res2', 'res3'),
+             (ref.hg[1].skip1[0], 'hg.1.skip1.0.', 'xin1', 'hg1.skip1'), (ref.post_res[1][0], 'post_res.1.0.', 'hg1.merge1', 'post1')]
+    for blk, prefix, in_name, out_name in sites:
+        a_in = _leaf(P.act(in_name))
+        tap = {}
+        a3 = emul_residual(blk, a_in, tap, out_name)
+        for k in ('.x1', '.x2', ''):
+            _close(errs, 'fwd ' + out_name + k, P.act(out_name + k), tap[out_name + k].detach(), FWD_TOL)
+        blk.zero_grad()
+        a3.backward(P.grad(out_name))
+        param_grads(prefix, blk)
+        for k in ('.x1', '.x2'):
+            inner = tap[out_name + k]
+            _close(errs, 'dz ' + out_name + k, P.grad(out_name + k), inner.grad * (inner.detach() > 0).float(), GRAD_TOL, GRAD_COS)
+    # ---- head of stack 0 (the loss enters here; the gradient of stack 1's input comes from the engine)
+    numel = float(B * 16 * (res // 4) ** 2)
+    a_post, a_x = _leaf(P.act('post0')), _leaf(P.act('xin0'))
+    lin, lbn = ref.linear[0][0], ref.linear[0][1]
+    l = torch.relu(_bn(lbn, R(_conv(lin, a_post))))
+    _close(errs, 'fwd lin0', P.act('lin0'), l.detach(), FWD_TOL)
+    heat = _conv(ref.out_conv[0], l)
+    _close(errs, 'fwd heat0', outs[0].cpu(), heat.detach(), FWD_TOL)
+    tmp = R(_conv(ref.forth_conv[0], l) + a_x)
+    xn = R(_conv(ref.in_conv[0], heat) + tmp)
+    _close(errs, 'fwd xin1', P.act('xin1'), xn.detach(), FWD_TOL)
+    obj = ((heat - heat_t) ** 2).sum() / numel + (xn * P.grad('xin1')).sum()
+    for m_ in (lin, lbn, ref.out_conv[0], ref.forth_conv[0], ref.in_conv[0]):
+        m_.zero_grad()
+    obj.backward()
+    for prefix, m_ in (('linear.0.0.', lin), ('linear.0.1.', lbn), ('out_conv.0.', ref.out_conv[0]), ('forth_conv.0.', ref.forth_conv[0]),
+                       ('in_conv.0.', ref.in_conv[0])):
+        for n, p in m_.named_parameters():
+            if prefix == 'linear.0.0.' and n == 'bias':
+                continue
+            _close(errs, 'grad ' + prefix + n, hip_grads[prefix + n], p.grad, GRAD_TOL, GRAD_COS)
+    _close(errs, 'node-grad post0', P.grad('post0'), a_post.grad * (P.act('post0') > 0).float(), GRAD_TOL, GRAD_COS)
+    assert not errs, '%d local mismatches, first: %s' % (len(errs), errs[:15])
+
+
 def test_graph_replay_refuses_the_fused_low_resolution_launch():
     """A captured fused launch would replay with the launch number of the capture (its barrier tags would match the granules of
     the previous replay): pa_hg_train_step(use_graph=1) must fail loudly while pa_net_set_fused_lowres is on."""

@@ -418,6 +418,34 @@ def test_hip_graph_replay_equals_eager_enqueue(stacks, chan, B):
     assert abs(finals[0][3] - finals[1][3]) < 1e-6 * abs(finals[0][3]) and finals[0][4] == finals[1][4]
 
 
+@pytest.mark.parametrize('stacks,chan,B', [(1, 128, 2), (2, 256, 24)])
+def test_finalize_in_the_consumer_prologue_gives_the_same_bits(stacks, chan, B):
+    """BatchNorm finalize of a residual block's inner tensors (models/asn_stacked_hg.py:19,22) folded into the prologue of the
+    consuming convolution at the low-resolution levels (csrc/bn_fin.h, pa_net_set_fin_prologue) against a finalize launch in front
+    of every consumer: ONE summation order in both forms, so parameters, running statistics and gradients after 3 steps are BITWISE
+    equal -- at the small test size (where even the 64 x 64 level has <= 128 partial rows) and at the benchmark's size."""
+    from pose_adv_aug_amd import _lib
+    from pose_adv_aug_amd.models.asn_stacked_hg import create_hg
+    from pose_adv_aug_amd.utils.optim import RMSprop
+    from pose_adv_aug_amd.data import Augmenter, DeviceBatch
+    from pose_adv_aug_amd.stack_hg import train_step
+    batches = [DeviceBatch.synthetic(B, seed=60 + k) for k in range(2)]
+    finals = []
+    for rows in (0, 128):
+        net = create_hg(stacks, 1, 16, chan, default_batch=B); net.reset_parameters(seed=5); net.train()
+        _lib.check(_lib.lib().pa_net_set_fin_prologue(net._net(B), rows))
+        opt = RMSprop(net, lr=2.5e-4)
+        aug = Augmenter(seed=11)
+        for i in range(3):
+            loss, pckh, pckh_o = train_step(net, opt, aug, batches[i % 2])
+        torch.cuda.synchronize()
+        finals.append((net.flat_params.clone(), net.flat_buffers.clone(), net.flat_grads.clone(), float(loss)))
+        del net, opt
+    assert torch.isfinite(finals[0][2]).all()
+    assert torch.equal(finals[0][0], finals[1][0]) and torch.equal(finals[0][1], finals[1][1]) and torch.equal(finals[0][2], finals[1][2])
+    assert abs(finals[0][3] - finals[1][3]) < 1e-6 * abs(finals[0][3])        # (the reported loss is summed with one float atomic per workgroup)
+
+
 def _blob_dataset(n, res, seed):
     """learnable synthetic people: every joint is a colour-coded Gaussian blob in the image at its location"""
     g = inputs.rng(seed, 7)
