@@ -148,10 +148,18 @@ __global__ __launch_bounds__(NT, (NT == 512 ? 1 : (TW == 16 ? (TH == 4 ? (SPS ==
         const int chunk = tid % CPP;                 // the same for every pass of a thread (256 % CPP == 0)
         const int c = chunk * 8;
         float k0[8], k1[8], k2[8];
-        if (LDMODE != PA_LD_PLAIN) {
-            if (a.fin.rows > 0) {
-                // the input's BatchNorm finalize from the producer's <= 128 partial rows (bn_fin.h) instead of a launch of its own in
-                // front of this kernel; table + scratch sit in the halo region, which nobody writes before the barrier below
+        if (LDMODE != PA_LD_PLAIN && a.fin.rows <= 0) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                k0[j] = a.in.k0[c + j]; k1[j] = a.in.k1[c + j];
+                if (LDMODE == PA_LD_LIN2) k2[j] = a.in.k2[c + j];
+            }
+        }
+        // a.fin.rows > 0: the input's BatchNorm finalize from the producer's <= 128 partial rows (bn_fin.h) instead of a launch of its own
+        // in front of this kernel -- called behind the first batch of staging loads, which are in flight meanwhile.  Table + scratch sit
+        // in the halo region, which nobody writes before the barrier at the end
+        auto fin_constants = [&]() {
+            if constexpr (LDMODE != PA_LD_PLAIN && !TRI) {
                 float* ktab = reinterpret_cast<float*>(halo);
                 pa_bn_fin_prologue<256, CIN>(a.fin, CIN, ktab, ktab + 3 * CIN, blockIdx.x == 0 && blockIdx.y == 0);
 #pragma unroll
@@ -160,14 +168,8 @@ __global__ __launch_bounds__(NT, (NT == 512 ? 1 : (TW == 16 ? (TH == 4 ? (SPS ==
                     if (LDMODE == PA_LD_LIN2) k2[j] = ktab[2 * CIN + c + j];
                 }
                 __syncthreads();
-            } else {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    k0[j] = a.in.k0[c + j]; k1[j] = a.in.k1[c + j];
-                    if (LDMODE == PA_LD_LIN2) k2[j] = a.in.k2[c + j];
-                }
             }
-        }
+        };
         constexpr int UN = LDMODE == PA_LD_LIN2 ? 6 : (TRI ? 9 : 12);      // loads in flight per thread before the first transform
 #pragma unroll
         for (int p0 = 0; p0 < NPASS; p0 += UN) {
@@ -189,6 +191,7 @@ __global__ __launch_bounds__(NT, (NT == 512 ? 1 : (TW == 16 ? (TH == 4 ? (SPS ==
                 ra[u] = *reinterpret_cast<const bf16x8*>(a.in.p + idx);
                 if (LDMODE == PA_LD_LIN2) rq[u] = *reinterpret_cast<const bf16x8*>(a.in.q + idx);
             }
+            if (p0 == 0 && a.fin.rows > 0) fin_constants();
 #pragma unroll
             for (int u = 0; u < UN; ++u) {
                 if ((p0 + u) < NPASS && hp[u] < HP) {
@@ -443,7 +446,7 @@ int pa_launch_conv3x3_tile(const PaConvArgs& a, hipStream_t st, int* stat_rows) 
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
     }
     const int wg3 = tiles128 / 3;
-    if (tri && !small && !half && a.Cin == 128 && bigN && tiles128 % 3 == 0 && wg3 % 8 == 0 && wg3 <= cus && 2 * wg3 > cus &&
+    if (tri && a.fin.rows <= 0 && !small && !half && a.Cin == 128 && bigN && tiles128 % 3 == 0 && wg3 % 8 == 0 && wg3 <= cus && 2 * wg3 > cus &&
         (a.ep.mode != PA_OUT_BWD || pa_bwd_epilogue_lds_ok(a))) {
         if (stat_rows) *stat_rows = wg3;
         if (a.ep.rows_out) *a.ep.rows_out = wg3;

@@ -77,6 +77,8 @@ def train_hg(batches, hg, optimizer_hg, agent_sr, augmenter, epoch, opt, log=pri
         meters.update({'loss_hg': loss, 'pckh': pckh, tag[0]: loss, tag[1]: pckh})
         if i % opt.print_freq == 0 or i == n - 1:
             log('epoch:%d, iters:%d/%d ' % (epoch, i, n) + ' '.join('%s: %.4f' % kv for kv in meters.averages().items()))
+            from .stack_hg import warn_skipped_steps
+            warn_skipped_steps(optimizer_hg, log)         # (fp16 build: a skipped step must not pass unnoticed)
     if meters is None:                                    # an empty feed
         return 0.0, 0.0
     d = meters.averages()

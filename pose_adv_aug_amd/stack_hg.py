@@ -68,6 +68,25 @@ def train_step(net, optimizer, augmenter, batch, want_pckh=True, data=None):
     return loss, pckh[0], pckh_o[0]
 
 
+_SKIPPED_SEEN = {}
+
+
+def warn_skipped_steps(optimizer, log=print):
+    """fp16 build: the engine skips (and counts) an optimizer step whose scaled gradient holds inf / NaN.  Silent skipping would hide a
+    persistent overflow, so the loops report every growth of the counter where they synchronise anyway (at print time).  The counter is
+    process-wide (one device word), so it is tracked per process here, whichever optimizer asked."""
+    from . import _lib
+    if _lib.DTYPE != 'fp16' or not hasattr(optimizer, 'skipped_steps'):
+        return 0
+    n = optimizer.skipped_steps()
+    seen = _SKIPPED_SEEN.get('n', 0)
+    if n > seen:
+        log('WARNING: %d optimizer step(s) skipped for a non-finite fp16 gradient (%d so far): the gradient scale PA_GRAD_SCALE '
+            'overflows this model -- train in the bf16 build or lower the scale' % (n - seen, n))
+        _SKIPPED_SEEN['n'] = n
+    return n - seen
+
+
 def train(batches, net, optimizer, augmenter, epoch, opt, log=print):
     """stack-hg.py:124-189 over a sized feed of DeviceBatches (a list, data.BatchFeed, MPII.batches()).  The meters see
     EVERY iteration (:171-180) through device-side sums; the host synchronises only every print_freq steps."""
@@ -86,6 +105,7 @@ def train(batches, net, optimizer, augmenter, epoch, opt, log=print):
         meters.update({'loss': loss, 'pckh': pckh, 'pckh_origin_res': pckh_o})
         if i % opt.print_freq == 0 or i == n - 1:          # the only host sync
             log('epoch:%d, iters:%d/%d ' % (epoch, i, n) + ''.join('%s: %.4f ' % kv for kv in meters.averages().items()))   # utils/visualizer.py:70-72
+            warn_skipped_steps(optimizer, log)
     if meters is None:                                    # an empty feed
         return 0.0, 0.0
     d = meters.averages()

@@ -3,6 +3,7 @@
 TAG=${1:-r1}
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
+export PA_BENCH_CHILD=1      # bench.py: no nested rocprofv3 child passes, no median pass (fixed step counts)
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$TAG -o bench -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline > gpurun_out/bench_prof_$TAG.log 2>&1
 tail -1 gpurun_out/bench_prof_$TAG.log | cut -c1-300
 f=$(find gpurun_out/prof_$TAG -name "*kernel_stats.csv" | head -1)

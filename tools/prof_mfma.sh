@@ -3,6 +3,7 @@
 TAG=${1:-r1}
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
+export PA_BENCH_CHILD=1      # bench.py: no nested rocprofv3 child passes, no median pass (fixed step counts)
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d gpurun_out/mfma_$TAG -o bench -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-parity > gpurun_out/mfma_$TAG.log 2>&1
 tail -1 gpurun_out/mfma_$TAG.log | cut -c1-120
 python - $TAG > gpurun_out/mfma_summary_$TAG.txt <<'PY'

@@ -3,6 +3,7 @@
 TAG=${1:-r1}
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
+export PA_BENCH_CHILD=1      # bench.py: no nested rocprofv3 child passes, no median pass (fixed step counts)
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C --kernel-trace --output-format csv -d gpurun_out/pmc_${TAG}_$C -o bench -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-parity > gpurun_out/pmc_${TAG}_$C.log 2>&1
   tail -1 gpurun_out/pmc_${TAG}_$C.log | cut -c1-120

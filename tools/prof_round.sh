@@ -2,12 +2,13 @@
 # Everything profiles/<round>_* is made from, in one gpurun call:  bash tools/prof_round.sh round3
 #   d/e  kernel stats of the timed region (multi-stream) and of the roofline pass (single stream) + trace classes
 #   f    PMC HBM traffic (FETCH_SIZE / WRITE_SIZE in separate passes)      g  MFMA busy        rccl  kernel names of one rank through RCCL
-R=${1:-round3}
+R=${1:-round4}
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
+export PA_BENCH_CHILD=1      # bench.py: no nested rocprofv3 child passes, no median pass (fixed step counts)
 mkdir -p gpurun_out
-python bench.py > gpurun_out/${R}_bench_line.json 2> gpurun_out/${R}_bench_line.err
-PA_BENCH_SEQ_OUT=gpurun_out/${R}_seq.json rocprofv3 --kernel-trace --stats --output-format csv rocpd -d gpurun_out/prof_${R} -o bench -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-parity > gpurun_out/${R}_prof_bench.log 2>&1
+env -u PA_BENCH_CHILD python bench.py --keep-profiles > gpurun_out/${R}_bench_line.json 2> gpurun_out/${R}_bench_line.err
+PA_BENCH_SEQ_OUT=gpurun_out/${R}_seq.json rocprofv3 --kernel-trace --stats --output-format csv rocpd -d gpurun_out/prof_${R} -o bench -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-parity --no-traffic --no-floor > gpurun_out/${R}_prof_bench.log 2>&1
 python - $R <<'PY'
 import csv, glob, json, sqlite3, sys, collections
 R = sys.argv[1]

@@ -2,6 +2,7 @@
 # SQ counters for the conv micro-benchmarks
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
+export PA_BENCH_CHILD=1      # bench.py: no nested rocprofv3 child passes, no median pass (fixed step counts)
 cat > /tmp/one.py <<'PY'
 import sys; sys.path.insert(0, '.')
 import ctypes as C, torch
