@@ -29,8 +29,10 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
+# classes 0-5: maps of >= 16384 pixels (32 x 32 and larger at batch 24); the last three: every convolution launch of the smaller maps
+# (16 x 16 ... 4 x 4: latency-bound launches)
 PROF_NAMES = ['conv_fwd_1x1', 'conv_fwd_3x3', 'conv_dgrad_1x1', 'conv_dgrad_3x3', 'conv_wgrad_1x1', 'conv_wgrad_3x3',
-              'stem_fwd_7x7', 'stem_wgrad_7x7', 'lowres_fused_fwd']
+              'stem_fwd_7x7', 'stem_wgrad_7x7', 'lowres_fused_fwd', 'conv_fwd_lowres', 'conv_dgrad_lowres', 'conv_wgrad_lowres']
 HBM_PEAK = 8.0e12          # B/s   (MI355X_MICROARCH.md)
 MFMA_PEAK = 2.5e15         # FLOP/s dense bf16
 
@@ -363,7 +365,7 @@ def main():
             c = measured_pmc['classes'][dom['kernel']]
             traffic = {'hbm_bytes_per_launch': round(c['hbm_bytes_per_launch'], 1), 'launches_profiled': c['launches_profiled'],
                        'whole_step': {'fetch_bytes_x2': round(measured_pmc['fetch_bytes_per_step_x2']), 'write_bytes': round(measured_pmc['write_bytes_per_step'])},
-                       'source': 'measured in this run: rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) and --pmc WRITE_SIZE child passes of this command, 4 steps each'}
+                       'source': 'measured in this run: rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) and --pmc WRITE_SIZE child passes of this command, 7 steps each; per class by launch order'}
         else:
             for name in ('round4_pmc.json', 'round3_pmc.json', 'round2_pmc.json'):
                 pmc_path = os.path.join(ROOT, 'profiles', name)

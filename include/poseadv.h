@@ -283,14 +283,15 @@ int pa_net_lowres_timing(pa_net* net, long long* counters);
 int pa_net_set_fused_lowres(pa_net* net, int on);
 /* Per-launch HIP-event timing of the MFMA kernels on the net's stream (bench.py's `roofline`).
  * begin: start recording; report: synchronise, stop recording and fill out_host[c][4] = {total ms, launches, algorithmic
- * bytes, flops} for the classes c = 0 fwd 1x1, 1 fwd 3x3, 2 dgrad 1x1, 3 dgrad 3x3, 4 wgrad 1x1, 5 wgrad 3x3, 6 stem fwd,
- * 7 stem wgrad, 8 fused low-resolution forward launch (pa_net_set_fused_lowres).  out_host is a HOST array of `cap_classes`
- * rows; classes beyond the capacity are dropped (never written).  Returns the library's number of classes (PA_PROF_CLASSES = 9
- * today) through *n_classes when it is not NULL. */
-#define PA_PROF_CLASSES 9
+ * bytes, flops} for the classes c = 0 fwd 1x1, 1 fwd 3x3, 2 dgrad 1x1, 3 dgrad 3x3, 4 wgrad 1x1, 5 wgrad 3x3 (maps of >= 16384
+ * pixels: 32 x 32 and larger at batch 24), 6 stem fwd, 7 stem wgrad, 8 fused low-resolution forward launch
+ * (pa_net_set_fused_lowres), 9 / 10 / 11 forward / data-gradient / weight-gradient launches of the smaller maps (latency-bound).
+ * out_host is a HOST array of `cap_classes` rows; classes beyond the capacity are dropped (never written).  Returns the library's
+ * number of classes (PA_PROF_CLASSES = 12 today) through *n_classes when it is not NULL. */
+#define PA_PROF_CLASSES 12
 int pa_net_profile_begin(pa_net* net);
 int pa_net_profile_report(pa_net* net, double* out_host, int cap_classes, int* n_classes);
-/* class (0..8 as above) of every timed launch of the last reported pass, in launch order: returns their number and fills
+/* class (0..11 as above) of every timed launch of the last reported pass, in launch order: returns their number and fills
  * out_host[0..min(cap, n)) (HOST array).  tools/trace_classes.py matches a rocprofv3 kernel trace of the same pass with it. */
 int pa_net_profile_classes(const pa_net* net, int32_t* out_host, int cap);
 /* BatchNorm finalize (models/asn_stacked_hg.py:19,22,25 in training mode) of a residual block's inner tensors at the low-resolution

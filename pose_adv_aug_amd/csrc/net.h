@@ -68,8 +68,12 @@ struct Act {                 // NHWC bf16 activation; `bn` != null means BatchNo
 struct Net;
 
 // optional per-launch timing of the MFMA kernels with HIP events (bench.py's roofline object)
+// classes 0-5: the maps with >= PA_PROF_LOW_M pixels (32 x 32 and larger at batch 24: bandwidth- / MFMA-shaped launches); 9-11: every
+// convolution launch below that (16 x 16 ... 4 x 4: bound by launch / staging / epilogue LATENCY, DESIGN.md section 4 -- averaging them
+// into the classes above says nothing about either)
 enum { PA_PROF_FWD1 = 0, PA_PROF_FWD3, PA_PROF_DGRAD1, PA_PROF_DGRAD3, PA_PROF_WGRAD1, PA_PROF_WGRAD3, PA_PROF_STEM_FWD,
-       PA_PROF_STEM_WGRAD, PA_PROF_LOWRES_FWD, PA_PROF_NCLS };
+       PA_PROF_STEM_WGRAD, PA_PROF_LOWRES_FWD, PA_PROF_LOW_FWD, PA_PROF_LOW_DGRAD, PA_PROF_LOW_WGRAD, PA_PROF_NCLS };
+#define PA_PROF_LOW_M 16384
 struct ProfEntry { hipEvent_t e0, e1; int cls; double bytes, flops; };
 struct Prof {
     bool on = false;

@@ -495,7 +495,7 @@ int Net::conv_fwd(ConvLayer& c, const PaOperand& in, int B_, int H, int W, const
     if ((ablate() & 128) && H <= ablate_h()) return 0;
     { const double M = (double)B_ * H * W;
       cnt((c.k == 7 ? 2.0 * B_ * 4.0 * H * W * 4 : opb(in, M * a.Cin)) + opb(add1, M * a.Cout) + opb(add2, M * a.Cout) + 2.0 * a.Cout * a.taps * a.Cin, 2.0 * M * a.Cout); }
-    ProfEntry* pe = prof.begin(c.k == 7 ? PA_PROF_STEM_FWD : (c.k == 3 ? PA_PROF_FWD3 : PA_PROF_FWD1), wb, wf, st);
+    ProfEntry* pe = prof.begin(c.k == 7 ? PA_PROF_STEM_FWD : ((long)B_ * H * W < PA_PROF_LOW_M ? PA_PROF_LOW_FWD : (c.k == 3 ? PA_PROF_FWD3 : PA_PROF_FWD1)), wb, wf, st);
     int rc = (c.k == 3 && (ablate() & 8)) ? 0 : ((c.k == 7) ? pa_launch_stem_conv(a, st) : pa_launch_conv(a, st));
     prof.end(pe, st);
     TRY(rc);
@@ -522,7 +522,7 @@ int Net::conv_dgrad(ConvLayer& c, const PaOperand& dy, int B_, int H, int W, con
         if ((!off && a.taps == 1 && pa_conv1x1_tile_supported(a)) || (!off3 && a.taps == 9 && pa_conv3x3_tile_supported(a))) { a.dz_out = dz_out; if (dz_done) *dz_done = true; }
     }
     double wb, wf; conv_work(B_ * H * W, c.Cin, c.Cout, c.taps(), false, wb, wf);
-    ProfEntry* pe = prof.begin(c.k == 3 ? PA_PROF_DGRAD3 : PA_PROF_DGRAD1, wb, wf, st);
+    ProfEntry* pe = prof.begin((long)B_ * H * W < PA_PROF_LOW_M ? PA_PROF_LOW_DGRAD : (c.k == 3 ? PA_PROF_DGRAD3 : PA_PROF_DGRAD1), wb, wf, st);
     if ((c.k == 3 && (ablate() & 8)) || (c.k == 1 && (ablate() & 16)) || ((ablate() & 256) && H <= ablate_h())) { if (a.ep.rows_out) *a.ep.rows_out = 1; prof.end(pe, st); return 0; }
     { const double M = (double)B_ * H * W;
       cnt(opb(dy, M * a.Cin) + opb(add1, M * a.Cout) + opb(add2, M * a.Cout) + (ep.mode == PA_OUT_BWD ? 2.0 * M * a.Cout : 0.0) + 2.0 * a.Cout * a.taps * a.Cin,
@@ -538,7 +538,7 @@ int Net::conv_wgrad(ConvLayer& c, const PaOperand& dy, const PaOperand& x, int B
     a.B = B_; a.H = H; a.W = W; a.Cin = c.pcin; a.Cout = c.pcout; a.taps = c.k == 7 ? 1 : c.taps(); a.splits = c.splits;
     double wb, wf; conv_work(B_ * H * W, c.k == 7 ? 147 : c.Cin, c.Cout, c.k == 7 ? 1 : c.taps(), true, wb, wf);
     if (c.k == 7) wb = 2.0 * B_ * (4.0 * H * W * 4 + (double)H * W * 64) + 4.0 * 64 * 147;
-    const int cls = c.k == 7 ? PA_PROF_STEM_WGRAD : (c.k == 3 ? PA_PROF_WGRAD3 : PA_PROF_WGRAD1);
+    const int cls = c.k == 7 ? PA_PROF_STEM_WGRAD : ((long)B_ * H * W < PA_PROF_LOW_M ? PA_PROF_LOW_WGRAD : (c.k == 3 ? PA_PROF_WGRAD3 : PA_PROF_WGRAD1));
     if (ablate() & 2) return 0;
     if ((ablate() & 32) && c.k == 1 && (long)B_ * H * W >= 16384) return 0;      // timing bound: what fusing the large 1x1 weight gradients into their data gradients could save at most
     if ((ablate() & 64) && c.k == 3 && (long)B_ * H * W >= 16384) return 0;

@@ -2,7 +2,8 @@
 parsers tools/pmc_to_json.py / tools/prof_pmc.sh share with it.
 
   traffic : two `rocprofv3 --pmc <C> --kernel-trace` passes (C = FETCH_SIZE, WRITE_SIZE -- separate passes, never combined with
-            sys / runtime / hip / hsa traces) of `python bench.py --steps 3 --warmup 1 --no-roofline ...` (4 steps).  Counter unit:
+            sys / runtime / hip / hsa traces) of `python bench.py --steps 3 --warmup 1 ...` (4 steps + the 3 steps of its roofline leg, whose
+            launches are matched with the engine's class sequence).  Counter unit:
             KiB as reported; FETCH_SIZE x2 (gfx950 tallies a wide coalesced 128-byte request at 64 bytes,
             /opt/skills/guides/MI355X_MICROARCH.md section HBM).
   trace   : one `rocprofv3 --kernel-trace` pass whose roofline leg (single stream) is matched launch by launch with the engine's
@@ -79,6 +80,38 @@ def parse_pmc(fetch_csv, write_csv, steps):
                         for k, v in per_kernel.items()}}
 
 
+MFMA_KERNELS = ('conv1x1_tile_kernel', 'conv3x3_tile_kernel', 'conv_igemm_kernel', 'wgrad_tile_kernel', 'conv_wgrad_kernel', 'stem_conv',
+                'stem_wgrad', 'lowres_fwd_kernel')
+
+
+def parse_pmc_sequence(fetch_csv, write_csv, seq_path, steps):
+    """Per-class traffic with bench.py's OWN classes (they depend on the map size, which a kernel name does not show): the child pass
+    also runs the roofline leg, whose MFMA-kernel launches are the last len(sequence) MFMA dispatches of the counter file, in launch
+    order (single stream) -- the matching tools/trace_classes.py does for durations.  Whole-step totals over all `steps` steps."""
+    seq = json.load(open(seq_path))
+    names, order = seq['classes'], seq['sequence']
+    out = collections.defaultdict(lambda: {'fetch_bytes': 0.0, 'write_bytes': 0.0, 'launches': 0})
+    tot = {}
+    for C, path in (('FETCH_SIZE', fetch_csv), ('WRITE_SIZE', write_csv)):
+        rows = [(int(r['Dispatch_Id']), r['Kernel_Name'], float(r['Counter_Value']) * 1024.0 * (2.0 if C == 'FETCH_SIZE' else 1.0))
+                for r in csv.DictReader(open(path)) if r['Counter_Name'] == C]
+        rows.sort()
+        tot[C] = sum(v for _, _, v in rows)
+        mf = [r for r in rows if any(k in r[1] for k in MFMA_KERNELS) and 'reduce' not in r[1]]
+        if len(mf) < len(order):
+            raise ValueError('fewer MFMA dispatches than the class sequence')
+        for (_, _, v), c in zip(mf[-len(order):], order):
+            o = out[names[c]]
+            if C == 'FETCH_SIZE':
+                o['fetch_bytes'] += v; o['launches'] += 1
+            else:
+                o['write_bytes'] += v
+    classes = {k: {'hbm_bytes_per_launch': (v['fetch_bytes'] + v['write_bytes']) / max(1, v['launches']),
+                   'fetch_bytes_per_launch_x2': v['fetch_bytes'] / max(1, v['launches']),
+                   'write_bytes_per_launch': v['write_bytes'] / max(1, v['launches']), 'launches_profiled': v['launches']} for k, v in out.items()}
+    return {'classes': classes, 'fetch_bytes_per_step_x2': tot['FETCH_SIZE'] / steps, 'write_bytes_per_step': tot['WRITE_SIZE'] / steps}
+
+
 def _env():
     e = dict(os.environ, PA_BENCH_CHILD='1', TMPDIR='/tmp')
     for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'POSEADV_DIST_INIT', 'POSEADV_FORCE_DIST'):
@@ -102,17 +135,19 @@ def measure_traffic(bench_args, timeout=240, keep=False):
     d = _workdir(keep)
     try:
         paths = {}
+        seq = os.path.join(d, 'seq.json')
         for C in ('FETCH_SIZE', 'WRITE_SIZE'):
             out = os.path.join(d, C)
+            # 1 warm-up + 3 timed steps, then the roofline leg's 3 steps (single stream, class sequence recorded): 7 steps of the same work
             cmd = ['rocprofv3', '--pmc', C, '--kernel-trace', '--output-format', 'csv', '-d', out, '-o', 'bench', '--', sys.executable,
-                   os.path.join(ROOT, 'bench.py'), '--steps', '3', '--warmup', '1', '--no-cpu-baseline', '--no-roofline', '--no-parity', '--no-traffic',
+                   os.path.join(ROOT, 'bench.py'), '--steps', '3', '--warmup', '1', '--no-cpu-baseline', '--no-parity', '--no-traffic',
                    '--no-floor'] + list(bench_args)
-            r = subprocess.run(cmd, cwd=ROOT, env=_env(), capture_output=True, text=True, timeout=timeout)
+            r = subprocess.run(cmd, cwd=ROOT, env=dict(_env(), PA_BENCH_SEQ_OUT=seq), capture_output=True, text=True, timeout=timeout)
             f = glob.glob(os.path.join(out, '**', '*counter_collection.csv'), recursive=True)
-            if r.returncode != 0 or not f:
+            if r.returncode != 0 or not f or not os.path.isfile(seq):
                 return None
             paths[C] = f[0]
-        return parse_pmc(paths['FETCH_SIZE'], paths['WRITE_SIZE'], 4.0)
+        return parse_pmc_sequence(paths['FETCH_SIZE'], paths['WRITE_SIZE'], seq, 7.0)
     except (subprocess.TimeoutExpired, OSError, KeyError, ValueError):
         return None
     finally:

@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 export PA_BENCH_CHILD=1      # bench.py: no nested rocprofv3 child passes, no median pass (fixed step counts)
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C --kernel-trace --output-format csv -d gpurun_out/pmc_${TAG}_$C -o bench -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-parity > gpurun_out/pmc_${TAG}_$C.log 2>&1
+  PA_BENCH_SEQ_OUT=gpurun_out/pmc_${TAG}_seq.json rocprofv3 --pmc $C --kernel-trace --output-format csv -d gpurun_out/pmc_${TAG}_$C -o bench -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-parity --no-traffic --no-floor > gpurun_out/pmc_${TAG}_$C.log 2>&1
   tail -1 gpurun_out/pmc_${TAG}_$C.log | cut -c1-120
 done
 python - $TAG > gpurun_out/pmc_summary_$TAG.txt <<'PY'
@@ -22,8 +22,8 @@ for C in ('FETCH_SIZE', 'WRITE_SIZE'):
         k = r['Kernel_Name'][:70]
         per[k][0] += float(r['Counter_Value']); per[k][1] += 1
     tot[C] = per
-steps = 4.0
-print('# rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) -- python bench.py --steps 3 --warmup 1   (4 steps)')
+steps = 7.0          # 1 warm-up + 3 timed steps + the 3 steps of the roofline leg
+print('# rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) -- python bench.py --steps 3 --warmup 1   (4 steps + the 3 steps of its single-stream roofline leg)')
 print('# units: KiB as reported (x1024 bytes); gfx950 FETCH_SIZE under-reports wide coalesced reads by 2x (MI355X_MICROARCH.md): corrected column = 2x')
 keys = sorted(set(tot.get('FETCH_SIZE', {})) | set(tot.get('WRITE_SIZE', {})), key=lambda k: -(tot.get('FETCH_SIZE', {}).get(k, [0])[0] * 2 + tot.get('WRITE_SIZE', {}).get(k, [0])[0]))
 gf = gw = 0
