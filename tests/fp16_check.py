@@ -107,6 +107,35 @@ def main():
     ok('8-stack 384: stem gradient magnitude survives (no underflow)', 0.5 < float(stem.norm() / rs.norm()) < 2.0 and float((stem == 0).float().mean()) < 0.01,
        (float(stem.norm() / rs.norm()), float((stem == 0).float().mean())))
 
+    # ---- BASELINE configs[4] at ITS OWN size (8-stack, 384x384, B = 16 per GPU): the fp32 oracle takes minutes there, so the checks are
+    # the size-independent properties -- the loss the engine reports IS sum_stacks mean((out - gaussian(pts))^2) of the heat maps it
+    # returns, every gradient is finite, none of the 8 stacks' or the stem's gradients vanished in half's range, an optimizer step is
+    # applied (not skipped) and the next step's loss is finite and lower on the same batch
+    B16 = 16
+    del net, ref
+    torch.cuda.empty_cache()
+    _, net = _hg_pair(8, chan, B16, res, seed=5)
+    img = t(inputs.images(33, B16, res)); pts = inputs.heat_pts(34, B16, res=res // 4)
+    heat = t(inputs.heatmaps_from_pts(pts, res=res // 4))
+    net.train()
+    opt16 = RMSprop(net, lr=2.5e-4, alpha=0.99, eps=1e-8)
+    loss, outs = net.loss_and_backward(img.cuda(), t(pts).cuda(), want_outputs=True)
+    again = sum(float(((o.cpu() - heat) ** 2).mean()) for o in outs)
+    ok('8-stack 384 B=16: reported loss == loss recomputed from the returned heat maps', abs(float(loss) - again) / again < 1e-3, (float(loss), again))
+    g = net.flat_grads
+    ok('8-stack 384 B=16: gradients finite', bool(torch.isfinite(g).all()))
+    gd = dict(net.named_grads())
+    dead = [n for n in ['conv1.weight'] + ['hg.%d.skip1.0.conv2.weight' % i for i in range(8)] + ['out_conv.%d.weight' % i for i in range(8)]
+            if float(gd[n].abs().max()) == 0.0 or float((gd[n] == 0).float().mean()) > 0.05]
+    ok('8-stack 384 B=16: no stack lost its gradient to underflow', not dead, dead)
+    before = net.flat_params.clone(); sk0 = opt16.skipped_steps()
+    opt16.step()
+    loss2, _ = net.loss_and_backward(img.cuda(), t(pts).cuda())
+    ok('8-stack 384 B=16: the step is applied and the loss falls', opt16.skipped_steps() == sk0 and not torch.equal(net.flat_params, before)
+       and bool(torch.isfinite(net.flat_params).all()) and np.isfinite(float(loss2)) and float(loss2) < float(loss), (float(loss), float(loss2)))
+    del net, opt16
+    torch.cuda.empty_cache()
+
     # ---- a few RMSprop steps: the scaled gradients give the oracle's trajectory
     B, res, chan = 2, 128, 128
     ref, net = _hg_pair(1, chan, B, res, seed=17)

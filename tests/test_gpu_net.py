@@ -486,7 +486,7 @@ def test_training_trajectory_tracks_the_oracle_over_150_steps():
     assert abs(l_dev[0] - l_ref[0]) / l_ref[0] < 1e-2
     tail = lambda v: float(np.mean(v[-20:]))
     assert tail(l_ref) < l_ref[0] / 3 and tail(l_dev) < l_dev[0] / 3, (l_ref[0], tail(l_ref), l_dev[0], tail(l_dev))
-    assert abs(tail(l_dev) - tail(l_ref)) / tail(l_ref) < 0.15, (tail(l_dev), tail(l_ref))
+    assert abs(tail(l_dev) - tail(l_ref)) / tail(l_ref) < 0.05, (tail(l_dev), tail(l_ref))       # observed 0.021 (round 4, three runs: deterministic)
     # held-out batch, eval mode (running statistics of 150 steps), PCKh by the oracle's Evaluation on each side's maps
     sl = slice(20, 24)
     ref.eval(); net.eval()
@@ -496,8 +496,10 @@ def test_training_trajectory_tracks_the_oracle_over_150_steps():
     idx = list(range(16))
     a_ref, a_dev = float(opl.accuracy(o_ref, t(heat[sl]), idx)[0]), float(opl.accuracy(o_dev, t(heat[sl]), idx)[0])
     v_ref, v_dev = float(((o_ref - t(heat[sl])) ** 2).mean()), float(((o_dev - t(heat[sl])) ** 2).mean())
+    print('TRAJECTORY observed: tail loss dev %.6g ref %.6g (rel %.4f); held-out PCKh dev %.4f ref %.4f; held-out mse dev %.6g ref %.6g (rel %.4f)'
+          % (tail(l_dev), tail(l_ref), abs(tail(l_dev) - tail(l_ref)) / tail(l_ref), a_dev, a_ref, v_dev, v_ref, abs(v_dev - v_ref) / v_ref))
     assert a_ref > 0.2 and a_dev > 0.2, (a_ref, a_dev)
-    assert abs(a_dev - a_ref) <= 0.12 and abs(v_dev - v_ref) / v_ref < 0.2, (a_ref, a_dev, v_ref, v_dev)
+    assert abs(a_dev - a_ref) <= 0.08 and abs(v_dev - v_ref) / v_ref < 0.04, (a_ref, a_dev, v_ref, v_dev)      # observed 0.036 and 0.016: twice that
     # ... and the engine's own metric kernel on its own maps says the same as the oracle code on those maps
     assert abs(float(net.accuracy(idx)[0]) - a_dev) < 1e-4
 

@@ -128,7 +128,7 @@ def _workdir(keep):
     return tempfile.mkdtemp(prefix='inrun_prof_', dir=base)
 
 
-def measure_traffic(bench_args, timeout=240, keep=False):
+def measure_traffic(bench_args, timeout=120, keep=False):
     """bench_args: the workload flags of the running bench.py (--bs / --stacks / ...).  -> parse_pmc() dict or None."""
     if not available():
         return None
@@ -155,7 +155,7 @@ def measure_traffic(bench_args, timeout=240, keep=False):
             shutil.rmtree(d, ignore_errors=True)
 
 
-def measure_trace(bench_args, steps=5, timeout=240, keep=False):
+def measure_trace(bench_args, steps=5, timeout=120, keep=False):
     """One --kernel-trace pass; -> {class: {'avg_us', 'launches_per_step', 'ms_per_step'}} of its roofline leg, or None."""
     if not available():
         return None
