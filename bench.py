@@ -228,6 +228,7 @@ def main():
     ap.add_argument('--res', type=int, default=256, help='network input resolution (SURVEY.md C5: --stacks 8 --res 384 --bs 16)')
     ap.add_argument('--dtype', choices=['bf16', 'fp16'], default='bf16', help='16-bit storage / MFMA operand type (BASELINE configs[4]: fp16)')
     ap.add_argument('--overlap', type=int, default=0, help='1 (N > 1): exchange each stack\'s hourglass gradients during the rest of the backward pass (RMSprop(overlap=True))')
+    ap.add_argument('--fin-rows', type=int, default=-1, help='>= 0: pa_net_set_fin_prologue(rows) -- row limit of the BatchNorm finalize in the consumer\'s prologue, 0 = every finalize a launch (A/B; default: the library\'s 128)')
     ap.add_argument('--graph', type=int, default=0, help='1: forward + backward replayed from a captured HIP graph (pa_hg_train_step)')
     ap.add_argument('--single-stream', type=int, default=0, help='1: the engine\'s side / weight-gradient streams off for the timed region too (experiments)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -269,6 +270,8 @@ def main():
     net.train()
     if args.single_stream:
         _lib.check(_lib.lib().pa_net_set_multi_stream(net._net(B), 0))
+    if args.fin_rows >= 0:
+        _lib.check(_lib.lib().pa_net_set_fin_prologue(net._net(B), args.fin_rows))
 
     def sync():
         if world > 1:

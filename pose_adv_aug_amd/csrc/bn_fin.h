@@ -12,10 +12,10 @@
 //
 // ONE summation order for <= PA_FIN_SMALL_ROWS rows, used by BOTH forms: sixteen interleaved chains p_j = rows j, j+16, j+32, ...
 // added in increasing order (<= 8 rows each), combined by a stride-halving tree: q_i = p_i + p_(i+8), r_i = q_i + q_(i+4),
-// s_i = r_i + r_(i+2), total = s_0 + s_1.  Sixteen independent chains put every load of a thread in flight at once (the finalize is
-// one L2 round trip, not rows / 8 of them), and the tree lets G = 1, 2, 4 or 8 threads share a channel pair -- each sums the chains
-// congruent to its index mod G and runs the tree down to stride G locally.  The prologue and the launch give the same bits, so the
-// choice between them (Net::fin_rows_max, PA_FIN_PROLOGUE in tuning builds) never changes a result.
+// s_i = r_i + r_(i+2), total = s_0 + s_1.  Sixteen independent chains keep many row loads in flight (the finalize is two L2 round
+// trips, not rows / 8 of them).  FOUR threads share a channel pair: thread g sums the chains g, g+4, g+8, g+12 and runs the first two
+// tree levels locally, the last two go through LDS.  The prologue and the launch give the same bits, so the choice between them
+// (Net::fin_rows_max, PA_FIN_PROLOGUE in tuning builds) never changes a result.
 #pragma once
 #include "common.h"
 
@@ -37,34 +37,52 @@ struct PaBnFin {
     int update_running;
 };
 
-// chains j0, j0 + G, ... (16 / G of them) of the channel PAIR (c2, c2 + 1), tree run down to stride G: the thread's partial of the pair
-// as {sum[c2], sq[c2], sum[c2+1], sq[c2+1]}.  All (16 / G) x 8 row loads are independent 16-byte loads.
-template <int G>
-__device__ __forceinline__ f32x4 pa_fin_partial(const float* stats, int rows, int C, int c2, int j0) {
-    constexpr int NC = 16 / G;
-    f32x4 p[NC];
+// chains g, g + 4, g + 8, g + 12 of the channel PAIR (c2, c2 + 1), first two tree levels applied: the thread's partial of the pair as
+// {sum[c2], sq[c2], sum[c2+1], sq[c2+1]}.  Two chains = 16 independent 16-byte loads at a time (64 registers in flight).
+__device__ __forceinline__ f32x4 pa_fin_partial4(const float* stats, int rows, int C, int c2, int g) {
+    f32x4 p[4];
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    const unsigned rstride = (unsigned)C * 2u;                     // floats per row (32-bit offsets: a statistics buffer is a few MB)
 #pragma unroll
-    for (int i = 0; i < NC; ++i) {
-        f32x4 v[8];
-        const int j = j0 + i * G;
+    for (int i0 = 0; i0 < 4; i0 += 2) {
+        f32x4 v[2][8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int r = j + 16 * u;
-            const int rc = r < rows ? r : 0;                       // clamped, unconditional: every load of the thread in flight
-            v[u] = *reinterpret_cast<const f32x4*>(stats + ((size_t)rc * C + c2) * 2);
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int r = g + 4 * (i0 + d) + 16 * u;
+                const unsigned rc = r < rows ? (unsigned)r : 0u;    // clamped, unconditional: every load of the batch in flight
+                v[d][u] = *reinterpret_cast<const f32x4*>(stats + rc * rstride + (unsigned)c2 * 2u);
+            }
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+            f32x4 acc = zero;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += (g + 4 * (i0 + d) + 16 * u < rows) ? v[d][u] : zero;      // (rows beyond the end add +0: straight-line code, same bits in both forms)
+            p[i0 + d] = acc;
         }
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int u = 0; u < 8; ++u) acc += (j + 16 * u < rows) ? v[u] : zero;      // (rows beyond the end add +0: straight-line code, same bits in both forms)
-        p[i] = acc;
+        // (no barrier between the two halves: all 32 loads of the thread in flight at once -- one L2 round trip)
     }
-    // stride-halving tree over this thread's chains: chain index j0 + i * G pairs with (j0 + i * G) + 8, + 4, ... while the stride >= G
+    // chains g, g+4, g+8, g+12: stride 8 first, then stride 4
+    return (p[0] + p[2]) + (p[1] + p[3]);
+}
+
+// ONE chain (rows j, j + 16, ...: <= 8 loads, one round trip) of the channel pair: the launch form has threads to spare and gives every
+// chain its own thread; the sixteen partials go through the same tree (stride 8, 4, 2, 1) in LDS
+__device__ __forceinline__ f32x4 pa_fin_chain16(const float* stats, int rows, int C, int c2, int j) {
+    f32x4 v[8];
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    const unsigned rstride = (unsigned)C * 2u;
 #pragma unroll
-    for (int n = NC; n > 1; n >>= 1)
+    for (int u = 0; u < 8; ++u) {
+        const int r = j + 16 * u;
+        const unsigned rc = r < rows ? (unsigned)r : 0u;
+        v[u] = *reinterpret_cast<const f32x4*>(stats + rc * rstride + (unsigned)c2 * 2u);
+    }
+    f32x4 acc = zero;
 #pragma unroll
-        for (int i = 0; i < n / 2; ++i) p[i] = p[i] + p[i + n / 2];
-    return p[0];
+    for (int u = 0; u < 8; ++u) acc += (j + 16 * u < rows) ? v[u] : zero;
+    return acc;
 }
 
 // the arithmetic of the two finalizes, contraction off: the same roundings wherever it is inlined
@@ -91,44 +109,36 @@ __device__ __forceinline__ void pa_bn_bwd_consts(float S1, float S2, float count
     kC = -s * S1 / count - b * mu;
 }
 
-// Consumer prologue: all NT threads of the workgroup; C <= 2 * NT channels, C % 2 == 0.  k (LDS, 3 * KS floats: k[c], k[KS + c], k[2 * KS + c])
+// Consumer prologue: all NT threads of the workgroup; C <= NT channels, C % 2 == 0.  k (LDS, 3 * KS floats: k[c], k[KS + c], k[2 * KS + c])
 // receives {scale, shift} or {kA, kB, kC}; scratch = 4 * NT floats of LDS.  `writer`: this workgroup stores the results to global memory.
 // Ends with a barrier: k is complete for every thread when it returns.
+// Inlined ONLY into kernel instances of their own (template parameter FIN of conv_igemm_kernel / conv3x3_tile_kernel, chosen by the
+// launchers when a launch brings a pending finalize): the first version was compiled into every BatchNorm-on-load instance with all
+// sixteen chains' loads in flight and cost those kernels 40 - 100 registers, spills and occupancy whether a launch carried a finalize
+// or not (+0.15 ms per step, +2 ms at 8 stacks, found by running the round-3 tree on the same box: tools/ab_r3.sh)
 template <int NT, int KS>
 __device__ __forceinline__ void pa_bn_fin_prologue(const PaBnFin& f, int C, float* k, float* scratch, bool writer) {
     const int tid = threadIdx.x;
-    const int CP = C >> 1;                                    // channel pairs
-    const int tpp = NT / CP;                                  // threads per pair available
-    const int G = tpp >= 8 ? 8 : (tpp >= 4 ? 4 : (tpp >= 2 ? 2 : 1));
-    const int pr = tid % CP, g = tid / CP;
-    f32x4* sc = reinterpret_cast<f32x4*>(scratch);            // [G][CP]
-    if (g < G) {
-        f32x4 s;
-        if (G == 8) s = pa_fin_partial<8>(f.stats, f.rows, C, 2 * pr, g);
-        else if (G == 4) s = pa_fin_partial<4>(f.stats, f.rows, C, 2 * pr, g);
-        else if (G == 2) s = pa_fin_partial<2>(f.stats, f.rows, C, 2 * pr, g);
-        else s = pa_fin_partial<1>(f.stats, f.rows, C, 2 * pr, 0);
-        sc[g * CP + pr] = s;
+    const int CP = C >> 1;                                    // channel pairs; four threads each
+    f32x4* sc = reinterpret_cast<f32x4*>(scratch);            // [4][CP]
+#pragma unroll 1
+    for (int w = tid; w < 4 * CP; w += NT) {                  // (C = 256 at 256 threads: two rounds)
+        const int pr = w % CP, g = w / CP;
+        sc[g * CP + pr] = pa_fin_partial4(f.stats, f.rows, C, 2 * pr, g);
     }
     __syncthreads();
-    if (tid < C) {
-        const int c = tid, half = c & 1;
-        // the remaining tree levels (strides G/2 ... 1) over the G partials of the channel's pair
-        float a[8], b[8];
+#pragma unroll 1
+    for (int c = tid; c < C; c += NT) {
+        const int half = c & 1;
+        // the last two tree levels (strides 2, 1) over the four partials of the channel's pair
+        float a[4], b[4];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const f32x4 v = sc[(i < G ? i : 0) * CP + (c >> 1)];
+        for (int i = 0; i < 4; ++i) {
+            const f32x4 v = sc[i * CP + (c >> 1)];
             a[i] = half ? v[2] : v[0]; b[i] = half ? v[3] : v[1];
         }
-        if (G >= 8) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { a[i] += a[i + 4]; b[i] += b[i + 4]; }
-        }
-        if (G >= 4) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i) { a[i] += a[i + 2]; b[i] += b[i + 2]; }
-        }
-        if (G >= 2) { a[0] += a[1]; b[0] += b[1]; }
+        a[0] += a[2]; a[1] += a[3]; b[0] += b[2]; b[1] += b[3];
+        a[0] += a[1]; b[0] += b[1];
         const f32x2 t = {a[0], b[0]};
         if (!f.bwd) {
             float s, sh, mu, is, var;

@@ -58,9 +58,17 @@ template <int N> __device__ __forceinline__ void pa_wait_vmcnt() {
 // per wave between two barriers instead of 16, and the launch is ONE full round of 256 workgroups instead of 768 on 512 slots.
 // 8 waves = 4 (pixels: 6 fragments of 16 each) x 2 (channels: 4 fragments); LDS 135 KB of halos + a ring of 3 slices: one workgroup
 // per CU, whose memory phases (staging, epilogue) run as chip-wide bursts.
-template <int CIN, int BN, int LDMODE, int TW = 16, int TH = 8, int SPS = 1, bool PF = false, int NT = 256>
+// FIN: the instance that can carry the input's BatchNorm finalize in its prologue (bn_fin.h): instantiated for the tilings the maps with
+// <= 128 statistics rows use (launch_tile_shape); all other instances are the plain kernel.
+// PA_TUNING builds only: a.dbg -- phase ablation (1 no K loop, 2 no epilogue, 4 no staging: wrong results, timing) and bit 8, per-workgroup tap rotation
+template <int CIN, int BN, int LDMODE, int TW = 16, int TH = 8, int SPS = 1, bool PF = false, int NT = 256, bool FIN = false>
 __global__ __launch_bounds__(NT, (NT == 512 ? 1 : (TW == 16 ? (TH == 4 ? (SPS == 1 ? 3 : 2) : 2) : 1))) void conv3x3_tile_kernel(PaConvArgs a) {
     constexpr bool TRI = NT == 512;
+#ifdef PA_TUNING
+    const int dbg = a.dbg;
+#else
+    constexpr int dbg = 0;
+#endif
     constexpr int NW = NT / 64, WM = NW / 2;                             // waves; waves along the pixels (2 along the channels)
     constexpr int BM = TRI ? 384 : ((TW == 16 && TH == 4) ? 64 : 128);
     constexpr int IMG = BM / (TW * TH), PW = TW + 2, PHh = TH + 2, HP = IMG * PHh * PW;   // 180 / 108 / 200 / 288 / 540 halo pixels
@@ -126,7 +134,7 @@ __global__ __launch_bounds__(NT, (NT == 512 ? 1 : (TW == 16 ? (TH == 4 ? (SPS ==
     }
     // tap rotation (a.dbg & 8): workgroup i walks the taps in the order rot, rot + 1, ... (mod 9), rot = i % 9 -- every workgroup of a launch
     // streams the SAME 295 KB of weights; started together they all pull the same slice from the same L2 channels at the same time
-    const int rot = (a.dbg & 8) ? (int)(blockIdx.x % 9) : 0;
+    const int rot = (dbg & 8) ? (int)(blockIdx.x % 9) : 0;
     auto ptap = [&](int ltap) { const int p = ltap + rot; return p >= 9 ? p - 9 : p; };
     auto issue_w = [&](int st) {                       // step st = slices st*SPS .. st*SPS+SPS-1
 #pragma unroll
@@ -144,32 +152,35 @@ __global__ __launch_bounds__(NT, (NT == 512 ? 1 : (TW == 16 ? (TH == 4 ? (SPS ==
     if (PF) issue_w(NBUF - 1);                         // (pipelined K loop: the whole ring is in flight during the staging)
 
     // ---- halo staging (single pass over the input, transform applied here)
-    if (!(a.dbg & 4)) {
+    if (!(dbg & 4)) {
         const int chunk = tid % CPP;                 // the same for every pass of a thread (256 % CPP == 0)
         const int c = chunk * 8;
         float k0[8], k1[8], k2[8];
-        if (LDMODE != PA_LD_PLAIN && a.fin.rows <= 0) {
+        if (LDMODE != PA_LD_PLAIN) {
+            bool done = false;
+            if constexpr (FIN && !TRI) {
+                if (a.fin.rows > 0) {
+                    // the input's BatchNorm finalize from the producer's <= 128 partial rows (bn_fin.h) instead of a launch of its own in
+                    // front of this kernel; table + scratch sit in the halo region, which nobody writes before the barrier below
+                    float* ktab = reinterpret_cast<float*>(halo);
+                    pa_bn_fin_prologue<256, CIN>(a.fin, CIN, ktab, ktab + 3 * CIN, blockIdx.x == 0 && blockIdx.y == 0);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                k0[j] = a.in.k0[c + j]; k1[j] = a.in.k1[c + j];
-                if (LDMODE == PA_LD_LIN2) k2[j] = a.in.k2[c + j];
+                    for (int j = 0; j < 8; ++j) {
+                        k0[j] = ktab[c + j]; k1[j] = ktab[CIN + c + j];
+                        if (LDMODE == PA_LD_LIN2) k2[j] = ktab[2 * CIN + c + j];
+                    }
+                    __syncthreads();
+                    done = true;
+                }
             }
-        }
-        // a.fin.rows > 0: the input's BatchNorm finalize from the producer's <= 128 partial rows (bn_fin.h) instead of a launch of its own
-        // in front of this kernel -- called behind the first batch of staging loads, which are in flight meanwhile.  Table + scratch sit
-        // in the halo region, which nobody writes before the barrier at the end
-        auto fin_constants = [&]() {
-            if constexpr (LDMODE != PA_LD_PLAIN && !TRI) {
-                float* ktab = reinterpret_cast<float*>(halo);
-                pa_bn_fin_prologue<256, CIN>(a.fin, CIN, ktab, ktab + 3 * CIN, blockIdx.x == 0 && blockIdx.y == 0);
+            if (!done) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    k0[j] = ktab[c + j]; k1[j] = ktab[CIN + c + j];
-                    if (LDMODE == PA_LD_LIN2) k2[j] = ktab[2 * CIN + c + j];
+                    k0[j] = a.in.k0[c + j]; k1[j] = a.in.k1[c + j];
+                    if (LDMODE == PA_LD_LIN2) k2[j] = a.in.k2[c + j];
                 }
-                __syncthreads();
             }
-        };
+        }
         constexpr int UN = LDMODE == PA_LD_LIN2 ? 6 : (TRI ? 9 : 12);      // loads in flight per thread before the first transform
 #pragma unroll
         for (int p0 = 0; p0 < NPASS; p0 += UN) {
@@ -191,7 +202,6 @@ __global__ __launch_bounds__(NT, (NT == 512 ? 1 : (TW == 16 ? (TH == 4 ? (SPS ==
                 ra[u] = *reinterpret_cast<const bf16x8*>(a.in.p + idx);
                 if (LDMODE == PA_LD_LIN2) rq[u] = *reinterpret_cast<const bf16x8*>(a.in.q + idx);
             }
-            if (p0 == 0 && a.fin.rows > 0) fin_constants();
 #pragma unroll
             for (int u = 0; u < UN; ++u) {
                 if ((p0 + u) < NPASS && hp[u] < HP) {
@@ -271,7 +281,7 @@ __global__ __launch_bounds__(NT, (NT == 512 ? 1 : (TW == 16 ? (TH == 4 ? (SPS ==
         for (int mi = 0; mi < MI; ++mi) fa[0][mi] = *reinterpret_cast<const bf16x8*>(halo + aoff[mi]);
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) fw[0][ni] = *reinterpret_cast<const bf16x8*>(wbuf + boff[ni]);
-        for (int tap = 0; tap < ((a.dbg & 1) ? 0 : 9); ++tap) {
+        for (int tap = 0; tap < ((dbg & 1) ? 0 : 9); ++tap) {
 #pragma unroll
             for (int g = 0; g < GPT; ++g) {
                 const int st = tap * GPT + g;
@@ -304,7 +314,7 @@ __global__ __launch_bounds__(NT, (NT == 512 ? 1 : (TW == 16 ? (TH == 4 ? (SPS ==
     // barrier into the buffer that was read in step st-1.  Counted vmcnt + raw s_barrier: __syncthreads() would drain
     // the LDS-DMA queue (vmcnt(0)) and expose one L2 round trip per slice, which is what bounded the first version
     // of this kernel (0.7 us per 64-channel slice = 30 % MFMA utilisation).
-    for (int tap = 0; tap < ((a.dbg & 1) ? 0 : 9); ++tap) {
+    for (int tap = 0; tap < ((dbg & 1) ? 0 : 9); ++tap) {
         const int pt = ptap(tap);
         const int dy = pt / 3 - 1, dx = pt - (pt / 3) * 3 - 1;
         const int toff = dy * PW + dx;
@@ -346,7 +356,7 @@ __global__ __launch_bounds__(NT, (NT == 512 ? 1 : (TW == 16 ? (TH == 4 ? (SPS ==
         }
     }
     __syncthreads();            // every wave is done with the halo and the ring before the epilogue reuses the LDS
-    if (a.dbg & 2) {            // (timing ablation: no epilogue; the accumulators stay alive)
+    if (dbg & 2) {            // (timing ablation: no epilogue; the accumulators stay alive)
         float sacc = 0.f;
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni)
@@ -367,8 +377,16 @@ __global__ __launch_bounds__(NT, (NT == 512 ? 1 : (TW == 16 ? (TH == 4 ? (SPS ==
                                      reinterpret_cast<float*>(lds), (int)blockIdx.x);
 }
 
-template <int CIN, int BN, int TW, int TH, int SPS, bool PF>
+// WITHFIN: this tiling also exists as a finalize-carrying instance (BatchNorm-on-load modes only), used when the launch brings one
+template <int CIN, int BN, int TW, int TH, int SPS, bool PF, bool WITHFIN = false>
 static void launch_tile_ld(const PaConvArgs& a, dim3 grid, hipStream_t st) {
+    if constexpr (WITHFIN) {
+        if (a.fin.rows > 0) {
+            if (a.in.mode == PA_LD_BNRELU) hipLaunchKernelGGL((conv3x3_tile_kernel<CIN, BN, PA_LD_BNRELU, TW, TH, SPS, PF, 256, true>), grid, dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((conv3x3_tile_kernel<CIN, BN, PA_LD_LIN2, TW, TH, SPS, PF, 256, true>), grid, dim3(256), 0, st, a);
+            return;
+        }
+    }
     switch (a.in.mode) {
         case PA_LD_PLAIN: hipLaunchKernelGGL((conv3x3_tile_kernel<CIN, BN, PA_LD_PLAIN, TW, TH, SPS, PF>), grid, dim3(256), 0, st, a); break;
         case PA_LD_BNRELU: hipLaunchKernelGGL((conv3x3_tile_kernel<CIN, BN, PA_LD_BNRELU, TW, TH, SPS, PF>), grid, dim3(256), 0, st, a); break;
@@ -382,21 +400,32 @@ static void launch_tile_ld(const PaConvArgs& a, dim3 grid, hipStream_t st) {
 template <int TW, int TH, int SPS>
 static void launch_tile_shape(const PaConvArgs& a, dim3 grid, bool bigN, hipStream_t st) {
     if constexpr (TW != 16) {                      // the small maps always run 64-channel halves (bigN is false for them)
-        if (a.Cin == 128) launch_tile_ld<128, 64, TW, TH, SPS, false>(a, grid, st); else launch_tile_ld<64, 64, TW, TH, 1, false>(a, grid, st);
+        if (a.Cin == 128) launch_tile_ld<128, 64, TW, TH, SPS, false, true>(a, grid, st); else launch_tile_ld<64, 64, TW, TH, 1, false, true>(a, grid, st);
     } else if constexpr (TH == 8 && SPS == 1) {
         static int pf = -1;
         if (pf < 0) { const char* e = pa_getenv("PA_CONV3_PF"); pf = e ? atoi(e) : 1; }
         if (pf) {
             if (a.Cin == 128) { if (bigN) launch_tile_ld<128, 128, TW, TH, 1, true>(a, grid, st); else launch_tile_ld<128, 64, TW, TH, 1, true>(a, grid, st); }
-            else { if (bigN) launch_tile_ld<64, 128, TW, TH, 1, true>(a, grid, st); else launch_tile_ld<64, 64, TW, TH, 1, true>(a, grid, st); }
+            else { if (bigN) launch_tile_ld<64, 128, TW, TH, 1, true>(a, grid, st); else launch_tile_ld<64, 64, TW, TH, 1, true, true>(a, grid, st); }
         } else {
             if (a.Cin == 128) { if (bigN) launch_tile_ld<128, 128, TW, TH, 1, false>(a, grid, st); else launch_tile_ld<128, 64, TW, TH, 1, false>(a, grid, st); }
             else { if (bigN) launch_tile_ld<64, 128, TW, TH, 1, false>(a, grid, st); else launch_tile_ld<64, 64, TW, TH, 1, false>(a, grid, st); }
         }
     } else {
-        if (a.Cin == 128) { if (bigN) launch_tile_ld<128, 128, TW, TH, SPS, false>(a, grid, st); else launch_tile_ld<128, 64, TW, TH, SPS, false>(a, grid, st); }
+        if (a.Cin == 128) { if (bigN) launch_tile_ld<128, 128, TW, TH, SPS, false, (SPS == 2)>(a, grid, st); else launch_tile_ld<128, 64, TW, TH, SPS, false, (SPS == 2)>(a, grid, st); }
         else { if (bigN) launch_tile_ld<64, 128, TW, TH, 1, false>(a, grid, st); else launch_tile_ld<64, 64, TW, TH, 1, false>(a, grid, st); }
     }
+}
+
+// does the instance the launcher below picks for this shape exist with the finalize prologue?  (pa_conv_takes_fin)
+bool pa_conv3x3_tile_takes_fin(const PaConvArgs& a) {
+    if (!pa_conv3x3_tile_supported(a)) return false;
+    if (pa_getenv("PA_CONV3_SPS") || pa_getenv("PA_CONV3_PF") || pa_getenv("PA_CONV3_BM64") || pa_getenv("PA_CONV3_BN64")) return false;      // (tuning switches select other instances)
+    const bool small = !(a.H % 8 == 0 && a.W % 16 == 0);
+    if (small) return true;                                                    // 8 x 8 / 4 x 4 maps: <128 | 64, 64, .., SPS 4 | 1>
+    const int tiles128 = a.B * (a.H / 8) * (a.W / 16);
+    if (a.Cin == 128) return tiles128 < 512;                                   // 16 x 4 tiles, half a tap per step
+    return a.Cout % 128 != 0;                                                  // 64 input channels: the 16 x 8 <64, 64> instance
 }
 
 static bool small_map(const PaConvArgs& a) { return (a.H == 8 && a.W == 8) || (a.H == 4 && a.W == 4); }

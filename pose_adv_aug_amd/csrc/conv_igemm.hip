@@ -24,12 +24,14 @@
 // STEM: the A operand is the 4-channel-padded input image and the kernel computes the 7x7 stride-2
 // stem conv (reference models/asn_stacked_hg.py:223) as a K=256 GEMM: k = ky*32 + kx*4 + c, i.e. one
 // 16-byte chunk = 2 horizontally adjacent input pixels; a.H/a.W are the OUTPUT dims.
-template <int BM, int BN, int LDMODE, int TAPS, bool STEM = false>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(PaConvArgs a) {
+// FIN: the instance that can carry the input's BatchNorm finalize in its prologue (bn_fin.h) -- the 64 x 64 tiles of the small maps only;
+// every other instance is the plain kernel, its register allocation untouched
+template <int BM, int BN, int LDMODE, int TAPS, bool STEM = false, bool FIN = false>
+__global__ __launch_bounds__(256, FIN ? 2 : 1) void conv_igemm_kernel(PaConvArgs a) {      // (FIN: left alone the prologue takes every register it can get -- 256, one workgroup per CU; the plain 64 x 64 instance runs at 116)
     constexpr int AI = BM / 32, BI = BN / 32;      // staged 16-byte chunks per thread (A / B tile)
     constexpr int MI = BM / 32, NI = BN / 32;      // 16x16 fragments per wave (wave tile BM/2 x BN/2)
     __shared__ __attribute__((aligned(16))) bf16 lds[(BM + BN) * 64];
-    __shared__ float kst[LDMODE == PA_LD_PLAIN ? 4 : 3 * 512 + 1024];      // per-channel constants of the input transform (+ the finalize prologue's scratch)
+    __shared__ float kst[LDMODE == PA_LD_PLAIN ? 4 : 3 * 512 + (FIN ? 2048 : 0)];      // per-channel constants of the input transform (+ the finalize prologue's scratch)
     bf16* As = lds;
     bf16* Bs = lds + BM * 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -146,15 +148,18 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(PaConvArgs a) {
 
     gload(0);
     // per-channel constants of the input transform, behind the first tile's loads (they are in flight meanwhile)
-    if (LDMODE != PA_LD_PLAIN) {
-        if (!STEM && a.fin.rows > 0) {
+    bool fin_done = false;
+    if constexpr (FIN && LDMODE != PA_LD_PLAIN) {
+        if (a.fin.rows > 0) {
             // the input's BatchNorm finalize (forward: scale / shift; backward: kA / kB / kC) from the producer's partial rows, bn_fin.h
             pa_bn_fin_prologue<256, 512>(a.fin, a.Cin, kst, kst + 3 * 512, blockIdx.x == 0 && blockIdx.y == 0);
-        } else {
-            for (int c = threadIdx.x; c < a.Cin; c += 256) {
-                kst[c] = a.in.k0[c]; kst[512 + c] = a.in.k1[c];
-                if (LDMODE == PA_LD_LIN2) kst[1024 + c] = a.in.k2[c];
-            }
+            fin_done = true;
+        }
+    }
+    if (LDMODE != PA_LD_PLAIN && !fin_done) {
+        for (int c = threadIdx.x; c < a.Cin; c += 256) {
+            kst[c] = a.in.k0[c]; kst[512 + c] = a.in.k1[c];
+            if (LDMODE == PA_LD_LIN2) kst[1024 + c] = a.in.k2[c];
         }
     }
     __syncthreads();            // kst visible
@@ -198,6 +203,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(PaConvArgs a) {
 
 template <int BM, int BN, int TAPS>
 static void launch_ld(const PaConvArgs& a, dim3 grid, hipStream_t st) {
+    if constexpr (BM == 64 && BN == 64) {
+        if (a.fin.rows > 0) {          // (pa_conv_takes_fin admits BNRELU / LIN2 inputs only)
+            if (a.in.mode == PA_LD_BNRELU) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, PA_LD_BNRELU, TAPS, false, true>), grid, dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, PA_LD_LIN2, TAPS, false, true>), grid, dim3(256), 0, st, a);
+            return;
+        }
+    }
     switch (a.in.mode) {
         case PA_LD_PLAIN: hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, PA_LD_PLAIN, TAPS>), grid, dim3(256), 0, st, a); break;
         case PA_LD_BNRELU: hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, PA_LD_BNRELU, TAPS>), grid, dim3(256), 0, st, a); break;
@@ -230,9 +242,12 @@ bool pa_conv_takes_fin(const PaConvArgs& a) {
     if (a.in.mode != PA_LD_BNRELU && a.in.mode != PA_LD_LIN2) return false;
     if (a.Cin > 256) return false;
     const bool old3 = pa_getenv("PA_CONV3_OLD") != nullptr, old1 = pa_getenv("PA_CONV1_OLD") != nullptr;
-    if (!old3 && pa_conv3x3_tile_supported(a)) return true;
+    if (!old3 && pa_conv3x3_tile_supported(a)) return pa_conv3x3_tile_takes_fin(a);
     if (!old1 && pa_conv1x1_tile_supported(a)) return false;
-    return true;
+    // generic kernel: only its 64 x 64-tile instance carries the prologue (the dispatch below: small M, or 64-channel outputs)
+    const int M = a.B * a.H * a.W;
+    const bool bigM = M >= 128 * 256, bigN = a.Cout % 128 == 0;
+    return !bigM && !(bigN && M >= 64 * 256);
 }
 
 int pa_launch_conv(const PaConvArgs& a0, hipStream_t st, int* stat_rows) {
@@ -257,7 +272,7 @@ int pa_launch_conv(const PaConvArgs& a0, hipStream_t st, int* stat_rows) {
         if (a.fin.rows > 0) { pa_set_error_msg("pa_launch_conv: a pending finalize was handed to the row-tile 1x1 kernel (pa_conv_takes_fin)"); return 1; }
         return pa_launch_conv1x1_tile(a, st, stat_rows);
     }
-    if (a.fin.rows > 0 && (a.fin.rows > PA_FIN_SMALL_ROWS || a.Cin > 256)) { pa_set_error_msg("pa_launch_conv: finalize prologue needs <= 128 partial rows and <= 256 channels"); return 1; }
+    if (a.fin.rows > 0 && (a.fin.rows > PA_FIN_SMALL_ROWS || a.Cin > 256 || !pa_conv_takes_fin(a))) { pa_set_error_msg("pa_launch_conv: finalize prologue needs <= 128 partial rows, <= 256 channels and a launch pa_conv_takes_fin() admits"); return 1; }
     const int M = a.B * a.H * a.W;
     // small problems get the 64-row tile so that the grid still covers the 256 CUs
     const bool bigM = M >= 128 * 256;

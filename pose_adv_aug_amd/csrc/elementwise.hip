@@ -6,6 +6,7 @@
 #include "common.h"
 #include "kernels.h"
 #include "bn_fin.h"
+#include <type_traits>
 
 // ------------------------------------------------------------------------------------------------
 // BatchNorm bookkeeping (reference semantics: torch.nn.BatchNorm2d, eps 1e-5, momentum 0.1,
@@ -21,35 +22,49 @@ __device__ __forceinline__ void reduce_partial_rows(const float* part, int rows,
     const int cl = threadIdx.x % FC, sl = threadIdx.x / FC;
     if (rows <= PA_FIN_SMALL_ROWS) {
         // the order the consumer-prologue form of the finalize uses too (bn_fin.h): sixteen interleaved chains, stride-halving tree;
-        // here 8 threads per channel pair (4 pairs per workgroup), each with two chains
-        f32x4* part4 = reinterpret_cast<f32x4*>(&red[0][0][0]);          // [8][4]
-        if (threadIdx.x < 32) {
-            const int pr = threadIdx.x & 3, g = threadIdx.x >> 2;
+        // here one thread per chain and channel pair (4 pairs x 16 chains), ONE round of <= 8 loads each
+        f32x4* part4 = reinterpret_cast<f32x4*>(&red[0][0][0]);          // [16][4]
+        if (threadIdx.x < 64) {
+            const int pr = threadIdx.x & 3, j = threadIdx.x >> 2;
             const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            part4[g * 4 + pr] = c0 + 2 * pr < C ? pa_fin_partial<8>(part, rows, C, c0 + 2 * pr, g) : z;
+            part4[j * 4 + pr] = c0 + 2 * pr < C ? pa_fin_chain16(part, rows, C, c0 + 2 * pr, j) : z;
         }
         __syncthreads();
         if (threadIdx.x < FC) {
             const int c = threadIdx.x, half = c & 1;
-            float a[8], b[8];
+            float a[16], b[16];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) { const f32x4 v = part4[i * 4 + (c >> 1)]; a[i] = half ? v[2] : v[0]; b[i] = half ? v[3] : v[1]; }
+            for (int i = 0; i < 16; ++i) { const f32x4 v = part4[i * 4 + (c >> 1)]; a[i] = half ? v[2] : v[0]; b[i] = half ? v[3] : v[1]; }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { a[i] += a[i + 4]; b[i] += b[i + 4]; }
+            for (int n = 16; n > 1; n >>= 1)
 #pragma unroll
-            for (int i = 0; i < 2; ++i) { a[i] += a[i + 2]; b[i] += b[i + 2]; }
-            sums[c][0] = a[0] + a[1]; sums[c][1] = b[0] + b[1];
+                for (int i = 0; i < n / 2; ++i) { a[i] += a[i + n / 2]; b[i] += b[i + n / 2]; }
+            sums[c][0] = a[0]; sums[c][1] = b[0];
         }
         __syncthreads();
         return;
     }
     float a = 0.f, b = 0.f;
     if (c0 + cl < C) {
-#pragma unroll 8
-        for (int r = sl; r < rows; r += SL) {
-            f32x2 v = *reinterpret_cast<const f32x2*>(part + ((size_t)r * C + c0 + cl) * 2);
-            a += v[0]; b += v[1];
-        }
+        // the thread's rows sl, sl + SL, ... in batches of NB loads in flight (clamped, unconditional; the sums stay in increasing order):
+        // hipcc compiled the plain loop `#pragma unroll 8` into a one-load-one-wait remainder loop in FRONT of the unrolled body, i.e. 3 / 6
+        // serial memory round trips at 384 / 768 rows in a kernel that is nothing but latency.  NB = 4 up to 512 rows (one round trip,
+        // <= 3 loads wasted), 8 above (768 rows: one round trip; 1536: two)
+        auto batches = [&](auto nbc) {
+            constexpr int NB = decltype(nbc)::value;
+            for (int r0 = sl; r0 < rows; r0 += NB * SL) {
+                f32x2 v[NB];
+#pragma unroll
+                for (int u = 0; u < NB; ++u) {
+                    const int r = r0 + u * SL;
+                    v[u] = *reinterpret_cast<const f32x2*>(part + ((size_t)(r < rows ? r : r0) * C + c0 + cl) * 2);
+                }
+#pragma unroll
+                for (int u = 0; u < NB; ++u)
+                    if (r0 + u * SL < rows) { a += v[u][0]; b += v[u][1]; }
+            }
+        };
+        if (rows <= 4 * SL) batches(std::integral_constant<int, 4>{}); else batches(std::integral_constant<int, 8>{});
     }
     red[sl][cl][0] = a; red[sl][cl][1] = b;
     __syncthreads();

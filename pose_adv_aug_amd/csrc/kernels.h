@@ -24,6 +24,7 @@ int pa_launch_conv(const PaConvArgs& a, hipStream_t st, int* stat_rows = nullptr
 bool pa_conv_takes_fin(const PaConvArgs& a);
 // halo-tile 3x3 kernel (conv3x3_tile.hip); pa_launch_conv dispatches to it when the shape is supported
 bool pa_conv3x3_tile_supported(const PaConvArgs& a);
+bool pa_conv3x3_tile_takes_fin(const PaConvArgs& a);      // ... and the instance it would run exists with the finalize prologue
 int pa_launch_conv3x3_tile(const PaConvArgs& a, hipStream_t st, int* stat_rows = nullptr);
 // row-tile 1x1 kernel (conv1x1_tile.hip), same dispatch rule
 bool pa_conv1x1_tile_supported(const PaConvArgs& a);
