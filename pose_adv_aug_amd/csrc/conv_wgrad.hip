@@ -318,9 +318,23 @@ __global__ void wgrad_reduce_kernel(const PaWgradReduceJob* jobs) {
             const int r = e - n * j.taps * j.real_cin;
             const int tap = r / j.real_cin, c = r - tap * j.real_cin;
             const float* src = j.part + (size_t)n * K + tap * j.Cin + c;
+            // (16 loads in flight per thread: the split counts of the networks are multiples of 16 or small; the sum stays in split order)
             float s = 0.f;
-#pragma unroll 8
-            for (int sp = 0; sp < j.splits; ++sp) s += src[(size_t)sp * j.Cout * K];
+            int sp = 0;
+            for (; sp + 16 <= j.splits; sp += 16) {
+                float v[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) v[u] = src[(size_t)(sp + u) * j.Cout * K];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) s += v[u];
+            }
+            if (sp < j.splits) {                       // the rest in one more batch (clamped, unconditional loads)
+                float v[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) v[u] = src[(size_t)(sp + u < j.splits ? sp + u : sp) * j.Cout * K];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) if (sp + u < j.splits) s += v[u];
+            }
             j.dst[((size_t)n * j.real_cin + c) * j.taps + tap] = s;
         } else if (j.dbdst) {
             const int n = e - total;

@@ -15,7 +15,7 @@
 // FC channels x (1024/FC) row slices, float2 loads, LDS tree over the slices.  Result in LDS sums[FC][2].
 // FC = 8: 16-32 workgroups per BatchNorm and <= 6 dependent loads per thread at 768 rows (the kernel is pure
 // latency: launch + one round of loads + tree; 32 channels per workgroup took 6 us).
-constexpr int FC = 8;
+constexpr int FC = 4;
 __device__ __forceinline__ void reduce_partial_rows(const float* part, int rows, int C, int c0, float (*sums)[2]) {
     constexpr int SL = 1024 / FC;
     __shared__ __attribute__((aligned(16))) float red[SL][FC + 1][2];
@@ -23,18 +23,19 @@ __device__ __forceinline__ void reduce_partial_rows(const float* part, int rows,
     if (rows <= PA_FIN_SMALL_ROWS) {
         // the order the consumer-prologue form of the finalize uses too (bn_fin.h): sixteen interleaved chains, stride-halving tree;
         // here one thread per chain and channel pair (4 pairs x 16 chains), ONE round of <= 8 loads each
-        f32x4* part4 = reinterpret_cast<f32x4*>(&red[0][0][0]);          // [16][4]
-        if (threadIdx.x < 64) {
-            const int pr = threadIdx.x & 3, j = threadIdx.x >> 2;
+        constexpr int NP = FC / 2;                                       // channel pairs of this workgroup
+        f32x4* part4 = reinterpret_cast<f32x4*>(&red[0][0][0]);          // [16][NP]
+        if (threadIdx.x < 16 * NP) {
+            const int pr = threadIdx.x % NP, j = threadIdx.x / NP;
             const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            part4[j * 4 + pr] = c0 + 2 * pr < C ? pa_fin_chain16(part, rows, C, c0 + 2 * pr, j) : z;
+            part4[j * NP + pr] = c0 + 2 * pr < C ? pa_fin_chain16(part, rows, C, c0 + 2 * pr, j) : z;
         }
         __syncthreads();
         if (threadIdx.x < FC) {
             const int c = threadIdx.x, half = c & 1;
             float a[16], b[16];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) { const f32x4 v = part4[i * 4 + (c >> 1)]; a[i] = half ? v[2] : v[0]; b[i] = half ? v[3] : v[1]; }
+            for (int i = 0; i < 16; ++i) { const f32x4 v = part4[i * NP + (c >> 1)]; a[i] = half ? v[2] : v[0]; b[i] = half ? v[3] : v[1]; }
 #pragma unroll
             for (int n = 16; n > 1; n >>= 1)
 #pragma unroll

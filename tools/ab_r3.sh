@@ -1,5 +1,9 @@
 #!/bin/bash
-# same-box comparison of the round-3 tree (r3_tmp/, built from commit aee3bb1) with the current one
+# Same-box, interleaved comparison of the round-3 tree with the current one (boxes of the pool differ by up to 3 % on the same binary,
+# and an in-build A/B cannot see a regression that hits both of its arms).  r3_tmp/ is NOT in git; make it with
+#   git worktree add /tmp/r3 aee3bb1 && (cd /tmp/r3 && bash pose_adv_aug_amd/csrc/build.sh)
+#   mkdir r3_tmp && (cd /tmp/r3 && tar cf - --exclude=.git --exclude=gpurun_out --exclude='pose_adv_aug_amd/build*' --exclude=profiles --exclude=tests/golden .) | (cd r3_tmp && tar xf -)
+# and run through gpurun:  gpurun -- 'bash tools/ab_r3.sh'
 cd /tmp && export TMPDIR=/tmp
 one() { python bench.py --no-cpu-baseline --no-parity --no-roofline "$@" 2>/dev/null | python -c "
 import json, sys
