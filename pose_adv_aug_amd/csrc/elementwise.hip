@@ -13,9 +13,9 @@
 // biased variance for normalisation, unbiased for the running estimate).
 // Sum `rows` partial rows [rows][C][2] for the FC channels of this workgroup: 1024 threads =
 // FC channels x (1024/FC) row slices, float2 loads, LDS tree over the slices.  Result in LDS sums[FC][2].
-// FC = 8: 16-32 workgroups per BatchNorm and <= 6 dependent loads per thread at 768 rows (the kernel is pure
-// latency: launch + one round of loads + tree; 32 channels per workgroup took 6 us).
-constexpr int FC = 4;
+// FC = 8: 16-32 workgroups per BatchNorm (the kernel is pure latency: launch + row loads in batches + tree; 32 channels per workgroup
+// took 6 us; FC = 4 -- every common row count in ONE batch of loads, twice the workgroups -- measured 0.03 ms per step slower, round 4).
+constexpr int FC = 8;
 __device__ __forceinline__ void reduce_partial_rows(const float* part, int rows, int C, int c0, float (*sums)[2]) {
     constexpr int SL = 1024 / FC;
     __shared__ __attribute__((aligned(16))) float red[SL][FC + 1][2];
