@@ -228,9 +228,15 @@ __global__ __launch_bounds__(256) void argmax_kernel(const float* maps, long sb,
     const int HW = H * W;
     float best = -INFINITY;
     int bi = 0x7fffffff;
-    for (int p = threadIdx.x; p < HW; p += 256) {
-        float v = base[(long)p * sp];
-        if (v > best) { best = v; bi = p; }               // p increases per thread: its first maximum is kept
+    for (int p0 = threadIdx.x; p0 < HW; p0 += 8 * 256) {          // eight loads in flight (a 64 x 64 map: two round trips instead of sixteen)
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int p = p0 + u * 256; v[u] = base[(long)(p < HW ? p : p0) * sp]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int p = p0 + u * 256;
+            if (p < HW && v[u] > best) { best = v[u]; bi = p; }               // p increases per thread: its first maximum is kept
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -264,14 +270,28 @@ __global__ __launch_bounds__(1024) void argmax_nhwc16_kernel(const float* maps, 
     float best[16]; int bi[16];
 #pragma unroll
     for (int j = 0; j < 16; ++j) { best[j] = -INFINITY; bi[j] = 0x7fffffff; }
-    for (int p = tid; p < HW; p += 1024) {
+    // four pixels (16 loads of 16 bytes) of a thread in flight at once: the plain loop made one memory round trip per pixel, and a 64 x 64
+    // map is exactly four pixels per thread -- the kernel is 24 workgroups of pure latency at the end of every step
+    for (int p0 = tid; p0 < HW; p0 += 4 * 1024) {
+        f32x4 v[4][4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const f32x4 v = base[(size_t)p * 4 + q];
+        for (int u = 0; u < 4; ++u) {
+            const int p = p0 + u * 1024;
+            const size_t pc = p < HW ? (size_t)p : (size_t)p0;           // clamped, unconditional loads
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int j = q * 4 + r;
-                if (v[r] > best[j]) { best[j] = v[r]; bi[j] = p; }       // p increases: the first maximum is kept
+            for (int q = 0; q < 4; ++q) v[u][q] = base[pc * 4 + q];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int p = p0 + u * 1024;
+            if (p < HW) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int j = q * 4 + r;
+                        if (v[u][q][r] > best[j]) { best[j] = v[u][q][r]; bi[j] = p; }       // p increases: the first maximum is kept
+                    }
             }
         }
     }
