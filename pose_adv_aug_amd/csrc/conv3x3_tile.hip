@@ -61,10 +61,26 @@ template <int N> __device__ __forceinline__ void pa_wait_vmcnt() {
 // FIN: the instance that can carry the input's BatchNorm finalize in its prologue (bn_fin.h): instantiated for the tilings the maps with
 // <= 128 statistics rows use (launch_tile_shape); all other instances are the plain kernel.
 // PA_TUNING builds only: a.dbg -- phase ablation (1 no K loop, 2 no epilogue, 4 no staging: wrong results, timing) and bit 8, per-workgroup tap rotation
-template <int CIN, int BN, int LDMODE, int TW = 16, int TH = 8, int SPS = 1, bool PF = false, int NT = 256, bool FIN = false>
-__global__ __launch_bounds__(NT, (NT == 512 ? 1 : (TW == 16 ? (TH == 4 ? (SPS == 1 ? 3 : 2) : 2) : 1))) void conv3x3_tile_kernel(PaConvArgs a) {
-    constexpr bool TRI = NT == 512;
+// NT = 512 / 1024 on the maps that give at most one workgroup per CU (8 x 8, 4 x 4, 16 x 16): with ONE wave per SIMD nothing overlaps -- cycle
+// stamps (tools/conv3_clocks.py) show a K-loop step as the plain SUM of its parts (barrier ~100 cycles, each LDS-DMA issue 100-150, the ds_read
+// round trip ~150, 17 per MFMA: 45-60 cycles per MFMA instead of 17), and the staging / epilogue are load / store round trips of 4 waves.  Two
+// or four waves per SIMD (the same 128 pixels x 64 channels, MI = 2 or 1 fragments per wave) let one wave's MFMAs run under another's waits.
 #ifdef PA_TUNING
+// cycle stamps of workgroup (0, 0), thread 0 (a.dbg & 64): {s_memtime, wall_clock64} at entry / weight ring issued / own halo part staged / K loop /
+// barrier / epilogue
+__device__ unsigned long long pa_conv3_clk[16];
+extern "C" int pa_debug_conv3_clocks(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pa_conv3_clk), sizeof(unsigned long long) * 16);
+}
+#define PA_STAMP(i) do { if ((a.dbg & 64) && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { pa_conv3_clk[2 * (i)] = __builtin_amdgcn_s_memtime(); pa_conv3_clk[2 * (i) + 1] = wall_clock64(); } } while (0)
+#else
+#define PA_STAMP(i) do { } while (0)
+#endif
+template <int CIN, int BN, int LDMODE, int TW = 16, int TH = 8, int SPS = 1, bool PF = false, int NT = 256, bool FIN = false>
+__global__ __launch_bounds__(NT, (NT >= 512 ? 1 : (TW == 16 ? (TH == 4 ? (SPS == 1 ? 3 : 2) : 2) : 1))) void conv3x3_tile_kernel(PaConvArgs a) {
+    constexpr bool TRI = NT == 512 && TW == 16 && TH == 8;
+    PA_STAMP(0);
+#if defined(PA_TUNING) && !defined(PA_CONV3_CONSTDBG)      // (PA_EXTRA=-DPA_CONV3_CONSTDBG: the release code with the cycle stamps only)
     const int dbg = a.dbg;
 #else
     constexpr int dbg = 0;
@@ -75,7 +91,12 @@ __global__ __launch_bounds__(NT, (NT == 512 ? 1 : (TW == 16 ? (TH == 4 ? (SPS ==
     constexpr int CPP = CIN / 8;                                         // 16-byte chunks per pixel
     constexpr int NI = BN / 32, MI = BM / (16 * WM);
     constexpr int NSL = CIN / 32;                                        // 32-channel weight slices per tap
-    constexpr int NIT = 9 * NSL, NIW = BN / (16 * NW);                   // slices [BN][32]; glds per wave per slice
+    constexpr int NIT = 9 * NSL;                                         // slices [BN][32]
+    // LDS-DMA pieces (16 rows x 64 B of a slice, one wave-instruction) per wave: NIW per slice when a slice has at least one piece for every wave,
+    // else (8 / 16 waves) the SPS * BN / 16 pieces of a STEP are dealt out, PPS per wave
+    constexpr bool DEAL = 16 * NW > BN;
+    constexpr int NIW = DEAL ? 0 : BN / (16 * NW), PPS = SPS * BN / (16 * NW);
+    static_assert(PPS >= 1 && PPS * 16 * NW == SPS * BN, "every wave issues the same number of weight pieces per step");
     constexpr int NST = NIT / SPS, GPT = NSL / SPS;                      // K-loop steps, steps per tap
     constexpr int NBUF = TRI ? 3 : (SPS == 1 ? (BM == 64 ? 3 : 4) : 3);  // ring of NBUF step buffers [SPS][BN][32]
     constexpr int AHEAD = NBUF - 2;                                      // steps still in flight while one is consumed
@@ -125,10 +146,16 @@ __global__ __launch_bounds__(NT, (NT == 512 ? 1 : (TW == 16 ? (TH == 4 ? (SPS ==
     // ---- weight slices [BN][32] (64-byte rows): wave w streams LDS rows [w*BN/4, (w+1)*BN/4), one instruction =
     // 16 rows x 4 slots.  Slot swizzle wsw(row) = (-(row >> 2)) & 3: conflict-free for ds_read_b128's lane groups
     // (rows 0-3/12-15 at chunk c with rows 4-11 at chunk c^1).  Slice `it` covers k = 32*it .. 32*it+31.
-    const bf16* wsrc[NIW];
+    const bf16* wsrc[DEAL ? PPS : NIW];
+    int wj[DEAL ? PPS : 1], wrow[DEAL ? PPS : 1];      // (DEAL) slice of the step and first LDS row of the wave's piece i
 #pragma unroll
-    for (int i = 0; i < NIW; ++i) {
-        const int lr = wave * (BN / NW) + i * 16 + (lane >> 2);
+    for (int i = 0; i < (DEAL ? PPS : NIW); ++i) {
+        int lr;
+        if constexpr (DEAL) {
+            const int q = wave * PPS + i;
+            wj[i] = q / (BN / 16); wrow[i] = (q % (BN / 16)) * 16;
+            lr = wrow[i] + (lane >> 2);
+        } else lr = wave * (BN / NW) + i * 16 + (lane >> 2);
         const int slot = lane & 3;
         wsrc[i] = a.w + (size_t)(n0 + pa_weight_row_of_lds_row<BN, NI>(lr)) * K + ((slot ^ ((-(lr >> 2)) & 3)) << 3);
     }
@@ -137,6 +164,15 @@ __global__ __launch_bounds__(NT, (NT == 512 ? 1 : (TW == 16 ? (TH == 4 ? (SPS ==
     const int rot = (dbg & 8) ? (int)(blockIdx.x % 9) : 0;
     auto ptap = [&](int ltap) { const int p = ltap + rot; return p >= 9 ? p - 9 : p; };
     auto issue_w = [&](int st) {                       // step st = slices st*SPS .. st*SPS+SPS-1
+        if constexpr (DEAL) {
+#pragma unroll
+            for (int i = 0; i < PPS; ++i) {
+                bf16* dst = wbuf + ((st % NBUF) * SPS + wj[i]) * (BN * 32) + wrow[i] * 32;
+                const int it = st * SPS + wj[i], lt = it / NSL;
+                const int pit = ptap(lt) * NSL + (it - lt * NSL);
+                __builtin_amdgcn_global_load_lds(PA_GLOBAL_PTR(wsrc[i] + pit * 32), PA_LDS_PTR(dst), 16, 0, 0);
+            }
+        } else
 #pragma unroll
         for (int j = 0; j < SPS; ++j) {
             bf16* dst = wbuf + ((st % NBUF) * SPS + j) * (BN * 32) + wave * (BN / NW) * 32;
@@ -150,6 +186,7 @@ __global__ __launch_bounds__(NT, (NT == 512 ? 1 : (TW == 16 ? (TH == 4 ? (SPS ==
     issue_w(0); issue_w(1);
     if (NBUF == 4) issue_w(2);
     if (PF) issue_w(NBUF - 1);                         // (pipelined K loop: the whole ring is in flight during the staging)
+    PA_STAMP(1);
 
     // ---- halo staging (single pass over the input, transform applied here)
     if (!(dbg & 4)) {
@@ -163,7 +200,7 @@ __global__ __launch_bounds__(NT, (NT == 512 ? 1 : (TW == 16 ? (TH == 4 ? (SPS ==
                     // the input's BatchNorm finalize from the producer's <= 128 partial rows (bn_fin.h) instead of a launch of its own in
                     // front of this kernel; table + scratch sit in the halo region, which nobody writes before the barrier below
                     float* ktab = reinterpret_cast<float*>(halo);
-                    pa_bn_fin_prologue<256, CIN>(a.fin, CIN, ktab, ktab + 3 * CIN, blockIdx.x == 0 && blockIdx.y == 0);
+                    pa_bn_fin_prologue<NT, CIN>(a.fin, CIN, ktab, ktab + 3 * CIN, blockIdx.x == 0 && blockIdx.y == 0);
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
                         k0[j] = ktab[c + j]; k1[j] = ktab[CIN + c + j];
@@ -241,6 +278,7 @@ __global__ __launch_bounds__(NT, (NT == 512 ? 1 : (TW == 16 ? (TH == 4 ? (SPS ==
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    PA_STAMP(2);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -289,8 +327,8 @@ __global__ __launch_bounds__(NT, (NT == 512 ? 1 : (TW == 16 ? (TH == 4 ? (SPS ==
                 const int cur = g & 1, nxt = cur ^ 1;                  // (GPT is even: the register set of a step is a compile-time index)
                 if (st + 1 < NST) {
                     const int younger = NST - 2 - st;               // slices issued after st + 1 (at most NBUF - 2 of them are in flight)
-                    if (younger >= 2 && NBUF == 4) pa_wait_vmcnt<2 * NIW>();
-                    else if (younger >= 1) pa_wait_vmcnt<NIW>();
+                    if (younger >= 2 && NBUF == 4) pa_wait_vmcnt<2 * PPS>();
+                    else if (younger >= 1) pa_wait_vmcnt<PPS>();
                     else pa_wait_vmcnt<0>();
                     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
                     if (st + NBUF < NST) issue_w(st + NBUF);
@@ -331,8 +369,8 @@ __global__ __launch_bounds__(NT, (NT == 512 ? 1 : (TW == 16 ? (TH == 4 ? (SPS ==
             const int st = tap * GPT + g;
             const int rem = NST - 1 - st;                       // steps issued after this one
             const int fly = rem < AHEAD ? rem : AHEAD;          // ... that may stay in flight
-            if (fly == 2) pa_wait_vmcnt<2 * SPS * NIW>();
-            else if (fly == 1) pa_wait_vmcnt<SPS * NIW>();
+            if (fly == 2) pa_wait_vmcnt<2 * PPS>();
+            else if (fly == 1) pa_wait_vmcnt<PPS>();
             else pa_wait_vmcnt<0>();
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             if (st + NBUF - 1 < NST) issue_w(st + NBUF - 1);
@@ -355,7 +393,9 @@ __global__ __launch_bounds__(NT, (NT == 512 ? 1 : (TW == 16 ? (TH == 4 ? (SPS ==
             }
         }
     }
+    PA_STAMP(3);
     __syncthreads();            // every wave is done with the halo and the ring before the epilogue reuses the LDS
+    PA_STAMP(4);
     if (dbg & 2) {            // (timing ablation: no epilogue; the accumulators stay alive)
         float sacc = 0.f;
 #pragma unroll
@@ -375,22 +415,23 @@ __global__ __launch_bounds__(NT, (NT == 512 ? 1 : (TW == 16 ? (TH == 4 ? (SPS ==
                                          return bb < a.B ? (bb * a.H + yy + r / TW) * a.W + xx + r % TW : -1;
                                      },
                                      reinterpret_cast<float*>(lds), (int)blockIdx.x);
+    PA_STAMP(5);
 }
 
 // WITHFIN: this tiling also exists as a finalize-carrying instance (BatchNorm-on-load modes only), used when the launch brings one
-template <int CIN, int BN, int TW, int TH, int SPS, bool PF, bool WITHFIN = false>
+template <int CIN, int BN, int TW, int TH, int SPS, bool PF, bool WITHFIN = false, int NT = 256>
 static void launch_tile_ld(const PaConvArgs& a, dim3 grid, hipStream_t st) {
     if constexpr (WITHFIN) {
         if (a.fin.rows > 0) {
-            if (a.in.mode == PA_LD_BNRELU) hipLaunchKernelGGL((conv3x3_tile_kernel<CIN, BN, PA_LD_BNRELU, TW, TH, SPS, PF, 256, true>), grid, dim3(256), 0, st, a);
-            else hipLaunchKernelGGL((conv3x3_tile_kernel<CIN, BN, PA_LD_LIN2, TW, TH, SPS, PF, 256, true>), grid, dim3(256), 0, st, a);
+            if (a.in.mode == PA_LD_BNRELU) hipLaunchKernelGGL((conv3x3_tile_kernel<CIN, BN, PA_LD_BNRELU, TW, TH, SPS, PF, NT, true>), grid, dim3(NT), 0, st, a);
+            else hipLaunchKernelGGL((conv3x3_tile_kernel<CIN, BN, PA_LD_LIN2, TW, TH, SPS, PF, NT, true>), grid, dim3(NT), 0, st, a);
             return;
         }
     }
     switch (a.in.mode) {
-        case PA_LD_PLAIN: hipLaunchKernelGGL((conv3x3_tile_kernel<CIN, BN, PA_LD_PLAIN, TW, TH, SPS, PF>), grid, dim3(256), 0, st, a); break;
-        case PA_LD_BNRELU: hipLaunchKernelGGL((conv3x3_tile_kernel<CIN, BN, PA_LD_BNRELU, TW, TH, SPS, PF>), grid, dim3(256), 0, st, a); break;
-        default: hipLaunchKernelGGL((conv3x3_tile_kernel<CIN, BN, PA_LD_LIN2, TW, TH, SPS, PF>), grid, dim3(256), 0, st, a); break;
+        case PA_LD_PLAIN: hipLaunchKernelGGL((conv3x3_tile_kernel<CIN, BN, PA_LD_PLAIN, TW, TH, SPS, PF, NT>), grid, dim3(NT), 0, st, a); break;
+        case PA_LD_BNRELU: hipLaunchKernelGGL((conv3x3_tile_kernel<CIN, BN, PA_LD_BNRELU, TW, TH, SPS, PF, NT>), grid, dim3(NT), 0, st, a); break;
+        default: hipLaunchKernelGGL((conv3x3_tile_kernel<CIN, BN, PA_LD_LIN2, TW, TH, SPS, PF, NT>), grid, dim3(NT), 0, st, a); break;
     }
 }
 
@@ -400,7 +441,15 @@ static void launch_tile_ld(const PaConvArgs& a, dim3 grid, hipStream_t st) {
 template <int TW, int TH, int SPS>
 static void launch_tile_shape(const PaConvArgs& a, dim3 grid, bool bigN, hipStream_t st) {
     if constexpr (TW != 16) {                      // the small maps always run 64-channel halves (bigN is false for them)
-        if (a.Cin == 128) launch_tile_ld<128, 64, TW, TH, SPS, false, true>(a, grid, st); else launch_tile_ld<64, 64, TW, TH, 1, false, true>(a, grid, st);
+        if (a.Cin == 128) {
+            if constexpr (SPS == 4) {
+                static int nt = -1;
+                if (nt < 0) { const char* e = pa_getenv("PA_CONV3_NT"); nt = e ? atoi(e) : 512; }      // measured 8x8: 14.1 / 10.6 / 12.8 us at 256 / 512 / 1024 threads
+                if (nt == 512) { launch_tile_ld<128, 64, TW, TH, SPS, false, true, 512>(a, grid, st); return; }
+                if (nt == 1024) { launch_tile_ld<128, 64, TW, TH, SPS, false, true, 1024>(a, grid, st); return; }
+            }
+            launch_tile_ld<128, 64, TW, TH, SPS, false, true>(a, grid, st);
+        } else launch_tile_ld<64, 64, TW, TH, 1, false, true>(a, grid, st);
     } else if constexpr (TH == 8 && SPS == 1) {
         static int pf = -1;
         if (pf < 0) { const char* e = pa_getenv("PA_CONV3_PF"); pf = e ? atoi(e) : 1; }
@@ -412,7 +461,20 @@ static void launch_tile_shape(const PaConvArgs& a, dim3 grid, bool bigN, hipStre
             else { if (bigN) launch_tile_ld<64, 128, TW, TH, 1, false>(a, grid, st); else launch_tile_ld<64, 64, TW, TH, 1, false>(a, grid, st); }
         }
     } else {
-        if (a.Cin == 128) { if (bigN) launch_tile_ld<128, 128, TW, TH, SPS, false, (SPS == 2)>(a, grid, st); else launch_tile_ld<128, 64, TW, TH, SPS, false, (SPS == 2)>(a, grid, st); }
+        if (a.Cin == 128) {
+            if constexpr (SPS == 2) {
+                // 512 threads when the launch is at most one workgroup per CU (the 16 x 16 maps in 64-channel halves: 192 workgroups, 12.0 -> 8.6 us);
+                // with two workgroups per CU (32 x 32) the 256-thread workgroups already overlap each other and 512 measured slower (16.1 vs 18.2)
+                static int nt = -1, cus = 0;
+                if (nt < 0) {
+                    int dev = 0;
+                    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
+                    const char* e = pa_getenv("PA_CONV3_NT16"); nt = e ? atoi(e) : 512;
+                }
+                if (nt == 512 && (int)(grid.x * grid.y) <= cus) { if (bigN) launch_tile_ld<128, 128, TW, TH, SPS, false, true, 512>(a, grid, st); else launch_tile_ld<128, 64, TW, TH, SPS, false, true, 512>(a, grid, st); return; }
+            }
+            if (bigN) launch_tile_ld<128, 128, TW, TH, SPS, false, (SPS == 2)>(a, grid, st); else launch_tile_ld<128, 64, TW, TH, SPS, false, (SPS == 2)>(a, grid, st);
+        }
         else { if (bigN) launch_tile_ld<64, 128, TW, TH, 1, false>(a, grid, st); else launch_tile_ld<64, 64, TW, TH, 1, false>(a, grid, st); }
     }
 }
@@ -454,7 +516,11 @@ int pa_launch_conv3x3_tile(const PaConvArgs& a, hipStream_t st, int* stat_rows) 
     static int n64 = -1;
     if (n64 < 0) n64 = pa_getenv("PA_CONV3_BN64") ? 1 : 0;          // experiment: 64-channel halves
     // the low-resolution levels have 3..12 pixel tiles: 64-channel halves double the number of workgroups
-    const bool bigN = a.Cout % 128 == 0 && !n64 && !small;
+    // ... and so do the 16 x 4 tiles (32 x 32 / 16 x 16 maps): 64-channel blocks halve the serial chain of a workgroup (weight pieces, MFMAs,
+    // epilogue) -- 32 x 32: 16.5 -> 16.1 / 19.3 -> 17.8 us (forward / data gradient), 16 x 16: see launch_tile_shape
+    static int h64 = -1;
+    if (h64 < 0) { const char* e = pa_getenv("PA_CONV3_HALF64"); h64 = e ? atoi(e) : 1; }
+    const bool bigN = a.Cout % 128 == 0 && !n64 && !small && !(half && h64);
     dim3 grid(tiles, a.Cout / (bigN ? 128 : 64));
     static int xcd = -1;
     if (xcd < 0) xcd = pa_getenv("PA_CONV3_NOXCD") ? 0 : 1;          // +0.3 % on the step (halo re-reads served by the XCD's own L2)
