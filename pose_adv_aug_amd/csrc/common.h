@@ -46,6 +46,20 @@ inline const char* pa_getenv(const char* name) { return getenv(name); }
 #else
 inline const char* pa_getenv(const char*) { return nullptr; }
 #endif
+// Cycle stamps inside a kernel (tuning builds; tools/conv3_clocks.py): PA_STAMP_DECL(sym, fn) defines the device array and its C accessor
+// in one translation unit, PA_STAMP_AT(sym, on, i) records {s_memtime (shader cycles), wall_clock64 (100 MHz)} of thread 0 of workgroup (0, 0).
+#ifdef PA_TUNING
+#define PA_STAMP_DECL(sym, fn)                                                                                              \
+    __device__ unsigned long long sym[32];                                                                                  \
+    extern "C" int fn(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(sym), sizeof(unsigned long long) * 32); }
+#define PA_STAMP_AT(sym, on, i)                                                                                             \
+    do {                                                                                                                    \
+        if ((on) && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { sym[2 * (i)] = __builtin_amdgcn_s_memtime(); sym[2 * (i) + 1] = wall_clock64(); } \
+    } while (0)
+#else
+#define PA_STAMP_DECL(sym, fn)
+#define PA_STAMP_AT(sym, on, i) do { } while (0)
+#endif
 
 void pa_set_error(const char* what, hipError_t e, const char* file, int line);
 void pa_set_error_msg(const char* msg);

@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256, (CIN == 128 && BM == 64) ? 3 : 2) void conv1x1
         float* T = reinterpret_cast<float*>(wbuf + ((nbi * KT + KT - 1) & 1) * (BN * 64));
         // BatchNorm-backward epilogue through LDS only for 256 input channels (cold 70 vs 76 us); the 128-channel kernels
         // (3 workgroups per CU, 168 registers) spill with it: 98 vs 70 us
-        pa_conv_epilogue_auto<BN, NI, MI, (CIN == 256 || CTAB), CTAB>(a, acc, (nb0 + nbi) * BN, wm, wn,
+        pa_conv_epilogue_auto<BN, NI, MI, (CIN == 256 || CTAB), CTAB, 256, (BN < 128)>(a, acc, (nb0 + nbi) * BN, wm, wn,
                                          [&](int wr, int mi, int p) { const int m = m0 + wr * (BM / 2) + mi * 16 + p; return m < M ? m : -1; },
                                          T, (int)blockIdx.x, CTAB ? reinterpret_cast<float4*>(lds + BM * CIN + 2 * BN * 64) : nullptr);
         __syncthreads();            // T is handed back to the weight ring

@@ -65,17 +65,9 @@ template <int N> __device__ __forceinline__ void pa_wait_vmcnt() {
 // stamps (tools/conv3_clocks.py) show a K-loop step as the plain SUM of its parts (barrier ~100 cycles, each LDS-DMA issue 100-150, the ds_read
 // round trip ~150, 17 per MFMA: 45-60 cycles per MFMA instead of 17), and the staging / epilogue are load / store round trips of 4 waves.  Two
 // or four waves per SIMD (the same 128 pixels x 64 channels, MI = 2 or 1 fragments per wave) let one wave's MFMAs run under another's waits.
-#ifdef PA_TUNING
-// cycle stamps of workgroup (0, 0), thread 0 (a.dbg & 64): {s_memtime, wall_clock64} at entry / weight ring issued / own halo part staged / K loop /
-// barrier / epilogue
-__device__ unsigned long long pa_conv3_clk[16];
-extern "C" int pa_debug_conv3_clocks(unsigned long long* out) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pa_conv3_clk), sizeof(unsigned long long) * 16);
-}
-#define PA_STAMP(i) do { if ((a.dbg & 64) && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { pa_conv3_clk[2 * (i)] = __builtin_amdgcn_s_memtime(); pa_conv3_clk[2 * (i) + 1] = wall_clock64(); } } while (0)
-#else
-#define PA_STAMP(i) do { } while (0)
-#endif
+// cycle stamps (tuning builds, a.dbg & 64): entry / weight ring issued / own halo part staged / K loop / barrier / epilogue
+PA_STAMP_DECL(pa_conv3_clk, pa_debug_conv3_clocks)
+#define PA_STAMP(i) PA_STAMP_AT(pa_conv3_clk, a.dbg & 64, i)
 template <int CIN, int BN, int LDMODE, int TW = 16, int TH = 8, int SPS = 1, bool PF = false, int NT = 256, bool FIN = false>
 __global__ __launch_bounds__(NT, (NT >= 512 ? 1 : (TW == 16 ? (TH == 4 ? (SPS == 1 ? 3 : 2) : 2) : 1))) void conv3x3_tile_kernel(PaConvArgs a) {
     constexpr bool TRI = NT == 512 && TW == 16 && TH == 8;

@@ -10,6 +10,9 @@
 #pragma once
 #include "common.h"
 #include "kernels.h"
+#ifndef PA_EPI_STAMP
+#define PA_EPI_STAMP(i) do { } while (0)
+#endif
 
 // LDS row lr (0 .. BN-1) of the weight tile holds which output channel (relative to the tile's n0)?
 template <int BN, int NI>
@@ -135,6 +138,67 @@ __device__ __forceinline__ void pa_conv_epilogue(const PaConvArgs& a, f32x4 (&ac
     }
 }
 
+// LDS-only workgroup barrier: __syncthreads() also drains vmcnt, i.e. waits for every global load AND store in flight -- between the passes of
+// an epilogue that is the round trip of the previous pass's output stores (and of operand loads requested ahead), for a barrier that only
+// orders LDS accesses
+__device__ __forceinline__ void pa_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// Per-channel sums of the workgroup from the threads' 8-channel partial sums {s1, s2} (thread = chunk tid % CPR of row group tid / CPR), through
+// LDS: P >= NT * 16 floats, dead (callers barrier first).  Returns the two sums of channel tid (threads tid < BN; others return 0).
+// Order (the one of the shuffle tree this replaces -- 48 ds_bpermute per thread, 1500 cycles of a 5000-cycle epilogue on the one-wave-per-SIMD
+// launches): inside a wave the 64 / CPR row groups of a chunk combine as a balanced tree over neighbours (lane ^ CPR, ^ 2 CPR, ...), then the
+// waves are added in order.
+// TSMALL: P holds NT * 8 floats only (the 64-channel row-tile kernel's ring half): the two sums go through it one after the other.
+template <int BN, int NT, bool TSMALL = false>
+__device__ __forceinline__ f32x2 pa_stats_reduce(const float (&s1)[8], const float (&s2)[8], float* P) {
+    constexpr int CPR = BN / 8, KPW = 64 / CPR, NW = NT / 64;
+    const int tid = threadIdx.x;
+    const int chunk = tid % CPR, g = tid / CPR;
+    f32x2 tot = {0.f, 0.f};
+    if constexpr (TSMALL) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (h) pa_lds_barrier();
+            f32x4* dst = reinterpret_cast<f32x4*>(P + g * BN + chunk * 8);
+            const float (&s)[8] = h ? s2 : s1;
+            dst[0] = f32x4{s[0], s[1], s[2], s[3]}; dst[1] = f32x4{s[4], s[5], s[6], s[7]};
+            pa_lds_barrier();
+            if (tid < BN) {
+#pragma unroll
+                for (int w = 0; w < NW; ++w) {
+                    float v[KPW];
+#pragma unroll
+                    for (int k = 0; k < KPW; ++k) v[k] = P[(w * KPW + k) * BN + tid];
+#pragma unroll
+                    for (int o = 1; o < KPW; o <<= 1)
+#pragma unroll
+                        for (int k = 0; k < KPW; k += 2 * o) v[k] += v[k + o];
+                    tot[h] = w == 0 ? v[0] : tot[h] + v[0];
+                }
+            }
+        }
+        return tot;
+    }
+    f32x4* dst = reinterpret_cast<f32x4*>(P + (g * BN + chunk * 8) * 2);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dst[j] = f32x4{s1[2 * j], s2[2 * j], s1[2 * j + 1], s2[2 * j + 1]};
+    pa_lds_barrier();
+    if (tid < BN) {
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            f32x2 v[KPW];
+#pragma unroll
+            for (int k = 0; k < KPW; ++k) v[k] = *reinterpret_cast<const f32x2*>(P + ((w * KPW + k) * BN + tid) * 2);
+#pragma unroll
+            for (int o = 1; o < KPW; o <<= 1)
+#pragma unroll
+                for (int k = 0; k < KPW; k += 2 * o) v[k] += v[k + o];
+            tot = w == 0 ? v[0] : tot + v[0];
+        }
+    }
+    return tot;
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // LDS-TRANSPOSED epilogue.  The direct epilogue above stores, per instruction, 16-byte pieces that lie 32 bytes apart
 // in 16 different pixel rows: measured on the 3x3 tile kernel (tools/bench_conv3.py ablation) the plain store of a
@@ -143,7 +207,8 @@ __device__ __forceinline__ void pa_conv_epilogue(const PaConvArgs& a, f32x4 (&ac
 // pixel row: every global access of the epilogue (addends, reference tensor, output) is a fully coalesced 16 B/lane
 // stream, and a thread owns the SAME 8 channels for all its pixels (bias / BatchNorm constants loaded once,
 // per-channel reductions in registers).  Arithmetic and rounding points are those of pa_conv_epilogue.
-//   T   : >= 32 * BN floats of LDS that are dead after the K loop (16-byte slots XOR-swizzled by the row)
+//   T   : >= max(32 * BN, 16 * NT) floats of LDS that are dead after the K loop (16-byte slots XOR-swizzled by the row; the statistics reduction
+//         takes 16 floats per thread -- TSMALL: 8)
 //   pix : (wm, mi, p) -> flattened NHWC pixel index of pixel p (0..15) of fragment row-block mi of wave row wm, or -1
 // Measured (tools/bench_conv1.py, bench.py): forward epilogues (plain / statistics, with residual addends) gain 10-30 %
 // on the 1x1 kernels; the BatchNorm-backward epilogue (reference tensor + mask + two reductions) is SLOWER this way
@@ -151,7 +216,7 @@ __device__ __forceinline__ void pa_conv_epilogue(const PaConvArgs& a, f32x4 (&ac
 // sweep's operands costs more registers than it hides).  pa_conv_epilogue_auto therefore keeps the direct epilogue
 // for PA_OUT_BWD.
 // NT = threads of the workgroup: 256 (2 waves along the pixels: 32-row passes) or 512 (4 waves along the pixels: 64-row passes, T >= 64 * BN floats)
-template <int BN, int NI, int MI, int NT = 256, class PixFn>
+template <int BN, int NI, int MI, int NT = 256, bool TSMALL = false, class PixFn>
 __device__ __forceinline__ void pa_conv_epilogue_lds(const PaConvArgs& a, f32x4 (&acc)[NI][MI], int n0, int wm, int wn,
                                                      PixFn pix, float* T, int stat_row) {
     constexpr int CPR = BN / 8;                      // 8-channel chunks per pixel row
@@ -164,17 +229,79 @@ __device__ __forceinline__ void pa_conv_epilogue_lds(const PaConvArgs& a, f32x4 
     const int n = n0 + chunk * 8;
     float bias[8], s1[8], s2[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; bias[j] = a.bias ? a.bias[n + j] : 0.f; }
+    for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; bias[j] = 0.f; }
+    if (a.bias) {                                    // (one uniform branch around the eight loads: a select per element made hipcc wait for them in front of the staging)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bias[j] = a.bias[n + j];
+    }
+    // PRE (workgroup tiles of at most two sweeps: the latency-bound small launches): the raw addend operands of every sweep and the addends'
+    // per-channel constants are requested HERE, before the staging barrier, instead of inside each sweep (a memory round trip per sweep with
+    // one wave per SIMD).  Same arithmetic as pa_read8 (pa_apply8).
+    constexpr int IT = MI * SW;
+    constexpr bool PRE = IT <= 2;
+    const int m1 = a.add1.mode, m2 = a.add2.mode;
+    bf16x8 p1[PRE ? IT : 1], q1[PRE ? IT : 1], p2[PRE ? IT : 1], q2[PRE ? IT : 1];
+    float ka1[8], kb1[8], kc1[8], ka2[8], kb2[8], kc2[8];
+    if constexpr (PRE) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int sw = 0; sw < SW; ++sw) {
+                const int it = mi * SW + sw, r = sw * RPS + rsub;
+                const int m = pix(r >> 4, mi, r & 15);
+                const unsigned idx = m < 0 ? 0u : (unsigned)m * (unsigned)N + (unsigned)n;      // clamped, unconditional
+                if (m1 != PA_LD_NONE) p1[it] = *reinterpret_cast<const bf16x8*>(a.add1.p + idx);
+                if (m1 == PA_LD_LIN2) q1[it] = *reinterpret_cast<const bf16x8*>(a.add1.q + idx);
+                if (m2 != PA_LD_NONE) p2[it] = *reinterpret_cast<const bf16x8*>(a.add2.p + idx);
+                if (m2 == PA_LD_LIN2) q2[it] = *reinterpret_cast<const bf16x8*>(a.add2.q + idx);
+            }
+        if (m1 == PA_LD_BNRELU || m1 == PA_LD_LIN2) {
+            const f32x4 s0 = *reinterpret_cast<const f32x4*>(a.add1.k0 + n), s4 = *reinterpret_cast<const f32x4*>(a.add1.k0 + n + 4);
+            const f32x4 t0 = *reinterpret_cast<const f32x4*>(a.add1.k1 + n), t4 = *reinterpret_cast<const f32x4*>(a.add1.k1 + n + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { ka1[j] = s0[j]; ka1[j + 4] = s4[j]; kb1[j] = t0[j]; kb1[j + 4] = t4[j]; }
+            if (m1 == PA_LD_LIN2) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) kc1[j] = a.add1.k2[n + j];
+            }
+        }
+        if (m2 == PA_LD_BNRELU || m2 == PA_LD_LIN2) {
+            const f32x4 s0 = *reinterpret_cast<const f32x4*>(a.add2.k0 + n), s4 = *reinterpret_cast<const f32x4*>(a.add2.k0 + n + 4);
+            const f32x4 t0 = *reinterpret_cast<const f32x4*>(a.add2.k1 + n), t4 = *reinterpret_cast<const f32x4*>(a.add2.k1 + n + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { ka2[j] = s0[j]; ka2[j + 4] = s4[j]; kb2[j] = t0[j]; kb2[j + 4] = t4[j]; }
+            if (m2 == PA_LD_LIN2) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) kc2[j] = a.add2.k2[n + j];
+            }
+        }
+    }
+    auto addend = [](int md, const bf16x8& p, const bf16x8& q, const float (&ka)[8], const float (&kb)[8], const float (&kc)[8], float (&v)[8]) {
+        if (md == PA_LD_NONE) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = 0.f;
+        } else if (md == PA_LD_PLAIN) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (float)p[j];
+        } else if (md == PA_LD_BNRELU) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = fmaxf(fmaf(ka[j], (float)p[j], kb[j]), 0.f);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = fmaf(ka[j], (float)p[j], fmaf(kb[j], (float)q[j], kc[j]));
+        }
+    };
     // writer side: lane (q = lane >> 4, p = lane & 15) of wave (wm, wn) holds channels wn*BN/2 + q*4*NI + 4*ni + reg of pixel p
     const int wrow = wm * 16 + (lane & 15);
     const int wslot0 = (wn * (BN / 2)) / 4 + 2 * (lane >> 4);                // 16-byte slot (4 floats) of fragment 0; fragment ni: + 8*(ni>>1) + (ni&1)
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
-        if (mi) __syncthreads();                     // the previous pass has been read
+        if (mi) pa_lds_barrier();                    // the previous pass has been read
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni)
             *reinterpret_cast<f32x4*>(T + wrow * BN + (((wslot0 + 8 * (ni >> 1) + (ni & 1)) ^ (wrow & 7)) << 2)) = acc[ni][mi];
-        __syncthreads();
+        pa_lds_barrier();
+        PA_EPI_STAMP(7 + 2 * mi);
 #pragma unroll
         for (int sw = 0; sw < SW; ++sw) {
             const int r = sw * RPS + rsub;           // 0..31: wave row r >> 4, pixel r & 15
@@ -184,8 +311,13 @@ __device__ __forceinline__ void pa_conv_epilogue_lds(const PaConvArgs& a, f32x4 
             const f32x4 v1 = *reinterpret_cast<const f32x4*>(T + r * BN + (((2 * chunk + 1) ^ (r & 7)) << 2));
             const unsigned idx = (unsigned)m * (unsigned)N + (unsigned)n;
             float e1[8], e2[8];
-            pa_read8(a.add1, idx, n, e1);
-            pa_read8(a.add2, idx, n, e2);
+            if constexpr (PRE) {
+                addend(m1, p1[mi * SW + sw], q1[mi * SW + sw], ka1, kb1, kc1, e1);
+                addend(m2, p2[mi * SW + sw], q2[mi * SW + sw], ka2, kb2, kc2, e2);
+            } else {
+                pa_read8(a.add1, idx, n, e1);
+                pa_read8(a.add2, idx, n, e2);
+            }
             bf16x8 o;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -197,28 +329,13 @@ __device__ __forceinline__ void pa_conv_epilogue_lds(const PaConvArgs& a, f32x4 
             }
             *reinterpret_cast<bf16x8*>(a.out + idx) = o;
         }
+        PA_EPI_STAMP(8 + 2 * mi);
     }
     if (a.ep.mode != PA_OUT_PLAIN) {
-        // threads with the same chunk: lanes l, l + CPR, ... of a wave, then the 4 waves through LDS
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-#pragma unroll
-            for (int o = CPR; o < 64; o <<= 1) { s1[j] += __shfl_xor(s1[j], o, 64); s2[j] += __shfl_xor(s2[j], o, 64); }
-        }
-        __syncthreads();                             // T is dead
-        const int wave = tid >> 6;
-        if (lane < CPR) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { T[(wave * BN + chunk * 8 + j) * 2] = s1[j]; T[(wave * BN + chunk * 8 + j) * 2 + 1] = s2[j]; }
-        }
-        __syncthreads();
-        for (int c = tid; c < BN; c += NT) {
-            f32x2 v = {T[c * 2] + T[(BN + c) * 2] + T[(2 * BN + c) * 2] + T[(3 * BN + c) * 2],
-                       T[c * 2 + 1] + T[(BN + c) * 2 + 1] + T[(2 * BN + c) * 2 + 1] + T[(3 * BN + c) * 2 + 1]};
-#pragma unroll
-            for (int w = 4; w < NW; ++w) { v[0] += T[(w * BN + c) * 2]; v[1] += T[(w * BN + c) * 2 + 1]; }
-            *reinterpret_cast<f32x2*>(a.ep.stats + ((size_t)stat_row * N + n0 + c) * 2) = v;
-        }
+        PA_EPI_STAMP(11);
+        pa_lds_barrier();                            // T is dead
+        const f32x2 v = pa_stats_reduce<BN, NT, TSMALL>(s1, s2, T);
+        if (tid < BN) *reinterpret_cast<f32x2*>(a.ep.stats + ((size_t)stat_row * N + n0 + tid) * 2) = v;
     }
 }
 
@@ -229,7 +346,7 @@ __device__ __forceinline__ void pa_conv_epilogue_lds(const PaConvArgs& a, f32x4 
 // (2) a thread owns the same 8 channels for all its pixels, so the constants live in registers; (3) the second reduction
 // is accumulated as sum(dz * x) and turned into sum(dz * xhat) = invstd * (sum(dz*x) - mean * sum(dz)) once per
 // workgroup row, which removes mean / invstd from the per-element work.
-template <int BN, int NI, int MI, bool TAB, int NT = 256, class PixFn>
+template <int BN, int NI, int MI, bool TAB, int NT = 256, bool TSMALL = false, class PixFn>
 __device__ __forceinline__ void pa_conv_epilogue_lds_bwd(const PaConvArgs& a, f32x4 (&acc)[NI][MI], int n0, int wm, int wn,
                                                          PixFn pix, float* T, int stat_row, float4* ctab = nullptr) {
     // ctab (optional, 2 * BN float4 of LDS outside T): the per-channel constants live there instead of in 40 registers
@@ -287,11 +404,11 @@ __device__ __forceinline__ void pa_conv_epilogue_lds_bwd(const PaConvArgs& a, f3
 #pragma unroll
         for (int pp = 0; pp < G; ++pp) {
             const int mi = g + pp;
-            if (mi) __syncthreads();                 // the previous pass has been read
+            if (mi) pa_lds_barrier();                // the previous pass has been read
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni)
                 *reinterpret_cast<f32x4*>(T + wrow * BN + (((wslot0 + 8 * (ni >> 1) + (ni & 1)) ^ (wrow & 7)) << 2)) = acc[ni][mi];
-            __syncthreads();
+            pa_lds_barrier();
 #pragma unroll
             for (int sw = 0; sw < SW; ++sw) {
                 const int it = pp * SW + sw, r = sw * RPS + rsub;
@@ -321,26 +438,14 @@ __device__ __forceinline__ void pa_conv_epilogue_lds_bwd(const PaConvArgs& a, f3
             }
         }
     }
-    // ---- statistics row: lanes l, l + CPR, ... of a wave share a chunk, then the 4 waves through LDS
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-#pragma unroll
-        for (int o = CPR; o < 64; o <<= 1) { s1[j] += __shfl_xor(s1[j], o, 64); s2[j] += __shfl_xor(s2[j], o, 64); }
-    }
-    __syncthreads();                                 // T is dead
-    const int wave = tid >> 6;
-    if (lane < CPR) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { T[(wave * BN + chunk * 8 + j) * 2] = s1[j]; T[(wave * BN + chunk * 8 + j) * 2 + 1] = s2[j]; }
-    }
-    __syncthreads();
-    for (int c = tid; c < BN; c += NT) {
-        float a1 = T[c * 2] + T[(BN + c) * 2] + T[(2 * BN + c) * 2] + T[(3 * BN + c) * 2];
-        float a2 = T[c * 2 + 1] + T[(BN + c) * 2 + 1] + T[(2 * BN + c) * 2 + 1] + T[(3 * BN + c) * 2 + 1];
-#pragma unroll
-        for (int w = 4; w < NW; ++w) { a1 += T[(w * BN + c) * 2]; a2 += T[(w * BN + c) * 2 + 1]; }
-        f32x2 v = {a1, a.ep.invstd[n0 + c] * (a2 - a.ep.mean[n0 + c] * a1)};
-        *reinterpret_cast<f32x2*>(a.ep.stats + ((size_t)stat_row * N + n0 + c) * 2) = v;
+    // ---- statistics row (the mean / invstd of the channel requested before the reduction's barrier)
+    float cm = 0.f, ci = 0.f;
+    if (tid < BN) { cm = a.ep.mean[n0 + tid]; ci = a.ep.invstd[n0 + tid]; }
+    pa_lds_barrier();                                // T is dead
+    const f32x2 t = pa_stats_reduce<BN, NT, TSMALL>(s1, s2, T);
+    if (tid < BN) {
+        f32x2 v = {t[0], ci * (t[1] - cm * t[0])};
+        *reinterpret_cast<f32x2*>(a.ep.stats + ((size_t)stat_row * N + n0 + tid) * 2) = v;
     }
 }
 
@@ -351,7 +456,8 @@ __host__ __device__ inline bool pa_bwd_epilogue_lds_ok(const PaConvArgs& a) {
 }
 
 // forward epilogues through LDS (coalesced rows), backward epilogue direct; pix(wm, mi, p) as above
-template <int BN, int NI, int MI, bool BWD_LDS = true, bool TAB = false, int NT = 256, class PixFn>
+// T: >= NT * 16 floats, or (TSMALL) >= NT * 8
+template <int BN, int NI, int MI, bool BWD_LDS = true, bool TAB = false, int NT = 256, bool TSMALL = false, class PixFn>
 __device__ __forceinline__ void pa_conv_epilogue_auto(const PaConvArgs& a, f32x4 (&acc)[NI][MI], int n0, int wm, int wn,
                                                       PixFn pix, float* T, int stat_row, float4* ctab = nullptr) {
     if (a.ep.mode == PA_OUT_BWD) {
@@ -359,7 +465,7 @@ __device__ __forceinline__ void pa_conv_epilogue_auto(const PaConvArgs& a, f32x4
         // the networks); anything else takes the direct epilogue
         const bool lds_ok = BWD_LDS && pa_bwd_epilogue_lds_ok(a);
         if (lds_ok) {
-            pa_conv_epilogue_lds_bwd<BN, NI, MI, TAB, NT>(a, acc, n0, wm, wn, pix, T, stat_row, ctab);
+            pa_conv_epilogue_lds_bwd<BN, NI, MI, TAB, NT, TSMALL>(a, acc, n0, wm, wn, pix, T, stat_row, ctab);
         } else if constexpr (TAB || NT != 256) {
             __builtin_trap();       // the 168-register / 512-thread kernels carry no direct epilogue: pa_bwd_epilogue_lds_ok() routes such launches elsewhere
         } else {
@@ -367,6 +473,6 @@ __device__ __forceinline__ void pa_conv_epilogue_auto(const PaConvArgs& a, f32x4
             pa_conv_epilogue<BN, NI, MI>(a, acc, n0, wm, wn, [&](int mi) { return pix(wm, mi, p); }, T, stat_row);
         }
     } else {
-        pa_conv_epilogue_lds<BN, NI, MI, NT>(a, acc, n0, wm, wn, pix, T, stat_row);
+        pa_conv_epilogue_lds<BN, NI, MI, NT, TSMALL>(a, acc, n0, wm, wn, pix, T, stat_row);
     }
 }

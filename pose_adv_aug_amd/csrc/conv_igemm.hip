@@ -19,6 +19,11 @@
 // one pixel (8-byte bf16x4 stores, per-channel reductions over the 16 pixel lanes by DPP shuffles).
 #include "common.h"
 #include "kernels.h"
+#include "common.h"
+// cycle stamps (tuning builds, a.dbg & 64): entry / loads issued / constants (finalize prologue) / staged / barrier / K loop / epilogue parts
+PA_STAMP_DECL(pa_conv1_clk, pa_debug_conv1_clocks)
+#define PA_STAMP1(i) PA_STAMP_AT(pa_conv1_clk, a.dbg & 64, i)
+#define PA_EPI_STAMP(i) PA_STAMP1(i)
 #include "conv_epilogue.h"
 
 // STEM: the A operand is the 4-channel-padded input image and the kernel computes the 7x7 stride-2
@@ -210,6 +215,7 @@ __global__ __launch_bounds__(256, FIN ? 2 : 1) void conv_igemm_kernel(PaConvArgs
 // (the MFMA accumulation order over K is unchanged).
 template <int NK, int LDMODE, bool FIN>
 __global__ __launch_bounds__(256, 2) void conv1x1_oneshot_kernel(PaConvArgs a) {
+    PA_STAMP1(0);
     constexpr int BM = 64, BN = 64, AI = 2, BI = 2, MI = 2, NI = 2;
     __shared__ __attribute__((aligned(16))) bf16 lds[(BM + BN) * 64 * NK];
     __shared__ float kst[LDMODE == PA_LD_PLAIN ? 4 : 3 * 512 + (FIN ? 2048 : 0)];
@@ -239,6 +245,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_oneshot_kernel(PaConvArgs a) {
         for (int i = 0; i < BI; ++i)
             xb[kt][i] = *reinterpret_cast<const bf16x8*>(a.w + (size_t)(n0 + r + 32 * i) * K + kt * 64 + cc * 8);
     }
+    PA_STAMP1(1);
     // ---- per-channel constants of the input transform (or the pending BatchNorm finalize, bn_fin.h), while the loads travel
     if (LDMODE != PA_LD_PLAIN) {
         bool fin_done = false;
@@ -253,6 +260,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_oneshot_kernel(PaConvArgs a) {
             __syncthreads();
         }
     }
+    PA_STAMP1(2);
     // ---- transform + stage the whole K range
 #pragma unroll
     for (int kt = 0; kt < NK; ++kt) {
@@ -282,7 +290,9 @@ __global__ __launch_bounds__(256, 2) void conv1x1_oneshot_kernel(PaConvArgs a) {
             *reinterpret_cast<bf16x8*>(Bs + kt * (BN * 64) + lrow * 64 + ((cc ^ (lrow & 7)) << 3)) = xb[kt][i];
         }
     }
+    PA_STAMP1(3);
     __syncthreads();
+    PA_STAMP1(4);
 
     f32x4 acc[NI][MI];
 #pragma unroll
@@ -311,14 +321,20 @@ __global__ __launch_bounds__(256, 2) void conv1x1_oneshot_kernel(PaConvArgs a) {
                 for (int mi = 0; mi < MI; ++mi)
                     acc[ni][mi] = PA_MFMA_16x16x32(fw[ni], fa[mi], acc[ni][mi]);
         }
+    PA_STAMP1(5);
     __syncthreads();            // every wave is done with the tiles before the epilogue reuses the LDS
     pa_conv_epilogue_auto<BN, NI, MI>(a, acc, n0, wm, wn,
                                      [&](int wr, int mi, int p) { const int m = m0 + wr * (BM / 2) + mi * 16 + p; return m < M ? m : -1; },
                                      reinterpret_cast<float*>(lds), (int)blockIdx.x);
+    PA_STAMP1(6);
 }
 
 template <int NK>
-static void launch_oneshot(const PaConvArgs& a, dim3 grid, hipStream_t st) {
+static void launch_oneshot(const PaConvArgs& a0, dim3 grid, hipStream_t st) {
+    PaConvArgs a = a0;
+    static int dbg = -1;
+    if (dbg < 0) { const char* e = pa_getenv("PA_CONV1_DBG"); dbg = e ? atoi(e) : 0; }      // tuning builds: cycle stamps
+    a.dbg = dbg;
     if (a.fin.rows > 0) {
         if (a.in.mode == PA_LD_BNRELU) hipLaunchKernelGGL((conv1x1_oneshot_kernel<NK, PA_LD_BNRELU, true>), grid, dim3(256), 0, st, a);
         else hipLaunchKernelGGL((conv1x1_oneshot_kernel<NK, PA_LD_LIN2, true>), grid, dim3(256), 0, st, a);
