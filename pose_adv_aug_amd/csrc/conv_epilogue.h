@@ -184,16 +184,18 @@ __device__ __forceinline__ f32x2 pa_stats_reduce(const float (&s1)[8], const flo
     for (int j = 0; j < 4; ++j) dst[j] = f32x4{s1[2 * j], s2[2 * j], s1[2 * j + 1], s2[2 * j + 1]};
     pa_lds_barrier();
     if (tid < BN) {
+        f32x2 v[NW][KPW];                            // every read in flight before the first addition
+#pragma unroll
+        for (int w = 0; w < NW; ++w)
+#pragma unroll
+            for (int k = 0; k < KPW; ++k) v[w][k] = *reinterpret_cast<const f32x2*>(P + ((w * KPW + k) * BN + tid) * 2);
 #pragma unroll
         for (int w = 0; w < NW; ++w) {
-            f32x2 v[KPW];
-#pragma unroll
-            for (int k = 0; k < KPW; ++k) v[k] = *reinterpret_cast<const f32x2*>(P + ((w * KPW + k) * BN + tid) * 2);
 #pragma unroll
             for (int o = 1; o < KPW; o <<= 1)
 #pragma unroll
-                for (int k = 0; k < KPW; k += 2 * o) v[k] += v[k + o];
-            tot = w == 0 ? v[0] : tot + v[0];
+                for (int k = 0; k < KPW; k += 2 * o) v[w][k] += v[w][k + o];
+            tot = w == 0 ? v[0][0] : tot + v[w][0];
         }
     }
     return tot;
@@ -216,7 +218,9 @@ __device__ __forceinline__ f32x2 pa_stats_reduce(const float (&s1)[8], const flo
 // sweep's operands costs more registers than it hides).  pa_conv_epilogue_auto therefore keeps the direct epilogue
 // for PA_OUT_BWD.
 // NT = threads of the workgroup: 256 (2 waves along the pixels: 32-row passes) or 512 (4 waves along the pixels: 64-row passes, T >= 64 * BN floats)
-template <int BN, int NI, int MI, int NT = 256, bool TSMALL = false, class PixFn>
+// FUSE (MI * BN <= 128, i.e. the whole workgroup tile fits the 16 * NT floats the statistics reduction needs anyway): all MI passes are staged at
+// once -- one barrier instead of 2 * MI - 1
+template <int BN, int NI, int MI, int NT = 256, bool TSMALL = false, bool FUSE = false, class PixFn>
 __device__ __forceinline__ void pa_conv_epilogue_lds(const PaConvArgs& a, f32x4 (&acc)[NI][MI], int n0, int wm, int wn,
                                                      PixFn pix, float* T, int stat_row) {
     constexpr int CPR = BN / 8;                      // 8-channel chunks per pixel row
@@ -294,21 +298,33 @@ __device__ __forceinline__ void pa_conv_epilogue_lds(const PaConvArgs& a, f32x4 
     // writer side: lane (q = lane >> 4, p = lane & 15) of wave (wm, wn) holds channels wn*BN/2 + q*4*NI + 4*ni + reg of pixel p
     const int wrow = wm * 16 + (lane & 15);
     const int wslot0 = (wn * (BN / 2)) / 4 + 2 * (lane >> 4);                // 16-byte slot (4 floats) of fragment 0; fragment ni: + 8*(ni>>1) + (ni&1)
+    constexpr int ROWS = NT / 8;                     // pixel rows of a pass (16 per wave row)
+    if constexpr (FUSE) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+                *reinterpret_cast<f32x4*>(T + (mi * ROWS + wrow) * BN + (((wslot0 + 8 * (ni >> 1) + (ni & 1)) ^ (wrow & 7)) << 2)) = acc[ni][mi];
+        pa_lds_barrier();
+    }
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
-        if (mi) pa_lds_barrier();                    // the previous pass has been read
+        if constexpr (!FUSE) {
+            if (mi) pa_lds_barrier();                // the previous pass has been read
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
-            *reinterpret_cast<f32x4*>(T + wrow * BN + (((wslot0 + 8 * (ni >> 1) + (ni & 1)) ^ (wrow & 7)) << 2)) = acc[ni][mi];
-        pa_lds_barrier();
+            for (int ni = 0; ni < NI; ++ni)
+                *reinterpret_cast<f32x4*>(T + wrow * BN + (((wslot0 + 8 * (ni >> 1) + (ni & 1)) ^ (wrow & 7)) << 2)) = acc[ni][mi];
+            pa_lds_barrier();
+        }
         PA_EPI_STAMP(7 + 2 * mi);
+        const float* Tp = T + (FUSE ? mi * ROWS * BN : 0);
 #pragma unroll
         for (int sw = 0; sw < SW; ++sw) {
             const int r = sw * RPS + rsub;           // 0..31: wave row r >> 4, pixel r & 15
             const int m = pix(r >> 4, mi, r & 15);
             if (m < 0) continue;
-            const f32x4 v0 = *reinterpret_cast<const f32x4*>(T + r * BN + (((2 * chunk) ^ (r & 7)) << 2));
-            const f32x4 v1 = *reinterpret_cast<const f32x4*>(T + r * BN + (((2 * chunk + 1) ^ (r & 7)) << 2));
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(Tp + r * BN + (((2 * chunk) ^ (r & 7)) << 2));
+            const f32x4 v1 = *reinterpret_cast<const f32x4*>(Tp + r * BN + (((2 * chunk + 1) ^ (r & 7)) << 2));
             const unsigned idx = (unsigned)m * (unsigned)N + (unsigned)n;
             float e1[8], e2[8];
             if constexpr (PRE) {
@@ -346,7 +362,7 @@ __device__ __forceinline__ void pa_conv_epilogue_lds(const PaConvArgs& a, f32x4 
 // (2) a thread owns the same 8 channels for all its pixels, so the constants live in registers; (3) the second reduction
 // is accumulated as sum(dz * x) and turned into sum(dz * xhat) = invstd * (sum(dz*x) - mean * sum(dz)) once per
 // workgroup row, which removes mean / invstd from the per-element work.
-template <int BN, int NI, int MI, bool TAB, int NT = 256, bool TSMALL = false, class PixFn>
+template <int BN, int NI, int MI, bool TAB, int NT = 256, bool TSMALL = false, bool FUSE = false, class PixFn>
 __device__ __forceinline__ void pa_conv_epilogue_lds_bwd(const PaConvArgs& a, f32x4 (&acc)[NI][MI], int n0, int wm, int wn,
                                                          PixFn pix, float* T, int stat_row, float4* ctab = nullptr) {
     // ctab (optional, 2 * BN float4 of LDS outside T): the per-channel constants live there instead of in 40 registers
@@ -355,7 +371,9 @@ __device__ __forceinline__ void pa_conv_epilogue_lds_bwd(const PaConvArgs& a, f3
     constexpr int RPS = NT / CPR;
     constexpr int SW = (NT / 8) / RPS;
     constexpr int NW = NT / 64;
-    constexpr int G = (MI >= 2 && !TAB) ? 2 : 1;    // passes per operand request (1 for the 168-register kernels)
+    constexpr int G = FUSE ? MI : ((MI >= 2 && !TAB) ? 2 : 1);    // passes per operand request (1 for the 168-register kernels)
+    constexpr int ROWS = NT / 8;
+    static_assert(!FUSE || !TAB, "fused staging: constants in registers");
     constexpr int IT = G * SW;
     const int tid = threadIdx.x, lane = tid & 63;
     const int N = a.Cout;
@@ -401,20 +419,31 @@ __device__ __forceinline__ void pa_conv_epilogue_lds_bwd(const PaConvArgs& a, f3
                 }
             }
         }
+        if constexpr (FUSE) {
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+                    *reinterpret_cast<f32x4*>(T + (mi * ROWS + wrow) * BN + (((wslot0 + 8 * (ni >> 1) + (ni & 1)) ^ (wrow & 7)) << 2)) = acc[ni][mi];
+            pa_lds_barrier();
+        }
 #pragma unroll
         for (int pp = 0; pp < G; ++pp) {
             const int mi = g + pp;
-            if (mi) pa_lds_barrier();                // the previous pass has been read
+            if constexpr (!FUSE) {
+                if (mi) pa_lds_barrier();            // the previous pass has been read
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni)
-                *reinterpret_cast<f32x4*>(T + wrow * BN + (((wslot0 + 8 * (ni >> 1) + (ni & 1)) ^ (wrow & 7)) << 2)) = acc[ni][mi];
-            pa_lds_barrier();
+                for (int ni = 0; ni < NI; ++ni)
+                    *reinterpret_cast<f32x4*>(T + wrow * BN + (((wslot0 + 8 * (ni >> 1) + (ni & 1)) ^ (wrow & 7)) << 2)) = acc[ni][mi];
+                pa_lds_barrier();
+            }
+            const float* Tp = T + (FUSE ? mi * ROWS * BN : 0);
 #pragma unroll
             for (int sw = 0; sw < SW; ++sw) {
                 const int it = pp * SW + sw, r = sw * RPS + rsub;
                 if (!ok[it]) continue;
-                const f32x4 v0 = *reinterpret_cast<const f32x4*>(T + r * BN + (((2 * chunk) ^ (r & 7)) << 2));
-                const f32x4 v1 = *reinterpret_cast<const f32x4*>(T + r * BN + (((2 * chunk + 1) ^ (r & 7)) << 2));
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(Tp + r * BN + (((2 * chunk) ^ (r & 7)) << 2));
+                const f32x4 v1 = *reinterpret_cast<const f32x4*>(Tp + r * BN + (((2 * chunk + 1) ^ (r & 7)) << 2));
                 bf16x8 o;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
@@ -460,12 +489,13 @@ __host__ __device__ inline bool pa_bwd_epilogue_lds_ok(const PaConvArgs& a) {
 template <int BN, int NI, int MI, bool BWD_LDS = true, bool TAB = false, int NT = 256, bool TSMALL = false, class PixFn>
 __device__ __forceinline__ void pa_conv_epilogue_auto(const PaConvArgs& a, f32x4 (&acc)[NI][MI], int n0, int wm, int wn,
                                                       PixFn pix, float* T, int stat_row, float4* ctab = nullptr) {
+    constexpr bool FUSE = !TSMALL && !TAB && MI > 1 && MI * BN <= 128;
     if (a.ep.mode == PA_OUT_BWD) {
         // supported operand modes of the LDS variant: addend 1 plain / LIN2, addend 2 plain, no bias (every data gradient of
         // the networks); anything else takes the direct epilogue
         const bool lds_ok = BWD_LDS && pa_bwd_epilogue_lds_ok(a);
         if (lds_ok) {
-            pa_conv_epilogue_lds_bwd<BN, NI, MI, TAB, NT, TSMALL>(a, acc, n0, wm, wn, pix, T, stat_row, ctab);
+            pa_conv_epilogue_lds_bwd<BN, NI, MI, TAB, NT, TSMALL, FUSE>(a, acc, n0, wm, wn, pix, T, stat_row, ctab);
         } else if constexpr (TAB || NT != 256) {
             __builtin_trap();       // the 168-register / 512-thread kernels carry no direct epilogue: pa_bwd_epilogue_lds_ok() routes such launches elsewhere
         } else {
@@ -473,6 +503,6 @@ __device__ __forceinline__ void pa_conv_epilogue_auto(const PaConvArgs& a, f32x4
             pa_conv_epilogue<BN, NI, MI>(a, acc, n0, wm, wn, [&](int mi) { return pix(wm, mi, p); }, T, stat_row);
         }
     } else {
-        pa_conv_epilogue_lds<BN, NI, MI, NT, TSMALL>(a, acc, n0, wm, wn, pix, T, stat_row);
+        pa_conv_epilogue_lds<BN, NI, MI, NT, TSMALL, FUSE>(a, acc, n0, wm, wn, pix, T, stat_row);
     }
 }
