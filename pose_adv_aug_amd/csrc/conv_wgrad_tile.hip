@@ -152,6 +152,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile_kernel(PaWgradArgs a, int n
 #pragma unroll
                 for (int j = 0; j < 8; ++j) { qk0[j] = a.x.k0[c0 + cchunk * 8 + j]; qk1[j] = a.x.k1[c0 + cchunk * 8 + j]; }
             }
+            // stem: (image, output row, output column) of the thread's pixel of pass u, walked from pass to pass (the pixel advances by 256 / CPC
+            // per pass) -- two integer divisions per pixel and pass were most of this kernel's instructions (32 per thread and tile)
+            int sb = 0, sy = 0, sx = 0;
+            if (QMODE == PA_WG_STEM) {
+                const int m0 = tile * 128 + tid / CPC, HWo = a.H * a.W;
+                sb = m0 / HWo; const int rem = m0 - sb * HWo; sy = rem / a.W; sx = rem - sy * a.W;
+            }
 #pragma unroll
             for (int u = 0; u < PASS_C; ++u) {
                 const int hp = u * (256 / CPC) + tid / CPC;
@@ -166,9 +173,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile_kernel(PaWgradArgs a, int n
                     // 7x7 stride-2 stem: the 'channels' are the 256 patch elements ky*32 + kx*4 + c of the 4-channel image; one
                     // 16-byte chunk = input pixels (2x + 2q - 3, +1) of input row 2y + ky - 3; a.H / a.W are the OUTPUT dims
                     const int chunk = c0 / 8 + cchunk, ky = chunk >> 2, q = chunk & 3;
-                    const int HWo = a.H * a.W, Hin = 2 * a.H, Win = 2 * a.W;
-                    const int mm = ok[u] ? m : 0;
-                    const int bb = mm / HWo, rem = mm - bb * HWo, y = rem / a.W, x = rem - y * a.W;
+                    const int Hin = 2 * a.H, Win = 2 * a.W;
+                    const int bb = ok[u] ? sb : 0, y = ok[u] ? sy : 0, x = ok[u] ? sx : 0;
+                    sx += 256 / CPC;                 // the next pass's pixel
+                    while (sx >= a.W) { sx -= a.W; if (++sy >= a.H) { sy = 0; ++sb; } }
                     const int yi = 2 * y + ky - 3, xi = 2 * x + 2 * q - 3;
                     const bool rowok = ok[u] && ky < 7 && (unsigned)yi < (unsigned)Hin;
                     const bool lok = rowok && (unsigned)xi < (unsigned)Win, hok = rowok && (unsigned)(xi + 1) < (unsigned)Win;

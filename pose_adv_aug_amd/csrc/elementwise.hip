@@ -95,18 +95,24 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* stats, i
                                                            int update_running) {
     __shared__ float sums[FC][2];
     const int c0 = blockIdx.x * FC;
+    // the channel's parameters are requested BEFORE the reduction (after it they were one more dependent memory round trip of a kernel that
+    // is nothing but round trips)
+    const bool mine = threadIdx.x < FC && c0 + (int)threadIdx.x < C;
+    float g = 0.f, bt = 0.f, rm = 0.f, rv = 0.f;
+    if (mine) {
+        g = gamma[c0 + threadIdx.x]; bt = beta[c0 + threadIdx.x];
+        if (update_running) { rm = rmean[c0 + threadIdx.x]; rv = rvar[c0 + threadIdx.x]; }
+    }
     reduce_partial_rows(stats, rows, C, c0, sums);
-    if (threadIdx.x >= FC) return;
+    if (!mine) return;
     const int c = c0 + threadIdx.x;
-    if (c >= C) return;
     float s, sh, mu, is, var;
-    pa_bn_fwd_consts(sums[threadIdx.x][0], sums[threadIdx.x][1], count, eps, gamma[c], beta[c], s, sh, mu, is, var);
+    pa_bn_fwd_consts(sums[threadIdx.x][0], sums[threadIdx.x][1], count, eps, g, bt, s, sh, mu, is, var);
     scale[c] = s;
     shift[c] = sh;
     mean[c] = mu;
     invstd[c] = is;
     if (update_running) {
-        float rm = rmean[c], rv = rvar[c];
         pa_bn_running(mu, var, count, momentum, rm, rv);
         rmean[c] = rm; rvar[c] = rv;
     }
@@ -141,13 +147,15 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* bsta
                                                                float* dgamma, float* dbeta, int C, float count) {
     __shared__ float sums[FC][2];
     const int c0 = blockIdx.x * FC;
+    const bool mine = threadIdx.x < FC && c0 + (int)threadIdx.x < C;
+    float sc = 0.f, is = 0.f, mu = 0.f;              // (requested before the reduction, see bn_finalize_kernel)
+    if (mine) { sc = scale[c0 + threadIdx.x]; is = invstd[c0 + threadIdx.x]; mu = mean[c0 + threadIdx.x]; }
     reduce_partial_rows(bstats, rows, C, c0, sums);
-    if (threadIdx.x >= FC) return;
+    if (!mine) return;
     const int c = c0 + threadIdx.x;
-    if (c >= C) return;
     float S1 = sums[threadIdx.x][0], S2 = sums[threadIdx.x][1];
     float ka, kb, kc;
-    pa_bn_bwd_consts(S1, S2, count, scale[c], invstd[c], mean[c], ka, kb, kc);
+    pa_bn_bwd_consts(S1, S2, count, sc, is, mu, ka, kb, kc);
     kA[c] = ka; kB[c] = kb; kC[c] = kc;
     if (dgamma) dgamma[c] = S2;
     if (dbeta) dbeta[c] = S1;
@@ -160,13 +168,15 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize2_kernel(BwdFinArgs a0, B
     __shared__ float sums[FC][2];
     const int c0 = blockIdx.x * FC;
     if (c0 >= a.C) return;
+    const bool mine = threadIdx.x < FC && c0 + (int)threadIdx.x < a.C;
+    float sc = 0.f, is = 0.f, mu = 0.f;
+    if (mine) { sc = a.scale[c0 + threadIdx.x]; is = a.invstd[c0 + threadIdx.x]; mu = a.mean[c0 + threadIdx.x]; }
     reduce_partial_rows(a.bstats, a.rows, a.C, c0, sums);
-    if (threadIdx.x >= FC) return;
+    if (!mine) return;
     const int c = c0 + threadIdx.x;
-    if (c >= a.C) return;
     float S1 = sums[threadIdx.x][0], S2 = sums[threadIdx.x][1];
     float ka, kb, kc;
-    pa_bn_bwd_consts(S1, S2, a.count, a.scale[c], a.invstd[c], a.mean[c], ka, kb, kc);
+    pa_bn_bwd_consts(S1, S2, a.count, sc, is, mu, ka, kb, kc);
     a.kA[c] = ka; a.kB[c] = kb; a.kC[c] = kc;
     if (a.dgamma) a.dgamma[c] = S2;
     if (a.dbeta) a.dbeta[c] = S1;
