@@ -273,6 +273,15 @@ int pa_hg_accuracy(pa_net* net, int stack, const int32_t* idxs, int nidx, float*
 int pa_hg_pckh(pa_net* net, int stack, const float* center, const float* scale, const float* rot, const float* gt_pts,
                const float* norm, const int32_t* idxs, int nidx, float* acc, float* person, float* scratch);
 
+/* The meters of a TRAINING step beside its backward pass.  stack-hg.py:171-180 computes the accuracies of a batch from the forward pass's
+ * heat maps after the optimizer step; they only read those maps, so a caller may ask for them between pa_hg_forward and pa_hg_backward:
+ * with on != 0 the pa_hg_accuracy / pa_hg_pckh calls that follow are launched on a stream of the engine's own, behind everything the net's
+ * stream holds at the call, and run beside the launches that stream is given next.  The net's stream waits for them at the end of the
+ * next pa_hg_backward (the last pa_hg_backward_phase) or in front of the next forward pass; until then `acc`, `person`, `scratch` and the
+ * meters' inputs must stay allocated and must not be read.  on == 0 (default): the meters run on the net's stream, ordered like every
+ * other call.  Same values either way. */
+int pa_net_meters_async(pa_net* net, int on);
+
 /* Tuning aid for the fused low-resolution launch (csrc/lowres_fused.hip; it has no reference counterpart): `counters` = 24 int64 in
  * device memory (zeroed by the caller) that workgroup 0 adds the shader-clock cycles of its phases to -- [level 16/8/4][phase:
  * constants, staging, MFMA + epilogue, publish, barrier wait, collect + finalize, pool / upsample-add, drain]; NULL switches it off. */

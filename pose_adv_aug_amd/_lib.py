@@ -123,6 +123,7 @@ _PROTOS = {
     'pa_asn_backward': (_i, [_vp, _vp, _vp, _vp, _vp]),
     'pa_asn_set_log_eps': (_i, [_vp, _f]),
     'pa_hg_pckh': (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
+    'pa_net_meters_async': (_i, [_vp, _i]),
     'pa_net_profile_begin': (_i, [_vp]),
     'pa_net_profile_report': (_i, [_vp, C.POINTER(C.c_double), _i, C.POINTER(_i)]),
     'pa_net_design_bytes': (_i, [_vp, C.POINTER(C.c_double)]),

@@ -528,13 +528,21 @@ int pa_hg_accuracy(pa_net* net, int stack, const int32_t* idxs, int nidx, float*
     float* gp = tgt + (size_t)B * J * H * H + (size_t)B * J * 2;      // [B][16][2]
     float* norm = gp + (size_t)B * J * 2;         // [B]
     const float* pp = nullptr;                    // [B][16][2] arg-max of the heat maps (shared with pa_hg_pckh)
-    TRY(n.heat_argmax(stack, &pp));
-    TRY(pa_launch_gaussian_heatmap(n.pts_dev, tgt, B, J, H, H, n.st));
-    TRY(pa_launch_argmax(tgt, (long)J * H * H, (long)H * H, 1, B, J, H, H, gp, nullptr, n.st));
-    TRY(pa_launch_fill(norm, (float)H / 10.f, B, n.st));
-    TRY(pa_launch_pck(pp, gp, norm, 1.f, idxs, nidx, 0.5f, nullptr, B, J, acc, nullptr, nullptr, n.st));
-    return 0;
+    hipStream_t ms;
+    TRY(n.meter_stream(&ms));
+    TRY(n.heat_argmax(stack, &pp, ms));
+    TRY(pa_launch_gaussian_heatmap(n.pts_dev, tgt, B, J, H, H, ms));
+    TRY(pa_launch_argmax(tgt, (long)J * H * H, (long)H * H, 1, B, J, H, H, gp, nullptr, ms));
+    TRY(pa_launch_fill(norm, (float)H / 10.f, B, ms));
+    TRY(pa_launch_pck(pp, gp, norm, 1.f, idxs, nidx, 0.5f, nullptr, B, J, acc, nullptr, nullptr, ms));
+    return n.meter_done(ms);
 }
+
+// pa_net_meters_async (include/poseadv.h): on != 0 -- pa_hg_accuracy / pa_hg_pckh calls are launched on the engine's meter stream, behind
+// everything the main stream holds at the call and beside whatever it is given next; the main stream joins them at the end of the next
+// pa_hg_backward / the last pa_hg_backward_phase (or in front of the next forward pass).  Until then their outputs and scratch buffers
+// must stay allocated and unread.
+int pa_net_meters_async(pa_net* net, int on) { g_err[0] = 0; net->n.meters_async = on != 0; return 0; }
 
 
 // Evaluation.accuracy_origin_res (pylib/Evaluation.py:77-97) and per_person_pckh (:99-167) of stack i's
@@ -545,17 +553,19 @@ int pa_hg_pckh(pa_net* net, int stack, const float* center, const float* scale, 
     Net& n = net->n;
     const int H = n.res / 4, J = 16, B = n.B;
     const float* pp = nullptr;                    // [B][16][2] arg-max (computed once per forward, shared with pa_hg_accuracy)
-    TRY(n.heat_argmax(stack, &pp));
+    hipStream_t ms;
+    TRY(n.meter_stream(&ms));
+    TRY(n.heat_argmax(stack, &pp, ms));
     float* fp = scratch + (size_t)B * J * 2;      // [B][16][2] back-projected predictions
     float* vis = fp + (size_t)B * J * 2;          // [B][16][2] arg-max of the augmented target
     float* tgt = vis + (size_t)B * J * 2;         // [B][16][H][H] (only when person != NULL)
-    TRY(pa_launch_final_preds(n.heat[stack], (long)H * H * 16, 1, 16, pp, center, scale, rot, B, J, H, H, fp, n.st));
+    TRY(pa_launch_final_preds(n.heat[stack], (long)H * H * 16, 1, 16, pp, center, scale, rot, B, J, H, H, fp, ms));
     if (person) {
-        TRY(pa_launch_gaussian_heatmap(n.pts_dev, tgt, B, J, H, H, n.st));
-        TRY(pa_launch_argmax(tgt, (long)J * H * H, (long)H * H, 1, B, J, H, H, vis, nullptr, n.st));
+        TRY(pa_launch_gaussian_heatmap(n.pts_dev, tgt, B, J, H, H, ms));
+        TRY(pa_launch_argmax(tgt, (long)J * H * H, (long)H * H, 1, B, J, H, H, vis, nullptr, ms));
     }
-    TRY(pa_launch_pck(fp, gt_pts, norm, 0.f, idxs, nidx, 0.5f, person ? vis : nullptr, B, J, acc, person, nullptr, n.st));
-    return 0;
+    TRY(pa_launch_pck(fp, gt_pts, norm, 0.f, idxs, nidx, 0.5f, person ? vis : nullptr, B, J, acc, person, nullptr, ms));
+    return n.meter_done(ms);
 }
 
 // per-launch HIP-event timing of the MFMA kernels (bench.py roofline): enable, run steps, then report.

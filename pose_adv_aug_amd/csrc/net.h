@@ -220,7 +220,15 @@ struct Net {
     double* pts_dev = nullptr;                     // [B][16][2] heat-map coords (caller provided per step)
     std::vector<float*> heat_peak;                 // [B][16][2] arg-max of heat[i], computed once per forward on demand (accuracy AND PCKh use it)
     std::vector<char> heat_peak_valid;
-    int heat_argmax(int stack, const float** out); // launches the arg-max unless this forward's result exists
+    int heat_argmax(int stack, const float** out, hipStream_t on = nullptr); // launches the arg-max unless this forward's result exists
+    // The meters of a training step (pa_hg_accuracy / pa_hg_pckh: ~8 short launches that only READ the forward pass's heat maps) on a stream of
+    // their own beside the backward pass (pa_net_meters_async): forked behind the last launch of the main stream, joined by the main stream
+    // at the end of the backward pass (or in front of the next forward pass), so every later reader on the main stream is ordered behind them.
+    hipStream_t mstream = nullptr; hipEvent_t ev_mfork = nullptr, ev_meter = nullptr;
+    bool meters_async = false, meter_pending = false;
+    int meter_stream(hipStream_t* out);         // the stream the meters are launched on now (forks mstream from st when meters_async)
+    int meter_done(hipStream_t ms);             // records the join event when ms is the meter stream
+    int join_meters();                          // the main stream waits for the pending meters
     // occlusion (dropout) branch, reference :172-190: [B][16] cell masks (caller-owned device memory) applied to the neck and the
     // four skip tensors of every stack in forward_pose / backward_pose; nullptr = off
     const float* drop_mask = nullptr;

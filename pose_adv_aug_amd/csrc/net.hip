@@ -865,6 +865,7 @@ int Net::ensure_streams() {
 void Net::release_streams() {
     release_graph();
     if (bucket_events) { for (int i = 0; i < 16; ++i) (void)hipEventDestroy(ev_bucket[i]); (void)hipEventDestroy(ev_bucket_main); bucket_events = false; }
+    if (mstream) { (void)hipStreamSynchronize(mstream); (void)hipStreamDestroy(mstream); (void)hipEventDestroy(ev_mfork); (void)hipEventDestroy(ev_meter); mstream = nullptr; meter_pending = false; }
     for (int k = 0; k < 4; ++k) {
         if (side[k]) {
             if (k < n_side) { (void)hipStreamSynchronize(side[k]); (void)hipStreamDestroy(side[k]); }
@@ -896,10 +897,36 @@ int Net::begin_step() {
 }
 
 // reference :282-342 (stem :283-289, stacks :292-334) + loss of stack-hg.py:156-159
-int Net::heat_argmax(int stack, const float** out) {
+int Net::meter_stream(hipStream_t* out) {
+    *out = st;
+    if (!meters_async || !multi_stream) return 0;
+    if (!mstream) {
+        PA_CHECK(hipStreamCreateWithFlags(&mstream, hipStreamNonBlocking));
+        PA_CHECK(hipEventCreateWithFlags(&ev_mfork, hipEventDisableTiming));
+        PA_CHECK(hipEventCreateWithFlags(&ev_meter, hipEventDisableTiming));
+    }
+    PA_CHECK(hipEventRecord(ev_mfork, st));
+    PA_CHECK(hipStreamWaitEvent(mstream, ev_mfork, 0));
+    *out = mstream;
+    return 0;
+}
+int Net::meter_done(hipStream_t ms) {
+    if (ms == st) return 0;
+    PA_CHECK(hipEventRecord(ev_meter, ms));
+    meter_pending = true;
+    return 0;
+}
+int Net::join_meters() {
+    if (!meter_pending) return 0;
+    PA_CHECK(hipStreamWaitEvent(st, ev_meter, 0));
+    meter_pending = false;
+    return 0;
+}
+
+int Net::heat_argmax(int stack, const float** out, hipStream_t on) {
     const int H = res / 4;
     if (!heat_peak_valid[stack]) {
-        TRY(pa_launch_argmax(heat[stack], (long)H * H * 16, 1, 16, B, 16, H, H, heat_peak[stack], nullptr, st));
+        TRY(pa_launch_argmax(heat[stack], (long)H * H * 16, 1, 16, B, 16, H, H, heat_peak[stack], nullptr, on ? on : st));
         heat_peak_valid[stack] = 1;
     }
     *out = heat_peak[stack];
@@ -910,6 +937,7 @@ int Net::forward_pose(const float* img_nchw, const bf16* img4_in, const double* 
     train_bn = train;
     heat_peak_valid.assign(stacks, 0);
     TRY(ensure_streams());
+    TRY(join_meters());                 // (meters of the previous forward pass still read the heat maps this one overwrites)
     TRY(begin_step());
     if (!train) TRY(pa_launch_bn_eval(bneval_jobs, n_bneval, eps, st));
     const bf16* image = img4_in ? img4_in : img4;
@@ -982,7 +1010,8 @@ int Net::backward_stem() {
     TRY(res1.bwd(*this, a0, pa_none(), true));
     TRY(finish_grad(a0));
     TRY(conv_wgrad(stem_conv, gradop(a0), pa_plain(cur_image), B, res / 2, res / 2));
-    return reduce_grads();
+    TRY(reduce_grads());
+    return join_meters();               // the step's meters ran beside this pass: later readers on the main stream come behind them
 }
 
 int Net::backward_pose() {

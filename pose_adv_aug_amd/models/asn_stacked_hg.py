@@ -286,11 +286,15 @@ class HourglassNet(_HipModule):
             check(lib().pa_net_set_fused_lowres(h, 1 if on else 0), 'pa_net_set_fused_lowres')
     on_stack_done = None     # callback(stack index) after the backward pass of a stack is enqueued (utils.optim.RMSprop(overlap=True))
 
-    def loss_and_backward(self, x=None, pts=None, img4=None, want_outputs=False, dropout_masks=None):
+    def loss_and_backward(self, x=None, pts=None, img4=None, want_outputs=False, dropout_masks=None, after_forward=None):
         """One pass of stack-hg.py:153-164 without the optimizer: forward in the current mode, loss
         sum_stacks mean((out - gaussian(pts))^2) with the target generated on the fly from `pts`
         ([B][16][2] heat-map coordinates), backward into flat_grads.  Returns (loss 0-d GPU tensor, outputs).
-        dropout_masks ([B][1][4][4]): the occlusion masks of the reference's dropout branch, in every stack."""
+        dropout_masks ([B][1][4][4]): the occlusion masks of the reference's dropout branch, in every stack.
+        after_forward: a callable run between the two passes; its accuracy() / pckh_origin_res() calls (stack-hg.py:176-178 read
+        nothing but the forward pass's heat maps) go to the engine's meter stream and run BESIDE the backward pass instead of between
+        two steps (pa_net_meters_async); their results are ordered behind this call like everything else.  The value it returns is
+        kept in self.after_forward_result.  (Not with use_graph: there the two passes are one launch.)"""
         B = x.shape[0] if x is not None else img4.shape[0]
         h = self._net(B)
         self._last_B = B
@@ -307,6 +311,13 @@ class HourglassNet(_HipModule):
                                       1 if self.training else 0, ptr(losses)), 'pa_hg_forward')
             if self.training:
                 self._nbt += 1
+            if after_forward is not None:
+                self._meter_keep = []                           # buffers the meter stream uses: alive until the backward pass has joined it
+                check(lib().pa_net_meters_async(h, 1), 'pa_net_meters_async')
+                try:
+                    self.after_forward_result = after_forward()
+                finally:
+                    check(lib().pa_net_meters_async(h, 0), 'pa_net_meters_async')
             if self.on_stack_done is not None:                  # the backward pass in phases: a finished stack's gradients can travel
                 for phase in range(self.num_stacks + 1):
                     check(lib().pa_hg_backward_phase(h, phase), 'pa_hg_backward_phase')
@@ -314,6 +325,7 @@ class HourglassNet(_HipModule):
                         self.on_stack_done(self.num_stacks - 1 - phase)
             else:
                 check(lib().pa_hg_backward(h), 'pa_hg_backward')
+            self._meter_keep = None                             # (the backward pass has enqueued the join: later users of these blocks are ordered behind the meters)
             outs = self.heatmaps(B) if want_outputs else None
         finally:
             if keep is not None:
@@ -337,6 +349,8 @@ class HourglassNet(_HipModule):
             ix = cache[key] = torch.as_tensor(key, dtype=torch.int32, device=dev)
         acc = torch.empty(len(idxs) + 1, dtype=torch.float32, device=dev)          # pck_kernel writes every entry
         check(lib().pa_hg_accuracy(h, stack, ptr(ix), len(idxs), ptr(acc), ptr(scratch)), 'pa_hg_accuracy')
+        if getattr(self, '_meter_keep', None) is not None:
+            self._meter_keep += [scratch, acc, ix]
         return acc
 
 
@@ -358,6 +372,8 @@ class HourglassNet(_HipModule):
         g = grnd_pts.float().contiguous(); nm = normalizers.float().contiguous()
         check(lib().pa_hg_pckh(h, stack, ptr(c), ptr(s), ptr(r), ptr(g), ptr(nm), ptr(self._pckh_idx), len(PCKH_JOINTS),
                                ptr(acc), ptr(person), ptr(scratch)), 'pa_hg_pckh')
+        if getattr(self, '_meter_keep', None) is not None:
+            self._meter_keep += [scratch, acc, person, c, s, r, g, nm]
         return acc, person
 
 

@@ -59,12 +59,22 @@ def train_step(net, optimizer, augmenter, batch, want_pckh=True, data=None):
     data: the batch's augmented input if it was prepared ahead (data.AugmentAhead), else it is made here."""
     if data is None:
         data = augmenter.regular(batch)
+    def meters():
+        pckh = net.accuracy(PCK_IDX)                                                    # stack-hg.py:176
+        pckh_o, _ = net.pckh_origin_res(data['c'], data['s'], data['r'], data['grnd_pts'], data['normalizer'])   # :178
+        return pckh, pckh_o
+    if want_pckh and not getattr(net, 'use_graph', False):
+        # the meters read the forward pass's heat maps only: launched between the two passes they run beside the backward pass on the
+        # engine's meter stream (100 us of short launches that otherwise sit between two steps); same values
+        loss, _ = net.loss_and_backward(img4=data['img4'], pts=data['pts'], after_forward=meters)
+        optimizer.step()
+        pckh, pckh_o = net.after_forward_result
+        return loss, pckh[0], pckh_o[0]
     loss, _ = net.loss_and_backward(img4=data['img4'], pts=data['pts'])
     optimizer.step()
     if not want_pckh:
         return loss, None, None
-    pckh = net.accuracy(PCK_IDX)                                                        # stack-hg.py:176
-    pckh_o, _ = net.pckh_origin_res(data['c'], data['s'], data['r'], data['grnd_pts'], data['normalizer'])   # :178
+    pckh, pckh_o = meters()
     return loss, pckh[0], pckh_o[0]
 
 

@@ -446,6 +446,44 @@ def test_finalize_in_the_consumer_prologue_gives_the_same_bits(stacks, chan, B):
     assert abs(finals[0][3] - finals[1][3]) < 1e-6 * abs(finals[0][3])        # (the reported loss is summed with one float atomic per workgroup)
 
 
+@pytest.mark.parametrize('stacks,chan,B', [(1, 128, 4), (2, 256, 24)])
+def test_meters_beside_the_backward_pass_give_the_same_values(stacks, chan, B):
+    """stack-hg.py:171-180's accuracies launched between the forward and the backward pass on the engine's meter stream
+    (pa_net_meters_async, stack_hg.train_step) against the reference's order (after the optimizer step, on the net's stream): the same
+    loss / accuracy values at every step and bitwise the same parameters, statistics and gradients over 4 steps -- the meters only read
+    the forward pass's heat maps, and the net's stream joins them at the end of the backward pass."""
+    from pose_adv_aug_amd.models.asn_stacked_hg import create_hg
+    from pose_adv_aug_amd.utils.optim import RMSprop
+    from pose_adv_aug_amd.data import Augmenter, DeviceBatch
+    from pose_adv_aug_amd.stack_hg import train_step, PCK_IDX
+    batches = [DeviceBatch.synthetic(B, seed=70 + k) for k in range(2)]
+    finals, meters = [], []
+    for beside in (True, False):
+        net = create_hg(stacks, 1, 16, chan, default_batch=B); net.reset_parameters(seed=6); net.train()
+        opt = RMSprop(net, lr=2.5e-4)
+        aug = Augmenter(seed=13)
+        vals = []
+        for i in range(4):
+            if beside:
+                loss, pckh, pckh_o = train_step(net, opt, aug, batches[i % 2])
+            else:                       # the reference's order, every call on the net's stream
+                data = aug.regular(batches[i % 2])
+                loss, _ = net.loss_and_backward(img4=data['img4'], pts=data['pts'])
+                opt.step()
+                pckh = net.accuracy(PCK_IDX)[0]
+                pckh_o = net.pckh_origin_res(data['c'], data['s'], data['r'], data['grnd_pts'], data['normalizer'])[0][0]
+            junk = torch.empty(1 << 22, device='cuda').normal_()       # allocator traffic between the steps: a freed meter buffer would be reused here
+            vals.append((loss, pckh, pckh_o)); del junk
+        torch.cuda.synchronize()
+        meters.append([(float(a), float(b), float(c)) for a, b, c in vals])
+        finals.append((net.flat_params.clone(), net.flat_buffers.clone(), net.flat_grads.clone()))
+        del net, opt
+    for (l0, a0, o0), (l1, a1, o1) in zip(meters[0], meters[1]):
+        assert abs(l0 - l1) < 1e-6 * abs(l1) and a0 == a1 and o0 == o1, (meters[0], meters[1])      # (the reported loss is summed with one float atomic per workgroup)
+    assert 0.0 <= meters[0][-1][1] <= 1.0 and 0.0 <= meters[0][-1][2] <= 1.0
+    assert torch.equal(finals[0][0], finals[1][0]) and torch.equal(finals[0][1], finals[1][1]) and torch.equal(finals[0][2], finals[1][2])
+
+
 def _blob_dataset(n, res, seed):
     """learnable synthetic people: every joint is a colour-coded Gaussian blob in the image at its location"""
     g = inputs.rng(seed, 7)
