@@ -32,7 +32,7 @@ import torch.distributed as dist  # noqa: E402
 # classes 0-5: maps of >= 16384 pixels (32 x 32 and larger at batch 24); the last three: every convolution launch of the smaller maps
 # (16 x 16 ... 4 x 4: latency-bound launches)
 PROF_NAMES = ['conv_fwd_1x1', 'conv_fwd_3x3', 'conv_dgrad_1x1', 'conv_dgrad_3x3', 'conv_wgrad_1x1', 'conv_wgrad_3x3',
-              'stem_fwd_7x7', 'stem_wgrad_7x7', 'lowres_fused_fwd', 'conv_fwd_lowres', 'conv_dgrad_lowres', 'conv_wgrad_lowres']
+              'stem_fwd_7x7', 'stem_wgrad_7x7', 'unused', 'conv_fwd_lowres', 'conv_dgrad_lowres', 'conv_wgrad_lowres']
 HBM_PEAK = 8.0e12          # B/s   (MI355X_MICROARCH.md)
 MFMA_PEAK = 2.5e15         # FLOP/s dense bf16
 
@@ -238,7 +238,6 @@ def main():
                     'by default they run at N = 1 when rocprofv3 is on PATH, and the recorded profiles/ numbers are quoted otherwise')
     ap.add_argument('--no-floor', action='store_true', help='skip the design-bytes / cold-rate floor of the roofline object')
     ap.add_argument('--keep-profiles', action='store_true', help='keep the child passes\' rocprofv3 output under gpurun_out/')
-    ap.add_argument('--fused-lowres', type=int, default=0, help='1: the sub-hourglass below 32 x 32 as one persistent launch per stack (experiment, DESIGN.md)')
     args = ap.parse_args()
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -262,7 +261,6 @@ def main():
     net = create_hg(args.stacks, 1, 16, args.chan, res=res, default_batch=B)
     net.reset_parameters(seed=0)
     net.use_graph = bool(args.graph)
-    net.fused_lowres = bool(args.fused_lowres)
     broadcast_parameters(net)
     opt = RMSprop(net, lr=2.5e-4, alpha=0.99, eps=1e-8, overlap=bool(args.overlap) and (world > 1 or os.environ.get('POSEADV_FORCE_DIST') == '1'))
     aug = Augmenter(seed=100 + rank, inp_res=res, out_res=res // 4)
@@ -355,8 +353,7 @@ def main():
         # otherwise the numbers committed under profiles/ are quoted, tagged as recorded.
         traffic, trace = None, None
         is_c2 = (args.stacks, args.chan, res, B, args.dtype) == (2, 256, 256, 24, 'bf16')
-        wl = ['--bs', str(B), '--stacks', str(args.stacks), '--chan', str(args.chan), '--res', str(res), '--dtype', args.dtype,
-              '--fused-lowres', str(args.fused_lowres)]
+        wl = ['--bs', str(B), '--stacks', str(args.stacks), '--chan', str(args.chan), '--res', str(res), '--dtype', args.dtype]
         measured_pmc = measured_tr = None
         if rank == 0 and world == 1 and not args.no_traffic:
             sys.path.insert(0, os.path.join(ROOT, 'tools'))

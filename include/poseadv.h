@@ -282,19 +282,11 @@ int pa_hg_pckh(pa_net* net, int stack, const float* center, const float* scale, 
  * other call.  Same values either way. */
 int pa_net_meters_async(pa_net* net, int on);
 
-/* Tuning aid for the fused low-resolution launch (csrc/lowres_fused.hip; it has no reference counterpart): `counters` = 24 int64 in
- * device memory (zeroed by the caller) that workgroup 0 adds the shader-clock cycles of its phases to -- [level 16/8/4][phase:
- * constants, staging, MFMA + epilogue, publish, barrier wait, collect + finalize, pool / upsample-add, drain]; NULL switches it off. */
-int pa_net_lowres_timing(pa_net* net, long long* counters);
-/* 1: the sub-hourglass below 32 x 32 of every stack (models/asn_stacked_hg.py:139-157, :192-203 at 16 x 16, 8 x 8, 4 x 4) runs as ONE
- * persistent launch in the training-mode forward pass of the pose net (one workgroup per image, BatchNorm statistics exchanged at
- * in-kernel barriers); 0 (default): the chain of per-layer launches.  Same results up to summation order. */
-int pa_net_set_fused_lowres(pa_net* net, int on);
 /* Per-launch HIP-event timing of the MFMA kernels on the net's stream (bench.py's `roofline`).
  * begin: start recording; report: synchronise, stop recording and fill out_host[c][4] = {total ms, launches, algorithmic
  * bytes, flops} for the classes c = 0 fwd 1x1, 1 fwd 3x3, 2 dgrad 1x1, 3 dgrad 3x3, 4 wgrad 1x1, 5 wgrad 3x3 (maps of >= 16384
- * pixels: 32 x 32 and larger at batch 24), 6 stem fwd, 7 stem wgrad, 8 fused low-resolution forward launch
- * (pa_net_set_fused_lowres), 9 / 10 / 11 forward / data-gradient / weight-gradient launches of the smaller maps (latency-bound).
+ * pixels: 32 x 32 and larger at batch 24), 6 stem fwd, 7 stem wgrad, 8 unused (the fused
+ * low-resolution launch of rounds 3-4, removed: DESIGN.md), 9 / 10 / 11 forward / data-gradient / weight-gradient launches of the smaller maps (latency-bound).
  * out_host is a HOST array of `cap_classes` rows; classes beyond the capacity are dropped (never written).  Returns the library's
  * number of classes (PA_PROF_CLASSES = 12 today) through *n_classes when it is not NULL. */
 #define PA_PROF_CLASSES 12

@@ -129,8 +129,6 @@ _PROTOS = {
     'pa_net_design_bytes': (_i, [_vp, C.POINTER(C.c_double)]),
     'pa_net_set_fin_prologue': (_i, [_vp, _i]),
     'pa_conv2d_time': (_i, [_i] * 9 + [_vp, C.POINTER(C.c_float), _vp]),
-    'pa_net_lowres_timing': (_i, [_vp, _vp]),
-    'pa_net_set_fused_lowres': (_i, [_vp, _i]),
     'pa_net_profile_classes': (_i, [_vp, C.POINTER(C.c_int32), _i]),
     'pa_net_set_multi_stream': (_i, [_vp, _i]),
     'pa_hg_debug_tensor': (_i, [_vp, C.c_char_p, _i, _vp, C.POINTER(_i)]),

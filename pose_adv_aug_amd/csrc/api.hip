@@ -569,14 +569,6 @@ int pa_hg_pckh(pa_net* net, int stack, const float* center, const float* scale, 
 }
 
 // per-launch HIP-event timing of the MFMA kernels (bench.py roofline): enable, run steps, then report.
-int pa_net_set_fused_lowres(pa_net* net, int on) {
-    Net& n = net->n;
-    n.fused_low = on != 0;
-    n.release_graph();
-    if (n.params) { TRY(n.upload_tables()); TRY(n.prepare_weights()); }      // the packed weight copies exist only while the switch is on
-    return 0;
-}
-int pa_net_lowres_timing(pa_net* net, long long* counters) { net->n.lr_timing = counters; return 0; }
 int pa_net_profile_begin(pa_net* net) { net->n.prof.used = 0; net->n.prof.on = true; return 0; }
 // out[cap_classes][4] = {total ms, launches, algorithmic bytes, flops} per class (include/poseadv.h).  Reporting synchronises and disables.
 int pa_net_profile_report(pa_net* net, double* out, int cap_classes, int* n_classes) {

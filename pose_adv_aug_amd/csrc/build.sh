@@ -4,7 +4,7 @@
 # (release) build reads no environment.
 set -e
 cd "$(dirname "$0")"
-SRCS="conv_igemm conv3x3_tile conv1x1_tile conv_wgrad conv_wgrad_tile lowres_fused elementwise pose_ops crop_warp net asn api"
+SRCS="conv_igemm conv3x3_tile conv1x1_tile conv_wgrad conv_wgrad_tile elementwise pose_ops crop_warp net asn api"
 build_variant() {      # $1 = object directory, $2 = extra flags, $3 = library name
   local dir=$1 flags=$2 lib=$3
   mkdir -p $dir

@@ -888,10 +888,6 @@ __global__ __launch_bounds__(1024) void weight_prep_kernel(const PaPrepJob* jobs
         for (int tap = 0; tap < j.taps; ++tap) {
             const bf16 v = (bf16)(ok ? src[tap] : 0.f);
             j.wf[((size_t)n * j.taps + tap) * j.pad_cin + c] = v;
-            if (j.wp) {                                                 // lane = (k % 32) / 8 * 16 + n % 16 of fragment (n / 16, k / 32), k = tap * Cin + c
-                const int k = tap * j.pad_cin + c, S = j.taps * j.pad_cin >> 5;
-                j.wp[((((size_t)(n >> 4) * S + (k >> 5)) * 64 + ((k & 31) >> 3) * 16 + (n & 15)) << 3) + (k & 7)] = v;
-            }
             tile[tap][tn][tc] = v;
         }
         __syncthreads();

@@ -93,40 +93,10 @@ int pa_launch_stem_wgrad(const PaWgradArgs& a, hipStream_t st);
 // reduce the stem's partial slabs [splits][64][256] into PyTorch layout dst[64][3][7][7]
 int pa_launch_stem_wgrad_reduce(const float* part, int splits, float* dst, hipStream_t st);
 
-// ---- the low-resolution sub-hourglass as ONE persistent launch (lowres_fused.hip): one workgroup per image runs the program
-enum { LR_CONV = 0, LR_POOL = 1, LR_UPADD = 2 };
-struct LrBn { const float* gamma; const float* beta; float* rmean; float* rvar; float* scale; float* shift; float* mean; float* invstd; };
-struct LrOp {
-    int type;                  // LR_CONV (1x1 / 3x3 'same', + bias, + optional addend), LR_POOL (2x2 max), LR_UPADD (nearest x2 + skip)
-    int H, W;                  // OUTPUT map of one image (16, 8 or 4)
-    int Cin, Cout, taps;       // channels (128 / 256), taps 1 or 9 (pool / upadd: Cout channels)
-    const bf16* in;  const float* in_k0;  const float* in_k1;      // value(in) = in_k0 ? relu(in_k0 * x + in_k1) : x     [B][pixels][C]
-    const bf16* add; const float* add_k0; const float* add_k1;     // conv: shortcut addend (may be null); upadd: the skip operand
-    const bf16* w;             // forward weights packed per MFMA fragment: [Cout / 16][taps * Cin / 32][64][8] bf16 (PaPrepJob::wp)
-    const float* bias;         // [Cout] fp32
-    bf16* out;                 // [B][H * W][Cout]
-    int has_bn;                // training-mode BatchNorm behind the convolution: statistics + finalize inside the launch
-    int src_lds, dst_lds;      // conv: the input is the raw tensor the previous convolution left in LDS buffer src_lds (-1: global memory);
-                               // the raw output also stays in LDS buffer dst_lds (-1: global memory only)
-    LrBn bn;
-};
-struct LrLaunch {
-    float2* rows;              // [2][B][256] 16-byte granules {sum, tag, sum of squares, tag}: partial statistics rows (scratch, 2 MB)
-    unsigned launch_id;        // unique per launch that shares `rows` (tags of an earlier launch must never match)
-    unsigned* counter;         // (unused: the tagged granules are the barrier)
-    float batch;               // B
-    float momentum, eps;
-    int update_running;
-    long long* timing;         // tuning aid (normally null): 24 cycle counters, see lowres_fused.hip
-};
-int pa_launch_lowres_fwd(const LrOp* ops_dev, int nops, const LrLaunch& L, int B, int chan, hipStream_t st);
-int pa_lowres_max_batch(int chan);      // workgroups (= images) of the fused launch the current device holds at once; larger batches take the launch chain
-
 // ---- optimizer / weight preparation
 int pa_launch_rmsprop(float* p, const float* g, float* v, size_t n, float lr, float alpha, float eps, float gscale, hipStream_t st);
 int pa_rmsprop_skipped(long long* out, hipStream_t st);     // half-precision build: steps skipped for a non-finite gradient
-struct PaPrepJob { const float* w; bf16* wf; bf16* wb; int Cout, Cin, taps, pad_cout, pad_cin;
-                   bf16* wp; };      // wp (optional): the forward weights packed per MFMA fragment [Cout/16][K/32][64 lanes][8] for lowres_fused.hip
+struct PaPrepJob { const float* w; bf16* wf; bf16* wb; int Cout, Cin, taps, pad_cout, pad_cin; };
 int pa_launch_weight_prep(const PaPrepJob* jobs_dev, int njobs, int max_elems, hipStream_t st);
 
 // ---- layout helpers

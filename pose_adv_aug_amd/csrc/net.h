@@ -47,7 +47,6 @@ struct ConvLayer {
     int pcin = 0, pcout = 0;               // padded (multiple of 64) dims used by the kernels
     size_t p_w = 0, p_b = 0;
     bf16 *wf = nullptr, *wb = nullptr;
-    bf16* wp = nullptr;                    // forward weights packed per MFMA fragment (blocks of the fused low-resolution launch only)
     float *part = nullptr, *dbpart = nullptr;
     int splits = 0;
     int red_index = -1;                    // index of this layer's job in the reduce table
@@ -111,13 +110,8 @@ struct Hourglass {
     bf16* poolgrad[4] = {nullptr, nullptr, nullptr, nullptr};   // gradient of the pool routed back to its input
     void declare(Net& n, const std::string& prefix, int chan);
     void layout(Net& n, Arena& a, int B, int H, int W, bool need_grad);
-    // fused: everything below 32 x 32 (pooled[1] ... up[1]) runs as ONE persistent launch (lowres_fused.hip) issued by encode
-    int encode(Net& n, const Act& in, bool fused = false);
-    int decode(Net& n, bool fused = false);
-    LrOp* lr_ops = nullptr; int n_lr_ops = 0;            // the fused program of this hourglass (device table, built by upload_tables)
-    int index = 0;                                       // stack index (barrier counter word)
-    void build_lowres_program(Net& n, std::vector<LrOp>& prog) const;
-    int lowres_fwd(Net& n);
+    int encode(Net& n, const Act& in);
+    int decode(Net& n);
     int bwd(Net& n, const Act& in, const PaOperand& extra0);
     const Act& out() const { return merged[0]; }
 };
@@ -146,14 +140,6 @@ struct Net {
     float* shared_part = nullptr; float* shared_db = nullptr; size_t shared_part_floats = 0, shared_db_floats = 0;
     bool immediate_reduce = false;     // measured on MI355X: +0.55 ms/step (100 extra launches) vs one deferred reduce, so off
     PaBnEvalJob* bneval_jobs = nullptr; int n_bneval = 0;
-    // fused low-resolution sub-hourglass (forward): partial-statistics rows [2][256][256] float2, per-stack barrier counters in
-    // the region begin_step zeroes (behind the loss words)
-    float2* lr_rows = nullptr;
-    unsigned lr_launches = 0;                   // tag of the fused launches' statistics granules
-    long long* lr_timing = nullptr;             // tuning aid: 24 cycle counters of the fused kernel's phases (pa_net_lowres_timing)
-    bool fused_low = false;                     // opt-in (pa_net_set_fused_lowres): measured break-even with the launch chain, DESIGN.md
-    // (a batch the device cannot hold as co-resident workgroups takes the launch chain: the in-kernel statistics exchange needs them all at once)
-    bool fused_low_ok() const { return fused_low && !is_agent && train_bn && !drop_mask && (chan == 256 || chan == 128) && res == 256 && B >= 1 && B <= 256 && B <= pa_lowres_max_batch(chan) && lr_rows != nullptr; }
     // run state
     hipStream_t st = nullptr;
     // side streams: the skip branch of hourglass level k runs on side[k] next to the low-resolution path

@@ -233,82 +233,9 @@ size_t Net::layout_all(char* base) {
         if (i == 0) xin[0] = res3.x3;
         if (i + 1 < stacks) xin[i + 1] = new_act(a, B, H4, H4, chan, nullptr, true);
     }
-    lr_rows = a.get<float2>((size_t)2 * 256 * 256 * 2);        // 16-byte granules
-    for (int i = 0; i < stacks; ++i) {
-        Hourglass& h = hg[i];
-        h.index = i; h.lr_ops = a.get<LrOp>(64);
-        for (Residual* r : {&h.down[1], &h.skip[2], &h.down[2], &h.skip[3], &h.down[3], &h.neck, &h.up[3], &h.up[2], &h.up[1]})
-            for (ConvLayer* c : {&r->c1, &r->c2, &r->c3}) c->wp = a.get<bf16>((size_t)c->pcout * c->taps() * c->pcin);
-    }
     layout_shared(a);
     a.take(0);
     return a.off;
-}
-
-// the fused program of one hourglass: pool -> down[1] -> skip[2] -> pool -> down[2] -> skip[3] -> pool -> down[3] -> neck -> up[3]
-// -> up+add -> up[2] -> up+add -> up[1]   (reference models/asn_stacked_hg.py:139-157, :192-203 below the 32 x 32 level)
-void Hourglass::build_lowres_program(Net& n, std::vector<LrOp>& prog) const {
-    auto tensor = [](const Act& a, const bf16*& p, const float*& k0, const float*& k1) {
-        p = a.raw; k0 = a.bn ? a.bn->scale : nullptr; k1 = a.bn ? a.bn->shift : nullptr;
-    };
-    auto bn_of = [&](const BNLayer& b) {
-        LrBn o; o.gamma = n.params + b.p_gamma; o.beta = n.params + b.p_beta; o.rmean = n.buffers + b.b_rmean; o.rvar = n.buffers + b.b_rvar;
-        o.scale = b.scale; o.shift = b.shift; o.mean = b.mean; o.invstd = b.invstd;
-        return o;
-    };
-    auto conv = [&](const ConvLayer& c, const Act& in, const Act* add, const Act& out, const BNLayer& bn, int src_lds, int dst_lds) {
-        LrOp o; memset(&o, 0, sizeof o);
-        o.src_lds = src_lds; o.dst_lds = dst_lds;
-        o.type = LR_CONV; o.H = out.H; o.W = out.W; o.Cin = c.pcin; o.Cout = c.pcout; o.taps = c.taps();
-        tensor(in, o.in, o.in_k0, o.in_k1);
-        if (add) tensor(*add, o.add, o.add_k0, o.add_k1);
-        o.w = c.wp; o.bias = n.params + c.p_b; o.out = out.raw; o.has_bn = 1; o.bn = bn_of(bn);
-        prog.push_back(o);
-    };
-    auto block = [&](const Residual& r, const Act& in) {
-        conv(r.c1, in, nullptr, r.x1, r.b1, -1, 1);       // x1 stays in LDS buffer V
-        conv(r.c2, r.x1, nullptr, r.x2, r.b2, 1, 0);      // ... x2 in U
-        conv(r.c3, r.x2, &in, r.x3, r.b3, 0, -1);
-    };
-    auto pool = [&](const Act& in, const Act& out) {
-        LrOp o; memset(&o, 0, sizeof o);
-        o.type = LR_POOL; o.H = out.H; o.W = out.W; o.Cin = o.Cout = out.C; o.taps = 1;
-        tensor(in, o.in, o.in_k0, o.in_k1); o.out = out.raw; o.src_lds = o.dst_lds = -1;
-        prog.push_back(o);
-    };
-    auto upadd = [&](const Act& low, const Act& sk, const Act& out) {
-        LrOp o; memset(&o, 0, sizeof o);
-        o.type = LR_UPADD; o.H = out.H; o.W = out.W; o.Cin = o.Cout = out.C; o.taps = 1;
-        tensor(low, o.in, o.in_k0, o.in_k1); tensor(sk, o.add, o.add_k0, o.add_k1); o.out = out.raw; o.src_lds = o.dst_lds = -1;
-        prog.push_back(o);
-    };
-    // (the first pooling, 32 x 32 -> 16 x 16, reads 0.5 MB per image: it stays a launch of its own on the whole chip)
-    block(down[1], pooled[1]);  block(skip[2], down[1].x3);
-    pool(down[1].x3, pooled[2]);  block(down[2], pooled[2]);  block(skip[3], down[2].x3);
-    pool(down[2].x3, pooled[3]);  block(down[3], pooled[3]);  block(neck, down[3].x3);  block(up[3], neck.x3);
-    upadd(up[3].x3, skip[3].x3, merged[3]);  block(up[2], merged[3]);
-    upadd(up[2].x3, skip[2].x3, merged[2]);  block(up[1], merged[2]);
-}
-
-int Hourglass::lowres_fwd(Net& n) {
-    LrLaunch L;
-    L.rows = n.lr_rows;
-    L.launch_id = ++n.lr_launches;
-    L.counter = reinterpret_cast<unsigned*>(n.loss_dev) + 32 + index;      // zeroed by begin_step
-    L.batch = (float)n.B; L.momentum = n.momentum; L.eps = n.eps; L.update_running = n.bn_update;
-    L.timing = n.lr_timing;
-    // algorithmic work of the 27 convolutions (every activation element once, weights once)
-    double bytes = 0, flops = 0;
-    for (const Residual* r : {&down[1], &skip[2], &down[2], &skip[3], &down[3], &neck, &up[3], &up[2], &up[1]}) {
-        const double M = (double)r->x1.M();
-        const double C = n.chan, Cm = n.chan / 2;
-        bytes += 2.0 * M * (C + Cm) + 2.0 * Cm * C + 2.0 * M * 2 * Cm + 2.0 * Cm * 9 * Cm + 2.0 * M * (Cm + C) + 2.0 * C * Cm;
-        flops += 2.0 * M * (C * Cm + Cm * 9 * Cm + Cm * C);
-    }
-    ProfEntry* pe = n.prof.begin(PA_PROF_LOWRES_FWD, bytes, flops, n.st);
-    const int rc = pa_launch_lowres_fwd(lr_ops, n_lr_ops, L, n.B, n.chan, n.st);
-    n.prof.end(pe, n.st);
-    return rc;
 }
 
 int Net::upload_tables() {
@@ -316,7 +243,7 @@ int Net::upload_tables() {
     prep_max = 0; red_max = 0;
     for (ConvLayer* c : convs) {
         if (immediate_reduce) { c->part = shared_part; c->dbpart = c->db_floats ? shared_db : nullptr; }
-        PaPrepJob p; p.w = params + c->p_w; p.wf = c->wf; p.wb = c->wb; p.wp = fused_low ? c->wp : nullptr; p.Cout = c->Cout; p.Cin = c->Cin;
+        PaPrepJob p; p.w = params + c->p_w; p.wf = c->wf; p.wb = c->wb; p.Cout = c->Cout; p.Cin = c->Cin;
         p.taps = c->k == 7 ? 49 : c->taps(); p.pad_cout = c->pcout; p.pad_cin = c->pcin;
         pj.push_back(p);
         int pe = c->pcout * (c->k == 7 ? 256 : c->taps() * c->pcin);
@@ -333,16 +260,6 @@ int Net::upload_tables() {
         PaBnEvalJob j; j.gamma = params + b->p_gamma; j.beta = params + b->p_beta; j.rmean = buffers + b->b_rmean;
         j.rvar = buffers + b->b_rvar; j.scale = b->scale; j.shift = b->shift; j.C = b->C;
         bj.push_back(j);
-    }
-    if (lr_rows && !is_agent && (chan == 256 || chan == 128) && res == 256) {
-        for (Hourglass& h : hg) {
-            std::vector<LrOp> prog;
-            h.build_lowres_program(*this, prog);
-            h.n_lr_ops = (int)prog.size();
-            if (h.n_lr_ops > 48) { pa_set_error_msg("upload_tables: fused program too long"); return 1; }
-            PA_CHECK(hipMemcpyAsync(h.lr_ops, prog.data(), prog.size() * sizeof(LrOp), hipMemcpyHostToDevice, st));
-            PA_CHECK(hipStreamSynchronize(st));
-        }
     }
     n_prep = (int)pj.size(); n_red = (int)rj.size(); n_bneval = (int)bj.size();
     PA_CHECK(hipMemcpyAsync(prep_jobs, pj.data(), pj.size() * sizeof(PaPrepJob), hipMemcpyHostToDevice, st));
@@ -724,13 +641,9 @@ struct StreamScope {
     ~StreamScope() { n.st = saved; n.on_side = saved_side; }
 };
 
-int Hourglass::encode(Net& n, const Act& in, bool fused) {
+int Hourglass::encode(Net& n, const Act& in) {
     const Act* cur = &in;
     for (int k = 0; k < 4; ++k) {
-        if (fused && k == 2) {                              // down[1] ... up[1] in one launch (the level-1 skip branch is already forked)
-            TRY(c_maxpool_fwd(n, n.op(*cur), pooled[1].raw, cur->B, cur->H, cur->W, cur->C, n.st));
-            return lowres_fwd(n);
-        }
         auto skip_branch = [&]() -> int {
             TRY(skip[k].fwd(n, *cur));
             if (n.drop_mask) TRY(pa_launch_cell_mask(n.op(skip[k].x3), n.drop_mask, ep_plain(), skipm[k].raw, cur->B, cur->H, cur->W, cur->C, n.st));
@@ -743,7 +656,6 @@ int Hourglass::encode(Net& n, const Act& in, bool fused) {
         } else {
             TRY(skip_branch());
         }
-        if (fused && k == 1) { cur = &down[0].x3; continue; }     // (its pooling and down[1] belong to the fused launch)
         TRY(c_maxpool_fwd(n, n.op(*cur), pooled[k].raw, cur->B, cur->H, cur->W, cur->C, n.st));
         TRY(down[k].fwd(n, pooled[k]));
         cur = &down[k].x3;
@@ -756,11 +668,10 @@ int Hourglass::encode(Net& n, const Act& in, bool fused) {
     return 0;
 }
 
-int Hourglass::decode(Net& n, bool fused) {
+int Hourglass::decode(Net& n) {
     const Act* low = n.drop_mask ? &neckm : &neck.x3;
     for (int k = 3; k >= 0; --k) {
-        if (!(fused && k >= 1)) TRY(up[k].fwd(n, *low));          // fused: up[3], up[2], up[1] and the two merges below them are done
-        if (fused && k >= 2) continue;
+        TRY(up[k].fwd(n, *low));
         const Act& m = merged[k];
         if (n.forks(k)) TRY(n.wait_join(k));
         TRY(c_upadd_fwd(n, n.op(up[k].x3), n.op(n.drop_mask ? skipm[k] : skip[k].x3), m.raw, m.B, m.H, m.W, m.C, n.st));
@@ -951,9 +862,8 @@ int Net::forward_pose(const float* img_nchw, const bf16* img4_in, const double* 
     TRY(res3.fwd(*this, res2.x3));
     const int Hh = res / 4;
     for (int i = 0; i < stacks; ++i) {
-        const bool fused = fused_low_ok();
-        TRY(hg[i].encode(*this, xin[i], fused));
-        TRY(hg[i].decode(*this, fused));
+        TRY(hg[i].encode(*this, xin[i]));
+        TRY(hg[i].decode(*this));
         TRY(post[i].fwd(*this, hg[i].out()));
         TRY(conv_fwd(lin[i], op(post[i].x3), B, Hh, Hh, pa_none(), pa_none(), lin_out[i].raw, &lin_bn[i]));
         TRY(c_head_fwd(*this, op(lin_out[i]), outc[i].wf, params + outc[i].p_b, heat[i], heat64[i], pts ? pts_dev : nullptr,
@@ -1052,7 +962,6 @@ int Net::train_step_graph(bool train) {
     const int key = (train ? 1 : 0) | (multi_stream ? 2 : 0);
     if (drop_mask || prof.on) { pa_set_error_msg("train_step_graph: not with the occlusion branch / the launch profiler"); return 1; }
     // (a replayed launch would carry the launch number of the capture: its barrier tags would match the previous replay's granules)
-    if (fused_low) { pa_set_error_msg("train_step_graph: not with the fused low-resolution launch (pa_net_set_fused_lowres)"); return 1; }
     if (!step_exec || step_key != key) {
         release_graph();
         // the caller's stream may be the legacy default stream, which cannot capture: capture on a stream of our own

@@ -65,8 +65,6 @@ class _HipModule(object):
             ws = torch.empty(L.pa_net_workspace_bytes(h), dtype=torch.uint8, device=dev)       # (pa_net_bind clears it)
             check(L.pa_net_bind(h, ptr(self.flat_params), ptr(self.flat_grads), ptr(self.flat_buffers), ptr(ws), stream()),
                   'pa_net_bind')
-            if getattr(self, '_fused_lowres', False):
-                check(L.pa_net_set_fused_lowres(h, 1), 'pa_net_set_fused_lowres')
             self._nets[B] = (h, ws)               # (binding packs THIS handle's bf16 weights; a pending change still has to reach
             if len(self._nets) == 1:              #  the handles of the other batch sizes, so the flag survives unless this is the only one)
                 self._weights_dirty = False
@@ -271,19 +269,6 @@ class HourglassNet(_HipModule):
         return outs
 
     use_graph = False        # loss_and_backward(img4=...) replays a captured HIP graph of forward + backward (pa_hg_train_step)
-    _fused_lowres = False
-
-    @property
-    def fused_lowres(self):
-        """True: the sub-hourglass below 32 x 32 of every stack runs as ONE persistent launch in the training forward pass
-        (pa_net_set_fused_lowres; an experiment that measured break-even); False (default): the per-layer launches."""
-        return self._fused_lowres
-
-    @fused_lowres.setter
-    def fused_lowres(self, on):
-        self._fused_lowres = bool(on)
-        for h, _ in self._nets.values():
-            check(lib().pa_net_set_fused_lowres(h, 1 if on else 0), 'pa_net_set_fused_lowres')
     on_stack_done = None     # callback(stack index) after the backward pass of a stack is enqueued (utils.optim.RMSprop(overlap=True))
 
     def loss_and_backward(self, x=None, pts=None, img4=None, want_outputs=False, dropout_masks=None, after_forward=None):

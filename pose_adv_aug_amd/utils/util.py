@@ -121,8 +121,7 @@ def adjust_lr(opt, optimizer, epoch):
 
 def mkdirs(paths):
     for p in (paths if isinstance(paths, list) else [paths]):
-        if not os.path.isdir(p):
-            os.makedirs(p)
+        os.makedirs(p, exist_ok=True)            # (every rank of a data-parallel run parses the options: check-then-create races)
 
 
 def gen_groundtruth(pred_distri, indexes, pckh_regular, pckh_agent):

@@ -105,7 +105,13 @@ def test_training_main_on_two_ranks_with_the_engine_stubbed_at_the_abi(tmp_path)
             ar = [j for j, n in enumerate(seg) if n == 'all_reduce' and r['log'][i + j][1][0] == 40]
             rp = seg.index('pa_rmsprop_step')
             assert len(ar) == 1 and 0 < ar[0] < rp < seg.index('pa_net_prepare_weights'), seg[:12]
-            assert 'pa_hg_accuracy' in seg[rp:] and 'pa_hg_pckh' in seg[rp:]                     # metrics after the update (stack-hg.py:176-178)
+            # the step's meters (stack-hg.py:176-178) read the forward pass's heat maps only: train_step asks for them between the two passes,
+            # on the engine's meter stream (pa_net_meters_async on ... off), so they run beside the backward pass
+            fwd = max(j for j in range(i) if names[j] == 'pa_hg_forward')
+            between = names[fwd:i]
+            on = [j for j, n in enumerate(between) if n == 'pa_net_meters_async']
+            assert len(on) == 2, between
+            assert on[0] < between.index('pa_hg_accuracy') < between.index('pa_hg_pckh') < on[1], between
         bind_stream = [a for n, a in r['log'] if n == 'pa_net_bind'][0][1]
         for n, a in r['log']:
             if n == 'pa_rmsprop_step':

@@ -62,15 +62,13 @@ def _leaf(x):
     return x.clone().requires_grad_(True)
 
 
-@pytest.mark.parametrize('fused', [False, True])
-def test_every_node_of_the_training_graph_matches_locally(fused):
-    """fused: the sub-hourglass below 32 x 32 as ONE persistent launch (csrc/lowres_fused.hip) instead of ~45 launches per stack:
-    the same nodes, the same tolerances."""
+def test_every_node_of_the_training_graph_matches_locally():
+    """models/asn_stacked_hg.py:139-203 as a whole: every node of a small 2-stack net (forward values, parameter gradients, inner masked
+    gradients) against the oracle, in place."""
     torch.set_num_threads(8)
     bf16_emul.ROUND_GRADS = True        # the engine stages gradient operands in bf16 (standard mixed precision)
     stacks, B, res, chan = 2, 2, 256, 128
     ref, net = _hg_pair(stacks, chan, B, res, seed=7)
-    net.fused_lowres = fused
     img = t(inputs.images(8, B, res))
     pts = inputs.heat_pts(9, B, res=res // 4)
     heat_t = t(inputs.heatmaps_from_pts(pts, res=res // 4))
@@ -192,18 +190,16 @@ def test_every_node_of_the_training_graph_matches_locally(fused):
     assert not errs, '%d local mismatches, first: %s' % (len(errs), errs[:15])
 
 
-@pytest.mark.parametrize('fused', [False, True])
-def test_blocks_of_every_resolution_match_locally_at_the_benchmark_size(fused):
+def test_blocks_of_every_resolution_match_locally_at_the_benchmark_size():
     """BASELINE configs[1] at FULL size (2-stack, chan 256, B = 24): one residual block per map size of stack 0 -- skip1 (64x64),
     skip2 (32x32), skip3 (16x16), skip4 (8x8), neck (4x4) -- checked in place like the small net above: forward of conv1 / conv2 /
     conv3 (1e-2), every parameter gradient and the two inner masked gradients (4e-2, cosine 0.999).  This pins the template
     instances only the large grid reaches (row-tile 1x1 kernels looping over channel blocks with >= 512 tiles, XCD-contiguous
-    3x3 tile ranges, 1536-row BatchNorm statistics) INSIDE the fused training graph, streams and all."""
+    3x3 tile ranges, 1536-row BatchNorm statistics) INSIDE the whole training graph, streams and all."""
     torch.set_num_threads(max(16, torch.get_num_threads()))
     bf16_emul.ROUND_GRADS = True
     stacks, B, res, chan = 2, 24, 256, 256
     ref, net = _hg_pair(stacks, chan, B, res, seed=11)
-    net.fused_lowres = fused
     img = t(inputs.images(41, B, res))
     pts = inputs.heat_pts(42, B, res=res // 4)
     ref.train(); net.train()
@@ -301,20 +297,3 @@ def test_stem_second_stack_and_head_layers_match_locally_at_the_benchmark_size()
     assert not errs, '%d local mismatches, first: %s' % (len(errs), errs[:15])
 
 
-def test_graph_replay_refuses_the_fused_low_resolution_launch():
-    """A captured fused launch would replay with the launch number of the capture (its barrier tags would match the granules of
-    the previous replay): pa_hg_train_step(use_graph=1) must fail loudly while pa_net_set_fused_lowres is on."""
-    from pose_adv_aug_amd._lib import PoseAdvError
-    from pose_adv_aug_amd.models.asn_stacked_hg import create_hg
-    from pose_adv_aug_amd.utils.optim import RMSprop
-    from pose_adv_aug_amd.data import Augmenter, DeviceBatch
-    from pose_adv_aug_amd.stack_hg import train_step
-    B = 2
-    net = create_hg(1, 1, 16, 128, default_batch=B); net.reset_parameters(seed=3); net.train()
-    net.fused_lowres = True
-    net.use_graph = True
-    with pytest.raises(PoseAdvError, match='fused low-resolution'):
-        train_step(net, RMSprop(net, lr=2.5e-4), Augmenter(seed=9), DeviceBatch.synthetic(B, seed=40))
-    net.use_graph = False
-    loss, _, _ = train_step(net, RMSprop(net, lr=2.5e-4), Augmenter(seed=9), DeviceBatch.synthetic(B, seed=40))
-    assert np.isfinite(float(loss))

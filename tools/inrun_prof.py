@@ -81,7 +81,7 @@ def parse_pmc(fetch_csv, write_csv, steps):
 
 
 MFMA_KERNELS = ('conv1x1_tile_kernel', 'conv3x3_tile_kernel', 'conv_igemm_kernel', 'wgrad_tile_kernel', 'conv_wgrad_kernel', 'stem_conv',
-                'stem_wgrad', 'lowres_fwd_kernel')
+                'stem_wgrad')
 
 
 def parse_pmc_sequence(fetch_csv, write_csv, seq_path, steps):

@@ -13,7 +13,7 @@ import sqlite3
 import sys
 
 MFMA_KERNELS = ('conv1x1_tile_kernel', 'conv3x3_tile_kernel', 'conv_igemm_kernel', 'wgrad_tile_kernel', 'conv_wgrad_kernel',
-                'stem_conv', 'stem_wgrad', 'lowres_fwd_kernel')
+                'stem_conv', 'stem_wgrad')
 
 
 def main(db, seq_path, out_path):
