@@ -35,6 +35,9 @@ def classify(name):
     m = re.match(r'void conv3x3_(?:tile|tri)_kernel<(\d+), (\d+), (\d+)[,>]', name)
     if m:
         return 'conv_dgrad_3x3' if int(m.group(3)) == 2 else 'conv_fwd_3x3'
+    m = re.match(r'void conv1x1_oneshot_kernel<(\d+), (\d+),', name)
+    if m:
+        return 'conv_dgrad_1x1' if int(m.group(2)) == 2 else 'conv_fwd_1x1'
     m = re.match(r'void conv1x1_tile_kernel<(\d+), (\d+), (\d+), (\d+)>', name)
     if m:
         return 'conv_dgrad_1x1' if int(m.group(4)) == 2 else 'conv_fwd_1x1'
@@ -80,7 +83,7 @@ def parse_pmc(fetch_csv, write_csv, steps):
                         for k, v in per_kernel.items()}}
 
 
-MFMA_KERNELS = ('conv1x1_tile_kernel', 'conv3x3_tile_kernel', 'conv_igemm_kernel', 'wgrad_tile_kernel', 'conv_wgrad_kernel', 'stem_conv',
+MFMA_KERNELS = ('conv1x1_tile_kernel', 'conv1x1_oneshot_kernel', 'conv3x3_tile_kernel', 'conv_igemm_kernel', 'wgrad_tile_kernel', 'conv_wgrad_kernel', 'stem_conv',
                 'stem_wgrad')
 
 
@@ -100,7 +103,9 @@ def parse_pmc_sequence(fetch_csv, write_csv, seq_path, steps):
         mf = [r for r in rows if any(k in r[1] for k in MFMA_KERNELS) and 'reduce' not in r[1]]
         if len(mf) < len(order):
             raise ValueError('fewer MFMA dispatches than the class sequence')
-        for (_, _, v), c in zip(mf[-len(order):], order):
+        for (_, kname, v), c in zip(mf[-len(order):], order):
+            if ('wgrad' in names[c]) != ('wgrad' in kname):      # (a kernel missing from MFMA_KERNELS shifts the whole matching)
+                raise ValueError('launch order and class sequence disagree: %s / %s' % (names[c], kname))
             o = out[names[c]]
             if C == 'FETCH_SIZE':
                 o['fetch_bytes'] += v; o['launches'] += 1

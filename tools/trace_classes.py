@@ -12,7 +12,7 @@ import json
 import sqlite3
 import sys
 
-MFMA_KERNELS = ('conv1x1_tile_kernel', 'conv3x3_tile_kernel', 'conv_igemm_kernel', 'wgrad_tile_kernel', 'conv_wgrad_kernel',
+MFMA_KERNELS = ('conv1x1_tile_kernel', 'conv1x1_oneshot_kernel', 'conv3x3_tile_kernel', 'conv_igemm_kernel', 'wgrad_tile_kernel', 'conv_wgrad_kernel',
                 'stem_conv', 'stem_wgrad')
 
 
@@ -25,6 +25,8 @@ def main(db, seq_path, out_path):
     mf = mf[-n:]
     agg = collections.defaultdict(lambda: [0, 0.0, collections.Counter()])
     for (name, t0, t1), cls in zip(mf, seq['sequence']):
+        # a kernel missing from MFMA_KERNELS shifts the whole matching: weight-gradient classes must meet weight-gradient kernels
+        assert ('wgrad' in seq['classes'][cls]) == ('wgrad' in name), ('launch order and class sequence disagree', seq['classes'][cls], name)
         a = agg[seq['classes'][cls]]
         a[0] += 1; a[1] += (t1 - t0) / 1e3; a[2][name.split('(')[0]] += 1
     out = {}
