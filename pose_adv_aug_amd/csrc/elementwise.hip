@@ -11,13 +11,25 @@
 // ------------------------------------------------------------------------------------------------
 // BatchNorm bookkeeping (reference semantics: torch.nn.BatchNorm2d, eps 1e-5, momentum 0.1,
 // biased variance for normalisation, unbiased for the running estimate).
-// Sum `rows` partial rows [rows][C][2] for the FC channels of this workgroup: 1024 threads =
-// FC channels x (1024/FC) row slices, float2 loads, LDS tree over the slices.  Result in LDS sums[FC][2].
+// Sum `rows` partial rows [rows][C][2] for the FC channels of this workgroup: FT threads =
+// FC channels x (FT / FC) row slices, float2 loads, LDS tree over the slices.  Result in LDS sums[FC][2].
 // FC = 8: 16-32 workgroups per BatchNorm (the kernel is pure latency: launch + row loads in batches + tree; 32 channels per workgroup
 // took 6 us; FC = 4 -- every common row count in ONE batch of loads, twice the workgroups -- measured 0.03 ms per step slower, round 4).
-constexpr int FC = 8;
+// workgroup shape of the finalize launches: FT threads = FC channels x FT / FC row slices (tuning builds: PA_FIN_THREADS, PA_FIN_FC)
+template <class F>
+static void fin_dispatch(F f) {
+    // 512 threads (8 channels x 64 row slices): measured 6.44 - 6.49 ms per step against 6.50 - 6.54 with 1024-thread workgroups (three
+    // interleaved pairs; 256 threads, or 4 channels per workgroup: the same as 512 / 8) -- a 1024-thread workgroup has to find a whole CU's
+    // worth of wave slots next to the other queues' kernels, and the launch is all these kernels are
+    static int ft = -1;
+    if (ft < 0) { const char* e = pa_getenv("PA_FIN_THREADS"); ft = e ? atoi(e) : 512; }
+    if (ft == 256) f(std::integral_constant<int, 256>{}, std::integral_constant<int, 8>{});
+    else if (ft == 1024) f(std::integral_constant<int, 1024>{}, std::integral_constant<int, 8>{});
+    else f(std::integral_constant<int, 512>{}, std::integral_constant<int, 8>{});
+}
+template <int FT, int FC>
 __device__ __forceinline__ void reduce_partial_rows(const float* part, int rows, int C, int c0, float (*sums)[2]) {
-    constexpr int SL = 1024 / FC;
+    constexpr int SL = FT / FC;
     __shared__ __attribute__((aligned(16))) float red[SL][FC + 1][2];
     const int cl = threadIdx.x % FC, sl = threadIdx.x / FC;
     if (rows <= PA_FIN_SMALL_ROWS) {
@@ -65,7 +77,9 @@ __device__ __forceinline__ void reduce_partial_rows(const float* part, int rows,
                     if (r0 + u * SL < rows) { a += v[u][0]; b += v[u][1]; }
             }
         };
-        if (rows <= 4 * SL) batches(std::integral_constant<int, 4>{}); else batches(std::integral_constant<int, 8>{});
+        if (rows <= 4 * SL) batches(std::integral_constant<int, 4>{});
+        else if (rows <= 8 * SL) batches(std::integral_constant<int, 8>{});
+        else batches(std::integral_constant<int, 12>{});      // (1536 rows at 128 slices: ONE round trip instead of 8 + 4)
     }
     red[sl][cl][0] = a; red[sl][cl][1] = b;
     __syncthreads();
@@ -89,7 +103,8 @@ __device__ __forceinline__ void reduce_partial_rows(const float* part, int rows,
     __syncthreads();
 }
 
-__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* stats, int rows, const float* gamma, const float* beta,
+template <int FT, int FC>
+__global__ __launch_bounds__(FT) void bn_finalize_kernel(const float* stats, int rows, const float* gamma, const float* beta,
                                                            float* rmean, float* rvar, float* scale, float* shift, float* mean,
                                                            float* invstd, int C, float count, float momentum, float eps,
                                                            int update_running) {
@@ -103,7 +118,7 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* stats, i
         g = gamma[c0 + threadIdx.x]; bt = beta[c0 + threadIdx.x];
         if (update_running) { rm = rmean[c0 + threadIdx.x]; rv = rvar[c0 + threadIdx.x]; }
     }
-    reduce_partial_rows(stats, rows, C, c0, sums);
+    reduce_partial_rows<FT, FC>(stats, rows, C, c0, sums);
     if (!mine) return;
     const int c = c0 + threadIdx.x;
     float s, sh, mu, is, var;
@@ -121,8 +136,11 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* stats, i
 int pa_launch_bn_finalize(const float* stats, int rows, const float* gamma, const float* beta, float* rmean, float* rvar,
                           float* scale, float* shift, float* mean, float* invstd, int C, float count,
                           float momentum, float eps, int update_running, hipStream_t st) {
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + FC - 1) / FC), dim3(1024), 0, st, stats, rows, gamma, beta, rmean, rvar, scale,
-                       shift, mean, invstd, C, count, momentum, eps, update_running);
+    fin_dispatch([&](auto ft, auto fc) {
+        constexpr int FT = decltype(ft)::value, FC = decltype(fc)::value;
+        hipLaunchKernelGGL((bn_finalize_kernel<FT, FC>), dim3((C + FC - 1) / FC), dim3(FT), 0, st, stats, rows, gamma, beta, rmean, rvar, scale,
+                           shift, mean, invstd, C, count, momentum, eps, update_running);
+    });
     return (int)hipGetLastError();
 }
 
@@ -142,7 +160,8 @@ int pa_launch_bn_eval(const PaBnEvalJob* jobs_dev, int njobs, float eps, hipStre
 }
 
 // dx = s*(dz - S1/M - xhat*S2/M) = kA*dz + kB*x + kC    (per channel)
-__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* bstats, int rows, const float* scale, const float* mean,
+template <int FT, int FC>
+__global__ __launch_bounds__(FT) void bn_bwd_finalize_kernel(const float* bstats, int rows, const float* scale, const float* mean,
                                                                const float* invstd, float* kA, float* kB, float* kC,
                                                                float* dgamma, float* dbeta, int C, float count) {
     __shared__ float sums[FC][2];
@@ -150,7 +169,7 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* bsta
     const bool mine = threadIdx.x < FC && c0 + (int)threadIdx.x < C;
     float sc = 0.f, is = 0.f, mu = 0.f;              // (requested before the reduction, see bn_finalize_kernel)
     if (mine) { sc = scale[c0 + threadIdx.x]; is = invstd[c0 + threadIdx.x]; mu = mean[c0 + threadIdx.x]; }
-    reduce_partial_rows(bstats, rows, C, c0, sums);
+    reduce_partial_rows<FT, FC>(bstats, rows, C, c0, sums);
     if (!mine) return;
     const int c = c0 + threadIdx.x;
     float S1 = sums[threadIdx.x][0], S2 = sums[threadIdx.x][1];
@@ -163,7 +182,8 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* bsta
 
 // two BatchNorm-backward finalizes in one launch (blockIdx.y picks the layer): the upsample-add backward feeds two layers at once
 struct BwdFinArgs { const float* bstats; int rows; const float* scale; const float* mean; const float* invstd; float *kA, *kB, *kC, *dgamma, *dbeta; int C; float count; };
-__global__ __launch_bounds__(1024) void bn_bwd_finalize2_kernel(BwdFinArgs a0, BwdFinArgs a1) {
+template <int FT, int FC>
+__global__ __launch_bounds__(FT) void bn_bwd_finalize2_kernel(BwdFinArgs a0, BwdFinArgs a1) {
     const BwdFinArgs& a = blockIdx.y == 0 ? a0 : a1;
     __shared__ float sums[FC][2];
     const int c0 = blockIdx.x * FC;
@@ -171,7 +191,7 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize2_kernel(BwdFinArgs a0, B
     const bool mine = threadIdx.x < FC && c0 + (int)threadIdx.x < a.C;
     float sc = 0.f, is = 0.f, mu = 0.f;
     if (mine) { sc = a.scale[c0 + threadIdx.x]; is = a.invstd[c0 + threadIdx.x]; mu = a.mean[c0 + threadIdx.x]; }
-    reduce_partial_rows(a.bstats, a.rows, a.C, c0, sums);
+    reduce_partial_rows<FT, FC>(a.bstats, a.rows, a.C, c0, sums);
     if (!mine) return;
     const int c = c0 + threadIdx.x;
     float S1 = sums[threadIdx.x][0], S2 = sums[threadIdx.x][1];
@@ -189,15 +209,21 @@ int pa_launch_bn_bwd_finalize2(const float* bs0, int rows0, const float* sc0, co
     BwdFinArgs a0 = {bs0, rows0, sc0, mu0, is0, kA0, kB0, kC0, dg0, db0, C0, cnt0};
     BwdFinArgs a1 = {bs1, rows1, sc1, mu1, is1, kA1, kB1, kC1, dg1, db1, C1, cnt1};
     const int cm = C0 > C1 ? C0 : C1;
-    hipLaunchKernelGGL(bn_bwd_finalize2_kernel, dim3((cm + FC - 1) / FC, 2), dim3(1024), 0, st, a0, a1);
+    fin_dispatch([&](auto ft, auto fc) {
+        constexpr int FT = decltype(ft)::value, FC = decltype(fc)::value;
+        hipLaunchKernelGGL((bn_bwd_finalize2_kernel<FT, FC>), dim3((cm + FC - 1) / FC, 2), dim3(FT), 0, st, a0, a1);
+    });
     return (int)hipGetLastError();
 }
 
 int pa_launch_bn_bwd_finalize(const float* bstats, int rows, const float* scale, const float* mean, const float* invstd,
                               float* kA, float* kB, float* kC, float* dgamma, float* dbeta, int C, float count,
                               hipStream_t st) {
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + FC - 1) / FC), dim3(1024), 0, st, bstats, rows, scale, mean, invstd, kA, kB,
-                       kC, dgamma, dbeta, C, count);
+    fin_dispatch([&](auto ft, auto fc) {
+        constexpr int FT = decltype(ft)::value, FC = decltype(fc)::value;
+        hipLaunchKernelGGL((bn_bwd_finalize_kernel<FT, FC>), dim3((C + FC - 1) / FC), dim3(FT), 0, st, bstats, rows, scale, mean, invstd, kA, kB,
+                           kC, dgamma, dbeta, C, count);
+    });
     return (int)hipGetLastError();
 }
 
