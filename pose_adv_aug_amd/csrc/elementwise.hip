@@ -449,11 +449,16 @@ int pa_launch_maxpool_fwd(const PaOperand& in, bf16* out, int B, int H, int W, i
     return (int)hipGetLastError();
 }
 
-// Streaming kernels with one partial-statistics row per workgroup (<= 512 rows): big tensors get 1024-thread
-// workgroups so that 512 of them still put 8 waves on every SIMD (256-thread ones left HBM half idle:
-// 3.3 TB/s measured vs 6+ TB/s for a plain copy of the same size).
+// Streaming kernels with one partial-statistics row per workgroup (<= 512 rows): big tensors get larger workgroups so that 512 of
+// them still keep enough loads in flight (256-thread ones, measured ALONE, left HBM half idle: 3.3 TB/s vs 6+ TB/s for a plain copy of the
+// same size).
 static inline void stream_launch_dims(size_t total, int& blocks, int& threads) {
-    threads = total >= (size_t)512 * 1024 ? 1024 : 256;
+    static int big = -1;
+    // 512 threads for the big tensors (1024 until round 4: 6.465 vs 6.434 ms per step over three interleaved pairs -- a 1024-thread
+    // workgroup needs a whole CU's wave slots at once next to the other queues' kernels; 512 workgroups x 512 threads x 9 loads of 16 bytes are
+    // still 38 MB in flight)
+    if (big < 0) { const char* e = pa_getenv("PA_STREAM_THREADS"); big = e ? atoi(e) : 512; }
+    threads = total >= (size_t)512 * 1024 ? big : 256;
     blocks = (int)((total + threads - 1) / threads);
     if (blocks > 512) blocks = 512;          // one partial-statistics row per workgroup
     if (blocks < 1) blocks = 1;
