@@ -142,6 +142,12 @@ int pa_rmsprop_step(float* param, const float* grad, float* square_avg, size_t n
  * pass) is SKIPPED -- parameters and square_avg untouched, the loss-scaling convention the reference's fp32 path never needs --
  * and counted.  *count = steps skipped so far in this process (synchronises `stream`); always 0 in the bf16 build. */
 int pa_rmsprop_skipped_steps(long long* count, void* stream);
+/* The same two calls with the skip state owned by the OPTIMIZER instead of the process: `state` = two int32 on the device
+ * ({this gradient is non-finite, steps skipped so far}), zeroed once by the caller.  Two optimizers that step on different streams
+ * (pose net and agent, joint-train-pose-s-r-agent.py:86-94) each pass their own pair; pa_rmsprop_step shares one pair per process. */
+int pa_rmsprop_step_state(float* param, const float* grad, float* square_avg, size_t n, float lr, float alpha,
+                          float eps, float gscale, int32_t* state, void* stream);
+int pa_rmsprop_skipped_steps_state(const int32_t* state, long long* count, void* stream);
 
 /* ---------------------------------------------------------------- operator level ---------- */
 /* One residual bottleneck block _Residual(C, C) (models/asn_stacked_hg.py:11-49), forward + backward,

@@ -85,6 +85,8 @@ _PROTOS = {
     'pa_sample_categorical': (_i, [_vp, _i, _i, _u64, _u64, C.c_uint, _vp, _vp, _vp]),
     'pa_rmsprop_step': (_i, [_vp, _vp, _vp, _sz, _f, _f, _f, _f, _vp]),
     'pa_rmsprop_skipped_steps': (_i, [_vp, _vp]),
+    'pa_rmsprop_step_state': (_i, [_vp, _vp, _vp, _sz, _f, _f, _f, _f, _vp, _vp]),
+    'pa_rmsprop_skipped_steps_state': (_i, [_vp, _vp, _vp]),
     'pa_residual_workspace_bytes': (_sz, [_i, _i, _i, _i]),
     'pa_residual_fwd_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     'pa_conv2d_workspace_bytes': (_sz, [_i, _i, _i, _i, _i, _i]),

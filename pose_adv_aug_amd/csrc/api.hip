@@ -104,9 +104,19 @@ int pa_cell_mask(const void* x, const float* masks, void* out, int B, int H, int
     TRY(pa_launch_cell_mask(pa_plain(reinterpret_cast<const bf16*>(x)), masks, e, reinterpret_cast<bf16*>(out), B, H, W, C, ST(s))); return 0;
 }
 int pa_rmsprop_step(float* p, const float* g, float* v, size_t n, float lr, float alpha, float eps, float gscale, void* s) {
-    TRY(pa_launch_rmsprop(p, g, v, n, lr, alpha, eps, gscale, ST(s))); return 0;
+    TRY(pa_launch_rmsprop(p, g, v, n, lr, alpha, eps, gscale, nullptr, ST(s))); return 0;
 }
-int pa_rmsprop_skipped_steps(long long* count, void* s) { if (!count) return 1; TRY(pa_rmsprop_skipped(count, ST(s))); return 0; }
+int pa_rmsprop_skipped_steps(long long* count, void* s) { if (!count) return 1; TRY(pa_rmsprop_skipped(nullptr, count, ST(s))); return 0; }
+// the same step with the optimizer's OWN skip state (two int32 on the device, zeroed by the caller once): optimizers on different
+// streams do not share the "this gradient is non-finite" flag
+int pa_rmsprop_step_state(float* p, const float* g, float* v, size_t n, float lr, float alpha, float eps, float gscale, int32_t* state, void* s) {
+    if (!state) { pa_set_error_msg("pa_rmsprop_step_state: state is NULL (two int32 on the device)"); return 1; }
+    TRY(pa_launch_rmsprop(p, g, v, n, lr, alpha, eps, gscale, state, ST(s))); return 0;
+}
+int pa_rmsprop_skipped_steps_state(const int32_t* state, long long* count, void* s) {
+    if (!count || !state) return 1;
+    TRY(pa_rmsprop_skipped(state, count, ST(s))); return 0;
+}
 int pa_nchw_to_nhwc(const float* src, void* dst, int B, int C, int H, int W, void* s) {
     TRY(pa_launch_nchw_f32_to_nhwc_bf16(src, reinterpret_cast<bf16*>(dst), B, C, H, W, ST(s))); return 0;
 }

@@ -13,7 +13,10 @@ build_variant() {      # $1 = object directory, $2 = extra flags, $3 = library n
   local objs=""
   for f in $SRCS; do
     local o=$dir/$f.o
-    if [ ! -f $o ] || [ $f.hip -nt $o ] || [ common.h -nt $o ] || [ kernels.h -nt $o ] || [ conv_epilogue.h -nt $o ] || [ net.h -nt $o ] || [ pose_ops.h -nt $o ] || [ ../../include/poseadv.h -nt $o ]; then
+    local stale=0                 # an object is stale when its source or ANY header is newer (bn_fin.h comes in through kernels.h)
+    [ -f $o ] && [ ! $f.hip -nt $o ] || stale=1
+    for h in *.h ../../include/poseadv.h; do [ $h -nt $o ] && stale=1; done
+    if [ $stale = 1 ]; then
       hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $flags -c $f.hip -o $o &
     fi
     objs="$objs $o"

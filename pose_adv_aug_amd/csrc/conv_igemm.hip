@@ -418,7 +418,7 @@ int pa_launch_conv(const PaConvArgs& a0, hipStream_t st, int* stat_rows) {
         if (a.fin.rows > 0) { pa_set_error_msg("pa_launch_conv: a pending finalize was handed to the row-tile 1x1 kernel (pa_conv_takes_fin)"); return 1; }
         return pa_launch_conv1x1_tile(a, st, stat_rows);
     }
-    if (a.fin.rows > 0 && (a.fin.rows > PA_FIN_SMALL_ROWS || a.Cin > 256 || !pa_conv_takes_fin(a))) { pa_set_error_msg("pa_launch_conv: finalize prologue needs <= 128 partial rows, <= 256 channels and a launch pa_conv_takes_fin() admits"); return 1; }
+    if (a.fin.rows > 0 && (a.fin.rows > PA_FIN_SMALL_ROWS || a.Cin > 256 || (a.Cin & 1) || !pa_conv_takes_fin(a))) { pa_set_error_msg("pa_launch_conv: finalize prologue needs <= 128 partial rows, <= 256 channels and a launch pa_conv_takes_fin() admits"); return 1; }
     const int M = a.B * a.H * a.W;
     // small problems get the 64-row tile so that the grid still covers the 256 CUs
     const bool bigM = M >= 128 * 256;

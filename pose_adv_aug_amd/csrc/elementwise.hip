@@ -136,6 +136,7 @@ __global__ __launch_bounds__(FT) void bn_finalize_kernel(const float* stats, int
 int pa_launch_bn_finalize(const float* stats, int rows, const float* gamma, const float* beta, float* rmean, float* rvar,
                           float* scale, float* shift, float* mean, float* invstd, int C, float count,
                           float momentum, float eps, int update_running, hipStream_t st) {
+    if (C & 1) { pa_set_error_msg("BatchNorm finalize: the statistics rows are read as 16-byte channel pairs -- C must be even (the networks pad to 64)"); return 1; }
     fin_dispatch([&](auto ft, auto fc) {
         constexpr int FT = decltype(ft)::value, FC = decltype(fc)::value;
         hipLaunchKernelGGL((bn_finalize_kernel<FT, FC>), dim3((C + FC - 1) / FC), dim3(FT), 0, st, stats, rows, gamma, beta, rmean, rvar, scale,
@@ -208,6 +209,7 @@ int pa_launch_bn_bwd_finalize2(const float* bs0, int rows0, const float* sc0, co
                                float* dg1, float* db1, int C1, float cnt1, hipStream_t st) {
     BwdFinArgs a0 = {bs0, rows0, sc0, mu0, is0, kA0, kB0, kC0, dg0, db0, C0, cnt0};
     BwdFinArgs a1 = {bs1, rows1, sc1, mu1, is1, kA1, kB1, kC1, dg1, db1, C1, cnt1};
+    if ((C0 | C1) & 1) { pa_set_error_msg("BatchNorm finalize: C must be even (16-byte channel pairs)"); return 1; }
     const int cm = C0 > C1 ? C0 : C1;
     fin_dispatch([&](auto ft, auto fc) {
         constexpr int FT = decltype(ft)::value, FC = decltype(fc)::value;
@@ -219,6 +221,7 @@ int pa_launch_bn_bwd_finalize2(const float* bs0, int rows0, const float* sc0, co
 int pa_launch_bn_bwd_finalize(const float* bstats, int rows, const float* scale, const float* mean, const float* invstd,
                               float* kA, float* kB, float* kC, float* dgamma, float* dbeta, int C, float count,
                               hipStream_t st) {
+    if (C & 1) { pa_set_error_msg("BatchNorm finalize: the statistics rows are read as 16-byte channel pairs -- C must be even (the networks pad to 64)"); return 1; }
     fin_dispatch([&](auto ft, auto fc) {
         constexpr int FT = decltype(ft)::value, FC = decltype(fc)::value;
         hipLaunchKernelGGL((bn_bwd_finalize_kernel<FT, FC>), dim3((C + FC - 1) / FC), dim3(FT), 0, st, bstats, rows, scale, mean, invstd, kA, kB,
@@ -821,11 +824,14 @@ __global__ void rmsprop_kernel(float* p, const float* g, float* v, size_t n, flo
 // Half-precision build only (gradients travel multiplied by PA_GRAD_SCALE, common.h): an overflow anywhere in the backward
 // pass shows up as inf / NaN in the flat gradient.  A step whose gradient holds a non-finite value is SKIPPED (parameters and
 // square_avg untouched, the loss-scaling convention) and counted; pa_rmsprop_skipped_steps reads the counter.
+// The two state words belong to ONE optimizer: the caller passes its own device pair (pa_rmsprop_step_state), so that two optimizers
+// stepping on different streams (pose net and agent in the joint stage) cannot see each other's flag; the process-wide pair below
+// only serves the stateless entry point pa_rmsprop_step.
 __device__ int g_grad_state[2];            // [0] this step's gradient holds a non-finite value, [1] steps skipped so far
 
-__global__ void grad_check_reset_kernel() { g_grad_state[0] = 0; }
+__global__ void grad_check_reset_kernel(int* state) { (state ? state : g_grad_state)[0] = 0; }
 
-__global__ void grad_check_kernel(const float* g, size_t n) {
+__global__ void grad_check_kernel(const float* g, size_t n, int* state) {
     size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     const size_t stride = (size_t)gridDim.x * blockDim.x * 4;
     bool bad = false;
@@ -834,12 +840,13 @@ __global__ void grad_check_kernel(const float* g, size_t n) {
         bad |= !(isfinite(gg[0]) && isfinite(gg[1]) && isfinite(gg[2]) && isfinite(gg[3]));
     }
     for (; i < n && i + 3 >= n; ++i) bad |= !isfinite(g[i]);
-    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(&g_grad_state[0], 1);
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(&(state ? state : g_grad_state)[0], 1);
 }
 
-__global__ void rmsprop_checked_kernel(float* p, const float* g, float* v, size_t n, float lr, float alpha, float eps, float gscale) {
-    if (g_grad_state[0]) {                  // uniform over the grid: every thread reads the same word
-        if (blockIdx.x == 0 && threadIdx.x == 0) g_grad_state[1] += 1;
+__global__ void rmsprop_checked_kernel(float* p, const float* g, float* v, size_t n, float lr, float alpha, float eps, float gscale, int* state) {
+    int* gs = state ? state : g_grad_state;
+    if (gs[0]) {                            // uniform over the grid: every thread reads the same word
+        if (blockIdx.x == 0 && threadIdx.x == 0) gs[1] += 1;
         return;
     }
     size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
@@ -862,25 +869,27 @@ __global__ void rmsprop_checked_kernel(float* p, const float* g, float* v, size_
     }
 }
 
-int pa_launch_rmsprop(float* p, const float* g, float* v, size_t n, float lr, float alpha, float eps, float gscale, hipStream_t st) {
+int pa_launch_rmsprop(float* p, const float* g, float* v, size_t n, float lr, float alpha, float eps, float gscale, int* state, hipStream_t st) {
     if (n == 0) return 0;
     int blocks = (int)((n / 4 + 255) / 256);
     if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;
 #ifdef PA_FP16
-    hipLaunchKernelGGL(grad_check_reset_kernel, dim3(1), dim3(1), 0, st);
-    hipLaunchKernelGGL(grad_check_kernel, dim3(blocks), dim3(256), 0, st, g, n);
-    hipLaunchKernelGGL(rmsprop_checked_kernel, dim3(blocks), dim3(256), 0, st, p, g, v, n, lr, alpha, eps, gscale);
+    hipLaunchKernelGGL(grad_check_reset_kernel, dim3(1), dim3(1), 0, st, state);
+    hipLaunchKernelGGL(grad_check_kernel, dim3(blocks), dim3(256), 0, st, g, n, state);
+    hipLaunchKernelGGL(rmsprop_checked_kernel, dim3(blocks), dim3(256), 0, st, p, g, v, n, lr, alpha, eps, gscale, state);
 #else
+    (void)state;
     hipLaunchKernelGGL(rmsprop_kernel, dim3(blocks), dim3(256), 0, st, p, g, v, n, lr, alpha, eps, gscale);
 #endif
     return (int)hipGetLastError();
 }
 
-int pa_rmsprop_skipped(long long* out, hipStream_t st) {
+int pa_rmsprop_skipped(const int* state, long long* out, hipStream_t st) {
     int h[2] = {0, 0};
 #ifdef PA_FP16
-    hipError_t e = hipMemcpyFromSymbolAsync(h, HIP_SYMBOL(g_grad_state), sizeof h, 0, hipMemcpyDeviceToHost, st);
+    hipError_t e = state ? hipMemcpyAsync(h, state, sizeof h, hipMemcpyDeviceToHost, st)
+                         : hipMemcpyFromSymbolAsync(h, HIP_SYMBOL(g_grad_state), sizeof h, 0, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) return (int)e;
 #endif

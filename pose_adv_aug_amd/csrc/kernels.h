@@ -94,8 +94,8 @@ int pa_launch_stem_wgrad(const PaWgradArgs& a, hipStream_t st);
 int pa_launch_stem_wgrad_reduce(const float* part, int splits, float* dst, hipStream_t st);
 
 // ---- optimizer / weight preparation
-int pa_launch_rmsprop(float* p, const float* g, float* v, size_t n, float lr, float alpha, float eps, float gscale, hipStream_t st);
-int pa_rmsprop_skipped(long long* out, hipStream_t st);     // half-precision build: steps skipped for a non-finite gradient
+int pa_launch_rmsprop(float* p, const float* g, float* v, size_t n, float lr, float alpha, float eps, float gscale, int* state, hipStream_t st);   // state: the optimizer's own {flag, skipped} device pair or NULL (process-wide pair)
+int pa_rmsprop_skipped(const int* state, long long* out, hipStream_t st);     // half-precision build: steps skipped for a non-finite gradient
 struct PaPrepJob { const float* w; bf16* wf; bf16* wb; int Cout, Cin, taps, pad_cout, pad_cin; };
 int pa_launch_weight_prep(const PaPrepJob* jobs_dev, int njobs, int max_elems, hipStream_t st);
 

@@ -810,7 +810,8 @@ int Net::begin_step() {
 // reference :282-342 (stem :283-289, stacks :292-334) + loss of stack-hg.py:156-159
 int Net::meter_stream(hipStream_t* out) {
     *out = st;
-    if (!meters_async || !multi_stream) return 0;
+    // a meter on the main stream may read what a pending meter-stream launch produced (the cached arg-max): order it behind them
+    if (!meters_async || !multi_stream) return join_meters();
     if (!mstream) {
         PA_CHECK(hipStreamCreateWithFlags(&mstream, hipStreamNonBlocking));
         PA_CHECK(hipEventCreateWithFlags(&ev_mfork, hipEventDisableTiming));
@@ -961,6 +962,9 @@ int Net::train_step_graph(bool train) {
     TRY(ensure_streams());
     const int key = (train ? 1 : 0) | (multi_stream ? 2 : 0);
     if (drop_mask || prof.on) { pa_set_error_msg("train_step_graph: not with the occlusion branch / the launch profiler"); return 1; }
+    // meters left on the meter stream by an eager step (pa_net_meters_async) read the heat maps / joints this launch overwrites; the
+    // join must also happen OUTSIDE a capture (its event was recorded outside)
+    TRY(join_meters());
     // (a replayed launch would carry the launch number of the capture: its barrier tags would match the previous replay's granules)
     if (!step_exec || step_key != key) {
         release_graph();

@@ -68,8 +68,10 @@ class BatchFeed(object):
     reference's loops, stack-hg.py:133,183): len() = number of batches, .num_samples = number of people, iter() starts a
     fresh pass (`make_iter` is called once per pass)."""
 
-    def __init__(self, num_batches, num_samples, make_iter):
+    def __init__(self, num_batches, num_samples, make_iter, dataset_size=None):
         self._n, self.num_samples, self._make_iter = int(num_batches), int(num_samples), make_iter
+        # people in the SPLIT the feed draws from (>= num_samples: a drop_last / sharded feed visits fewer per pass)
+        self.dataset_size = int(num_samples if dataset_size is None else dataset_size)
 
     def __len__(self):
         return self._n
@@ -87,6 +89,12 @@ class BatchFeed(object):
 def num_samples(batches):
     """people in a feed WITHOUT consuming it"""
     return batches.num_samples if hasattr(batches, 'num_samples') else sum(b.B for b in batches)
+
+
+def dataset_size(batches):
+    """people in the split behind a feed (what a dataset-order, keep-everything pass over it visits): a shuffled training
+    feed drops its last partial batch, so its num_samples can be smaller"""
+    return batches.dataset_size if hasattr(batches, 'dataset_size') else num_samples(batches)
 
 
 class Augmenter(object):

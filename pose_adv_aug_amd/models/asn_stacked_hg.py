@@ -315,6 +315,11 @@ class HourglassNet(_HipModule):
         finally:
             if keep is not None:
                 self._set_masks(h, None)
+            if getattr(self, '_meter_keep', None) is not None:
+                # after_forward() or the backward call raised: the join was never enqueued.  Wait for the meter stream before its
+                # buffers go back to the allocator, and stop collecting (later accuracy() calls would grow the list for ever).
+                torch.cuda.synchronize()
+                self._meter_keep = None
         return losses.sum(), outs
 
     def accuracy(self, idxs, stack=-1):

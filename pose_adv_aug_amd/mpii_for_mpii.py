@@ -204,7 +204,8 @@ class MPII(object):
                             pass
 
         total = sum(min(batch_size, n - k * batch_size) for k in (range(rank, nb_all, world) if world > 1 else range(nb_all)))
-        return BatchFeed(nb, total if world == 1 else min(total, nb * batch_size), one_pass_processes if decoder == 'process' else one_pass_threads)
+        return BatchFeed(nb, total if world == 1 else min(total, nb * batch_size), one_pass_processes if decoder == 'process' else one_pass_threads,
+                         dataset_size=n)
 
     # ---- process-pool path
     MAX_FRAME = (1088, 1920)                  # slot size: MPII images are at most 1920 x 1080

@@ -114,6 +114,23 @@ def validate(batches, scale_distri, rotation_distri, hg, agent, augmenter, epoch
     return _run(batches, scale_distri, rotation_distri, hg, agent, None, augmenter, epoch, opt, log)
 
 
+def distribution_rows(path, people, collect):
+    """The rows of one distribution file (row i = person i of the split, `people` rows).  A file that is missing or was cut short
+    by an interrupted collection (collect_data appends) is collected again -- `collect(tmp_path)` writes it -- and appears under
+    its name only when it is complete."""
+    rows = read_grnd_distri_from_txt(path) if os.path.isfile(path) else None
+    if rows is None or len(rows) != people:
+        tmp = path + '.collecting'
+        if os.path.isfile(tmp):
+            os.remove(tmp)
+        collect(tmp)
+        os.replace(tmp, path)
+        rows = read_grnd_distri_from_txt(path)
+        if len(rows) != people:
+            raise RuntimeError('%s: %d distribution rows for %d people' % (path, len(rows), people))
+    return rows
+
+
 def main(argv=None):
     """pretrain-s-r-agent.py:34-146: collect (if the text files are missing) + pre-train.  The agent checkpoints carry an
     ASNTrainHistory (lowest_loss / is_best by train loss, :52,:131-135) so that stage 3 loads them
@@ -146,7 +163,7 @@ def main(argv=None):
     # the feeds are STREAMED every pass (an MPII split resident in HBM would be 60-130 GB of padded frames): the collection
     # pass walks each split once in dataset order (row i of a text file = person i, collect-scale-ditri.py:123-255), the
     # training passes look a person's distribution up by its dataset index (data/pretrain_s_r_agent.py:127-128)
-    from .data import num_samples
+    from .data import dataset_size
     train_feed, val_feed = make_feeds(opt)
     ordered = {}                                          # the dataset-order train feed (a second JSON parse + decoder pool): only when a file has to be collected
 
@@ -158,19 +175,12 @@ def main(argv=None):
         return ordered['train']
     distri = {}
     for split in ('train', 'val'):
-        people = num_samples(train_feed if split == 'train' else val_feed)
+        # rows of a distribution file = people of the SPLIT (the ordered feed that writes it keeps the last partial batch; the
+        # shuffled training feed drops it, so ITS num_samples is (n // bs) * bs)
+        people = dataset_size(train_feed if split == 'train' else val_feed)
         for kind, fname in (('scale', '%s_scales.txt' % split), ('rotation', '%s_rotations.txt' % split)):
             path = os.path.join(sr_dir, fname)
-            rows = read_grnd_distri_from_txt(path) if os.path.isfile(path) else None
-            if rows is None or len(rows) != people:       # missing, or cut short by an interrupted collection (it appends): collect again
-                tmp = path + '.collecting'
-                if os.path.isfile(tmp):
-                    os.remove(tmp)
-                collect_data(feed_of(split), hg, aug, kind, tmp)
-                os.replace(tmp, path)                     # the file appears only when it is complete
-                rows = read_grnd_distri_from_txt(path)
-                if len(rows) != people:
-                    raise RuntimeError('%s: %d distribution rows for %d people' % (path, len(rows), people))
+            rows = distribution_rows(path, people, lambda tmp: collect_data(feed_of(split), hg, aug, kind, tmp))
             distri[(split, kind)] = rows
     summary = sr_dir + '/' + 'training-summary.txt'
     resumed = opt.load_prefix_sr != '' and os.path.isfile(summary)

@@ -31,6 +31,9 @@ class RMSprop(object):
         net._ensure_table()
         self.param_groups = [{'lr': lr, 'alpha': alpha, 'eps': eps, 'momentum': 0, 'weight_decay': 0, 'centered': False}]
         self.square_avg = torch.zeros_like(net.flat_params)
+        # fp16 build: {this gradient is non-finite, steps skipped so far} of THIS optimizer (the pose net's and the agent's step on
+        # different streams in the joint stage; a process-wide flag would let one see the other's overflow)
+        self._skip_state = torch.zeros(2, dtype=torch.int32, device=net.flat_params.device)
         self.steps = 0
 
     def zero_grad(self):
@@ -85,9 +88,9 @@ class RMSprop(object):
         world_scale = self._finish_exchange() if self._works else self.allreduce_grads()
         gscale = world_scale / _lib.grad_scale()                    # 1/world, and the fp16 build's gradient scale divided out
         n = self.net.flat_params.numel()
-        check(lib().pa_rmsprop_step(ptr(self.net.flat_params), ptr(self.net.flat_grads), ptr(self.square_avg), n,
-                                    float(g['lr']), float(g['alpha']), float(g['eps']), float(gscale), stream()),
-              'pa_rmsprop_step')
+        check(lib().pa_rmsprop_step_state(ptr(self.net.flat_params), ptr(self.net.flat_grads), ptr(self.square_avg), n,
+                                          float(g['lr']), float(g['alpha']), float(g['eps']), float(gscale), ptr(self._skip_state), stream()),
+              'pa_rmsprop_step_state')
         self.steps += 1
         self.net.weights_changed()
         self.net._net(self.net._last_B or self.net.default_batch)      # refresh the bf16 weight copies now
@@ -96,7 +99,7 @@ class RMSprop(object):
         """fp16 build: optimizer steps the engine skipped because the (scaled) gradient held inf / NaN; 0 in the bf16 build"""
         import ctypes as C
         n = C.c_longlong(0)
-        check(lib().pa_rmsprop_skipped_steps(C.byref(n), stream()), 'pa_rmsprop_skipped_steps')
+        check(lib().pa_rmsprop_skipped_steps_state(ptr(self._skip_state), C.byref(n), stream()), 'pa_rmsprop_skipped_steps_state')
         return int(n.value)
 
     # torch.optim-compatible (de)serialisation: per-parameter state keyed by index, in parameters() order

@@ -99,6 +99,10 @@ class FakeLib(object):
         p.addcdiv_(gg, v.sqrt().add_(eps), value=-lr)
         return 0
 
+    def pa_rmsprop_step_state(self, p, g, v, n, lr, alpha, eps, gscale, state, stream):
+        assert state.numel() == 2 and state.dtype == torch.int32          # the optimizer's own {flag, skipped} pair
+        return self.pa_rmsprop_step(p, g, v, n, lr, alpha, eps, gscale, stream)
+
 
 def install(rank):
     """Route the package's ctypes layer to a FakeLib on CPU tensors.  Returns the FakeLib."""

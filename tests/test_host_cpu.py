@@ -219,6 +219,43 @@ def test_mpii_feed_sizes_and_rank_shards(tmp_path):
     assert len(f0) == len(f1) == 2 and f0.num_samples == f1.num_samples == 16       # equal counts on every rank
 
 
+def test_distribution_files_are_sized_by_the_split_not_by_the_drop_last_feed(tmp_path):
+    """stage 2 (pretrain-s-r-agent.py:262-275): a distribution file has one row per person of the SPLIT; the shuffled training
+    feed drops its last partial batch (n % bs != 0 on real MPII), so a complete file must not be judged 'cut short'."""
+    import json
+    from pose_adv_aug_amd.mpii_for_mpii import MPII
+    from pose_adv_aug_amd.data import dataset_size, num_samples, BatchFeed
+    from pose_adv_aug_amd.pretrain_s_r_agent import distribution_rows
+    anno = [dict(dataset='MPII', isValidation=float(i % 5 == 0), img_paths='i%d.jpg' % i, joint_self=[[1.0, 2.0, 1.0]] * 16,
+                 objpos=[100.0, 80.0], scale_provided=1.0, normalizer=10.0) for i in range(53)]
+    p = tmp_path / 'a.json'
+    p.write_text(json.dumps(anno))
+    ds = MPII(str(p), str(tmp_path), is_train=True, log=lambda m: None)
+    shuffled, ordered = ds.batches(8, drop_last=True), ds.batches(8, shuffle=False, drop_last=False)
+    assert num_samples(shuffled) == 40 and dataset_size(shuffled) == 42 == num_samples(ordered) == dataset_size(ordered)
+    assert dataset_size(BatchFeed.of([types.SimpleNamespace(B=3), types.SimpleNamespace(B=2)])) == 5
+    path = str(tmp_path / 'train_scales.txt')
+    calls = []
+
+    def write_rows(n):
+        def collect(tmp):
+            calls.append(n)
+            with open(tmp, 'w') as fd:
+                for _ in range(n):
+                    fd.write('0.25 0.25 0.50\n')
+        return collect
+    rows = distribution_rows(path, dataset_size(shuffled), write_rows(42))               # missing: collected once
+    assert len(rows) == 42 and calls == [42]
+    rows = distribution_rows(path, dataset_size(shuffled), write_rows(42))               # complete: NOT collected again
+    assert len(rows) == 42 and calls == [42]
+    with open(path, 'w') as fd:                                                          # cut short by an interrupted run
+        fd.write('0.25 0.25 0.50\n' * 17)
+    rows = distribution_rows(path, dataset_size(shuffled), write_rows(42))
+    assert len(rows) == 42 and calls == [42, 42] and not os.path.exists(path + '.collecting')
+    with pytest.raises(RuntimeError):                                                    # a collection that comes out short is an error
+        distribution_rows(str(tmp_path / 'val_scales.txt'), 11, write_rows(10))
+
+
 def test_optimizer_state_loads_torch_files_and_warns(tmp_path):
     """utils/optim.RMSprop.load_state_dict: torch.optim.RMSprop files keyed by position OR by arbitrary ids (torch 0.3), a
     missing / mis-shaped entry is reported"""
