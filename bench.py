@@ -135,46 +135,68 @@ def pckh_parity(net, aug, batch, B, res):
             'per_joint_values_compared': int(sum(len(x) for x in (e_acc, e_pck, e2_acc, e2_pck)))}
 
 
-def cold_rate(dev, mb=(25, 50, 100)):
-    """What a plain streaming kernel reaches on tensors it has not touched for a few hundred MB of traffic (tools/bw_probe_cold.py's
-    protocol: `a + b -> c` on bf16 tensors of the step's sizes, 640 MB of other traffic between launches, one event pair per launch).
-    Returns TB/s at the median size and the per-size table."""
-    flush = torch.empty(640 << 20, dtype=torch.uint8, device=dev)
+def cold_rate(dev, mb=(25, 50, 100, 400)):
+    """What "just moving the bytes" reaches on this box, with the ENGINE'S OWN plain streaming kernel (pa_copy_probe: 16 B per lane,
+    elementwise.hip) -- not a framework kernel: a copy of a buffer of each size that has not been touched for 640 MB of other traffic
+    (the step's tensors are cold: ~19 GB move between two uses), one HIP-event pair per launch, median of 7; and the large-buffer rate
+    (1.6 GB copy, warm-up + median of 5) that a launch's ramp and tail no longer dent.  Returns (rate at the median per-launch size,
+    per-size table, large-buffer rate), TB/s of read + written bytes."""
+    from pose_adv_aug_amd import _lib
+    lib, ptr, check, stream = _lib.lib(), _lib.ptr, _lib.check, _lib.stream
+    flush_a = torch.empty(320 << 20, dtype=torch.uint8, device=dev)
+    flush_b = torch.empty(320 << 20, dtype=torch.uint8, device=dev)
+
+    def timed(dst, src, nbytes, flush):
+        if flush:
+            check(lib.pa_copy_probe(ptr(flush_b), ptr(flush_a), flush_a.numel(), stream()), 'pa_copy_probe')
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); check(lib.pa_copy_probe(ptr(dst), ptr(src), nbytes, stream()), 'pa_copy_probe'); e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e-3
     out = {}
     for m in mb:
-        n = (m << 20) // 2
-        a, b, c = (torch.empty(n, dtype=torch.bfloat16, device=dev).normal_() for _ in range(3))
-        ts = []
-        for _ in range(7):
-            flush.add_(1)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(); torch.add(a, b, out=c); e1.record()
-            torch.cuda.synchronize()
-            ts.append(e0.elapsed_time(e1) * 1e-3)
-        ts.sort()
-        out[m] = 3.0 * (m << 20) / ts[len(ts) // 2] / 1e12
-    sizes = sorted(out)
-    return out[sizes[len(sizes) // 2]], {('%dMB' % k): round(v, 2) for k, v in out.items()}
+        n = m << 20
+        a = torch.empty(n, dtype=torch.uint8, device=dev).random_(0, 255)
+        b = torch.empty(n, dtype=torch.uint8, device=dev)
+        ts = sorted(timed(b, a, n, True) for _ in range(7))
+        out[m] = 2.0 * n / ts[len(ts) // 2] / 1e12
+        del a, b
+    n = 1600 << 20
+    a = torch.empty(n, dtype=torch.uint8, device=dev).random_(0, 255)
+    b = torch.empty(n, dtype=torch.uint8, device=dev)
+    timed(b, a, n, False)
+    ts = sorted(timed(b, a, n, False) for _ in range(5))
+    large = 2.0 * n / ts[len(ts) // 2] / 1e12
+    sizes = sorted(k for k in out if k <= 100)
+    return out[sizes[len(sizes) // 2]], {('%dMB' % k): round(v, 2) for k, v in out.items()}, large
 
 
-def design_floor(net, opt, B, res, h):
-    """`roofline.floor`: the bytes THIS fused design moves per step (engine launch table, pa_net_design_bytes: activations, both
-    operands of the BatchNorm-backward loads, reference tensors, stored dz tensors, fp32 slabs written + read back, weights; plus the
-    optimizer, the weight re-pack and the crop counted here from their sizes) at the cold streaming rate measured in this run =>
-    the step time this set of fusions cannot go below on this box; algorithmic bytes beside it."""
+def design_floor(net, opt, B, res, h, frame_hw=(720, 1280)):
+    """`roofline.floor`: the bytes THIS fused design moves per step, all from the library's own tables -- the engine's launch table
+    (pa_net_design_bytes: activations, both operands of the BatchNorm-backward loads, reference tensors, stored dz tensors, fp32 slabs
+    written + read back, weights), the crop's stage buffers (pa_crop_design_bytes: an upper bound, worst-case windows), RMSprop
+    (p, g, v read; p, v written) and the weight re-pack (fp32 read, two 16-bit copies written) from the parameter count -- at two
+    rates measured in this run with the engine's own copy kernel: cold at the step's per-launch tensor sizes (what one launch of
+    25-100 MB can see) and the large-buffer rate (what the memory system sustains).  Algorithmic bytes beside it."""
     from pose_adv_aug_amd import _lib
     rw = (C.c_double * 2)()
     _lib.check(_lib.lib().pa_net_design_bytes(h, rw))
+    crop = (C.c_double * 2)()
+    _lib.check(_lib.lib().pa_crop_design_bytes(B, frame_hw[0], frame_hw[1], res, crop))
     npar = int(net.flat_params.numel())
-    extra_rd = 3 * 4.0 * npar + 4.0 * npar + B * 3.0 * 720 * 1280 * 0.35       # RMSprop p, g, v; re-pack source; crop window (~35 % of a frame)
-    extra_wr = 2 * 4.0 * npar + 2 * 2.0 * npar + B * (res * res * 4 * 2.0 + 3.3e6 * 0.3)
-    total = rw[0] + rw[1] + extra_rd + extra_wr
-    rate, table = cold_rate(net.flat_params.device)
-    return {'design_bytes_per_step': round(total), 'design_read': round(rw[0] + extra_rd), 'design_write': round(rw[1] + extra_wr),
+    opt_rd, opt_wr = 3 * 4.0 * npar + 4.0 * npar, 2 * 4.0 * npar + 2 * 2.0 * npar
+    total = rw[0] + rw[1] + crop[0] + crop[1] + opt_rd + opt_wr
+    rate, table, large = cold_rate(net.flat_params.device)
+    return {'design_bytes_per_step': round(total), 'design_read': round(rw[0] + crop[0] + opt_rd), 'design_write': round(rw[1] + crop[1] + opt_wr),
+            'parts': {'net_read': round(rw[0]), 'net_write': round(rw[1]), 'crop_read_bound': round(crop[0]), 'crop_write_bound': round(crop[1]),
+                      'optimizer_repack_read': round(opt_rd), 'optimizer_repack_write': round(opt_wr)},
             'algorithmic_bytes_per_step': round(380.5e6 * B) if res == 256 else None,
-            'cold_rate_TBps': round(rate, 2), 'cold_rate_table_TBps': table, 'floor_ms': round(total / (rate * 1e12) * 1e3, 3),
+            'cold_rate_TBps': round(rate, 2), 'cold_rate_table_TBps': table, 'rate_large_TBps': round(large, 2),
+            'floor_ms': round(total / (rate * 1e12) * 1e3, 3), 'floor_ms_at_large_rate': round(total / (large * 1e12) * 1e3, 3),
             'floor_ms_at_8TBps': round(total / 8e12 * 1e3, 3),
-            'note': 'floor_ms = design bytes / cold streaming rate of a plain a+b->c kernel at the median tensor size (measured in this run)'}
+            'algorithmic_floor_ms_at_large_rate': round(380.5e6 * B / (large * 1e12) * 1e3, 3) if res == 256 else None,
+            'note': 'rates: pa_copy_probe (the engine\'s own 16 B/lane copy) measured in this run; floor_ms = design bytes / cold rate at the '
+                    'median per-launch size (25-100 MB buffers untouched for 640 MB of traffic); floor_ms_at_large_rate = design bytes / 1.6 GB copy rate'}
 
 
 def self_launch(n):
@@ -302,6 +324,15 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax[0])
     value = world * B * args.steps / dt
+    # who actually took part: a one per rank summed THROUGH the collective backend, and the distinct devices behind the ranks
+    ranks_seen, devices_seen, backend = 1, 1, None
+    if world > 1 or (dist.is_available() and dist.is_initialized()):
+        ones = torch.ones(1, dtype=torch.float64, device=dev)
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+        ranks_seen = int(round(float(ones[0])))
+        ids = [None] * dist.get_world_size()
+        dist.all_gather_object(ids, '%s:%s' % (os.uname().nodename, getattr(torch.cuda.get_device_properties(dev), 'uuid', torch.cuda.current_device())))
+        devices_seen, backend = len(set(ids)), dist.get_backend()
 
     # median of per-step event intervals, in a pass of its own: an event record between two kernels of a queue
     # costs that queue a bubble, so it stays out of the timed region that `value` comes from
@@ -423,6 +454,7 @@ def main():
                                        % ('BASELINE configs[1]: ' if (args.stacks, args.chan, res, B, args.dtype) == (2, 256, 256, 24, 'bf16') else
                                           ('BASELINE configs[4]: ' if (args.stacks, args.chan, res, B, args.dtype) == (8, 256, 384, 16, 'fp16') else ''), args.stacks, args.chan, B, res, res),
                            'global_batch': world * B, 'parallelism': 'dp%d' % world + ('+overlapped-exchange' if args.overlap and world > 1 else ''),
+                           'ranks_seen': ranks_seen, 'devices_seen': devices_seen, 'collective_backend': backend,
                            'loss': float(loss), 'pckh': float(pckh), 'pckh_origin_res': float(pckh_o)},
                 'pckh_parity': parity, 'roofline': roofline, 'cpu_baseline': cpu}
         print(json.dumps(line))

@@ -98,6 +98,9 @@ int pa_transform_pts_sized(const float* pts, const double* params, const double*
  * workspace: pa_crop_workspace_bytes() bytes (scratch, no initialisation needed);
  * out4: bf16 [B][res][res][4] network input, outf: fp32 [B][3][res][res], out8: uint8 [B][res][res][3]; any may be NULL. */
 size_t pa_crop_workspace_bytes(int B, int Hs, int Ws, int res);
+/* Upper bound of the bytes one pa_crop call reads (out[0]) and writes (out[1]), from the geometry of its own stage buffers at their
+ * worst-case window sizes (bench.py's roofline.floor; the reference's crop, pylib/HumanAug.py:117-176, has no such notion). */
+int pa_crop_design_bytes(int B, int Hs, int Ws, int res, double* out_host);
 int pa_crop(const uint8_t* src, int Hs, int Ws, const int32_t* sizes, const double* params, int B, int res, void* workspace,
             void* out4, float* outf, uint8_t* out8, void* stream);
 
@@ -312,6 +315,10 @@ int pa_net_set_fin_prologue(pa_net* net, int max_rows);
  * weight-gradient slabs written and read back, weights; halo re-reads and cache hits are NOT modelled (it is a floor for this set
  * of fusions, above the "every activation once" figure of SURVEY.md section 8d).  out_host[0] = bytes read, [1] = bytes written. */
 int pa_net_design_bytes(const pa_net* net, double* out_host);
+/* Bandwidth calibration for the same floor: dst[i] = src[i] with the engine's own plain 16-byte-per-lane streaming kernel (`bytes` a
+ * multiple of 16).  Not part of the reference's surface (stack-hg.py has no roofline); bench.py times it on cold buffers of the step's
+ * tensor sizes and on GB-sized ones. */
+int pa_copy_probe(void* dst, const void* src, size_t bytes, void* stream);
 /* Micro-benchmark of ONE convolution launch (tools/bench_conv*.py; no reference counterpart): mode 0 forward, 1 data gradient,
  * 2 weight gradient; variant bits: 1 input transform (BatchNorm+ReLU / BatchNorm backward on load), 2 statistics / masked epilogue,
  * 4 one residual addend, 8 (weight gradient) BatchNorm+ReLU on the x operand, 16: cold protocol is the caller's business.  `ws` =

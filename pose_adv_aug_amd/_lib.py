@@ -77,6 +77,7 @@ _PROTOS = {
     'pa_affine_warp_bilinear_sized': (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
     'pa_transform_pts_sized': (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
     'pa_crop_workspace_bytes': (_sz, [_i, _i, _i, _i]),
+    'pa_crop_design_bytes': (_i, [_i, _i, _i, _i, C.POINTER(C.c_double)]),
     'pa_crop': (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     'pa_flip_lr_nhwc4': (_i, [_vp, _vp, _i, _i, _i, _vp]),
     'pa_flip_tta_merge': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
@@ -129,6 +130,7 @@ _PROTOS = {
     'pa_net_profile_begin': (_i, [_vp]),
     'pa_net_profile_report': (_i, [_vp, C.POINTER(C.c_double), _i, C.POINTER(_i)]),
     'pa_net_design_bytes': (_i, [_vp, C.POINTER(C.c_double)]),
+    'pa_copy_probe': (_i, [_vp, _vp, _sz, _vp]),
     'pa_net_set_fin_prologue': (_i, [_vp, _i]),
     'pa_conv2d_time': (_i, [_i] * 9 + [_vp, C.POINTER(C.c_float), _vp]),
     'pa_net_profile_classes': (_i, [_vp, C.POINTER(C.c_int32), _i]),

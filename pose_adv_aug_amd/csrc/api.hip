@@ -64,6 +64,13 @@ int pa_affine_warp_bilinear_sized(const uint8_t* src, int Hs, int Ws, const int3
     TRY(pa_launch_warp(src, Hs, Ws, sizes, tinv, params, B, res, reinterpret_cast<bf16*>(out4), outf, ST(s))); return 0;
 }
 size_t pa_crop_workspace_bytes(int B, int Hs, int Ws, int res) { return pa_crop_workspace_size(B, Hs, Ws, res); }
+int pa_crop_design_bytes(int B, int Hs, int Ws, int res, double* out) { if (!out) return 1; pa_crop_bytes_bound(B, Hs, Ws, res, out, out + 1); return 0; }
+// calibration kernel of bench.py's floor (elementwise.hip): dst[i] = src[i], 16 bytes per lane, grid-stride over `bytes` (a multiple of 16)
+int pa_copy_probe(void* dst, const void* src, size_t bytes, void* s) {
+    g_err[0] = 0;
+    if (!dst || !src || (bytes & 15)) { pa_set_error_msg("pa_copy_probe: NULL buffer or a size that is not a multiple of 16"); return 1; }
+    TRY(pa_launch_copy16(dst, src, bytes, ST(s))); return 0;
+}
 int pa_crop(const uint8_t* src, int Hs, int Ws, const int32_t* sizes, const double* params, int B, int res, void* workspace,
             void* out4, float* outf, uint8_t* out8, void* s) {
     if (!src || !params || !workspace || B <= 0 || res <= 0) { pa_set_error_msg("pa_crop: bad arguments"); return 1; }

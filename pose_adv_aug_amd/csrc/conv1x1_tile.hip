@@ -18,6 +18,15 @@
 #include "conv_epilogue.h"
 #include <stdlib.h>
 
+// cycle stamps of ONE workgroup (tuning builds, tools/conv1t_clocks.py): PA_CONV1T_DBG = 64 + 256 * <blockIdx.x to stamp>
+PA_STAMP_DECL(pa_conv1t_clk, pa_debug_conv1t_clocks)
+#ifdef PA_TUNING
+#define PA_STAMPT(i) do { if ((a.dbg & 64) && blockIdx.x == (unsigned)(a.dbg >> 8) && blockIdx.y == 0 && threadIdx.x == 0) { \
+        pa_conv1t_clk[2 * (i)] = __builtin_amdgcn_s_memtime(); pa_conv1t_clk[2 * (i) + 1] = wall_clock64(); } } while (0)
+#else
+#define PA_STAMPT(i) do { } while (0)
+#endif
+
 #define PA_GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 #define PA_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 
@@ -42,6 +51,7 @@ __global__ __launch_bounds__(256, (CIN == 128 && BM == 64) ? 3 : 2) void conv1x1
     const int m0 = blockIdx.x * BM;
     const int nb0 = blockIdx.y * nb_per_wg;
     const int nit = nb_per_wg * KT;
+    PA_STAMPT(0);
 
     // ---- weight slices: iteration it -> n-block nb0 + it / KT, k-slice it % KT
     int wrow[NI], wcol[NI];
@@ -82,6 +92,7 @@ __global__ __launch_bounds__(256, (CIN == 128 && BM == 64) ? 3 : 2) void conv1x1
                 ra[u] = *reinterpret_cast<const bf16x8*>(a.in.p + idx);
                 if (LDMODE == PA_LD_LIN2) rq[u] = *reinterpret_cast<const bf16x8*>(a.in.q + idx);
             }
+            if (p0 == 0) PA_STAMPT(1);                // the first batch's loads are issued
 #pragma unroll
             for (int u = 0; u < UN; ++u) {
                 const int row = (p0 + u) * PSTEP + tid / CPP;
@@ -108,8 +119,10 @@ __global__ __launch_bounds__(256, (CIN == 128 && BM == 64) ? 3 : 2) void conv1x1
         }
     }
 
+    PA_STAMPT(2);                                     // transformed and written to LDS (this thread)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    PA_STAMPT(3);
 
     const int frow = lane & 15, fchk = lane >> 4;
     for (int nbi = 0; nbi < nb_per_wg; ++nbi) {
@@ -147,6 +160,7 @@ __global__ __launch_bounds__(256, (CIN == 128 && BM == 64) ? 3 : 2) void conv1x1
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
         }
+        if (nbi == 0) PA_STAMPT(4);                   // K loop of the first channel block
         // the ring half that the last K step read is free now (the other one holds the next block's first slice)
         float* T = reinterpret_cast<float*>(wbuf + ((nbi * KT + KT - 1) & 1) * (BN * 64));
         // BatchNorm-backward epilogue through LDS only for 256 input channels (cold 70 vs 76 us); the 128-channel kernels
@@ -154,12 +168,18 @@ __global__ __launch_bounds__(256, (CIN == 128 && BM == 64) ? 3 : 2) void conv1x1
         pa_conv_epilogue_auto<BN, NI, MI, (CIN == 256 || CTAB), CTAB, 256, (BN < 128)>(a, acc, (nb0 + nbi) * BN, wm, wn,
                                          [&](int wr, int mi, int p) { const int m = m0 + wr * (BM / 2) + mi * 16 + p; return m < M ? m : -1; },
                                          T, (int)blockIdx.x, CTAB ? reinterpret_cast<float4*>(lds + BM * CIN + 2 * BN * 64) : nullptr);
+        if (nbi == 0) PA_STAMPT(5);                   // its epilogue
         __syncthreads();            // T is handed back to the weight ring
     }
+    PA_STAMPT(6);
 }
 
 template <int CIN, int BM, int BN>
-static void launch_row_ld(const PaConvArgs& a, dim3 grid, int nbw, hipStream_t st) {
+static void launch_row_ld(const PaConvArgs& a0, dim3 grid, int nbw, hipStream_t st) {
+    PaConvArgs a = a0;
+    static int dbg = -1;
+    if (dbg < 0) { const char* e = pa_getenv("PA_CONV1T_DBG"); dbg = e ? atoi(e) : 0; }      // tuning builds: cycle stamps
+    a.dbg = dbg;
     switch (a.in.mode) {
         case PA_LD_PLAIN: hipLaunchKernelGGL((conv1x1_tile_kernel<CIN, BM, BN, PA_LD_PLAIN>), grid, dim3(256), 0, st, a, nbw); break;
         case PA_LD_BNRELU: hipLaunchKernelGGL((conv1x1_tile_kernel<CIN, BM, BN, PA_LD_BNRELU>), grid, dim3(256), 0, st, a, nbw); break;

@@ -19,7 +19,10 @@
 #include "common.h"
 #include "kernels.h"
 #include <stdlib.h>
+#include <hip/hip_ext.h>
 
+#define PA_WGRAD_MINPER1_DEFAULT 1
+#define PA_WGRAD_MINPER9_DEFAULT 1
 #define PA_WG_STEM 3          // QMODE of the stem: x is the 4-channel image, gathered as 7x7/2 patches (K = 256)
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
@@ -44,9 +47,20 @@ __device__ __forceinline__ bf16x8 wg_tr_frag(const bf16* tile, int gran, PixFn p
     return __builtin_bit_cast(bf16x8, v);
 }
 
+__device__ __forceinline__ void wg_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // NF/CF: 16-channel fragments per wave along n / c; WNW waves along n (4/WNW along c)
-template <int TAPS, int NF, int CF, int WNW, int PMODE, int QMODE, bool DB>
-__global__ __launch_bounds__(256, 2) void wgrad_tile_kernel(PaWgradArgs a, int ntiles) {
+// PIPE (round 5): a launch is ONE workgroup per CU (<= 256 workgroups: the fp32 slabs grow with the workgroup count), i.e. one wave per
+// SIMD, and a wave that runs alone is the plain sum of its phases: every tile paid the full global-load round trip of its operands
+// (2 - 8 K cycles cold) in front of 1 - 2.3 K cycles of MFMA.  The pipelined form requests tile t+1's 16-byte chunks into registers
+// (all of them at once: with one workgroup per CU the kernel may use 512 registers) right before the MFMA section of tile t, and
+// transforms + writes them to LDS after it; the barriers are LDS-only (s_waitcnt lgkmcnt(0); s_barrier -- __syncthreads() also drains
+// vmcnt, i.e. would wait for the prefetch), the transform constants stay in registers for the whole kernel.  Same sums in the same
+// order as the plain form: bitwise the same slabs.
+// OCC: workgroups per CU the register allocation must leave room for (PIPE only; 1 = up to 512 registers, the CU is this kernel's alone;
+// 2 = at most 256, another queue's workgroup fits beside it)
+template <int TAPS, int NF, int CF, int WNW, int PMODE, int QMODE, bool DB, bool PIPE = false, int OCC = 1>
+__global__ __launch_bounds__(256, PIPE ? OCC : 2) void wgrad_tile_kernel(PaWgradArgs a, int ntiles) {
     constexpr int WCW = 4 / WNW;
     constexpr int NB = 16 * NF * WNW, CB = 16 * CF * WCW;
     // 3x3: 10 x 18 halo pixels, stored with a row pitch of 32 pixels: the swizzle bits (<= bit 3) and the pixel-in-row
@@ -85,6 +99,199 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile_kernel(PaWgradArgs a, int n
 #pragma unroll
             for (int f = 0; f < NF; ++f) acc[t][cf][f] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // the MFMA section of one staged tile (both forms)
+    auto mfma_tile = [&]() {
+        if (TAPS == 9) {
+            // per-lane element offsets for k-step 0 / halo row 0; everything else is a compile-time offset
+            int doff[NF][2], xoff[3][2];
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const int kl = 8 * (lane >> 4) + 4 * hh + ((lane & 15) >> 2);
+#pragma unroll
+                for (int f = 0; f < NF; ++f) doff[f][hh] = kl * NB + (((wn * NF + f) ^ wg_sw<NB>(kl)) << 4) + 4 * (lane & 3);
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    const int col = (kl & 15) + d;                                   // + 1 + dx, dx = d - 1
+                    xoff[d][hh] = ((kl >> 4) * PWL + col) * CB + ((wc ^ wg_sw<CB>(col)) << 4) + 4 * (lane & 3);
+                }
+            }
+            auto tr8 = [&](const bf16* base, int o0, int o1) {
+                s16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + o0));
+                s16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + o1));
+                s16x8 v = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+                return __builtin_bit_cast(bf16x8, v);
+            };
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                bf16x8 fd[NF];
+#pragma unroll
+                for (int f = 0; f < NF; ++f) fd[f] = tr8(dyT + ks * 32 * NB, doff[f][0], doff[f][1]);
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const int row = 2 * ks + 1 + (t / 3 - 1);                        // halo row of the first 16 pixels
+                    bf16x8 fx = tr8(xT + row * PWL * CB, xoff[t % 3][0], xoff[t % 3][1]);
+#pragma unroll
+                    for (int f = 0; f < NF; ++f)
+                        acc[t][0][f] = PA_MFMA_16x16x32(fx, fd[f], acc[t][0][f]);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                bf16x8 fd[NF];
+#pragma unroll
+                for (int f = 0; f < NF; ++f) fd[f] = wg_tr_frag<NB>(dyT, wn * NF + f, [&](int kl) { return 32 * ks + kl; });
+#pragma unroll
+                for (int cf = 0; cf < CF; ++cf) {
+                    bf16x8 fx = wg_tr_frag<CB>(xT, wc * CF + cf, [&](int kl) { return 32 * ks + kl; });
+#pragma unroll
+                    for (int f = 0; f < NF; ++f)
+                        acc[0][cf][f] = PA_MFMA_16x16x32(fx, fd[f], acc[0][cf][f]);
+                }
+            }
+        }
+    };
+
+    if constexpr (PIPE) {
+        constexpr bool LIN2 = PMODE == PA_LD_LIN2, STEM = QMODE == PA_WG_STEM;
+        bf16x8 rp[PASS_N], rq[LIN2 ? PASS_N : 1], rx[STEM ? 1 : PASS_C];
+        bf16x4 rxl[STEM ? PASS_C : 1], rxh[STEM ? PASS_C : 1];          // stem: the two 4-channel input pixels of a patch chunk
+        unsigned lokm = 0, hokm = 0;                                   // ... and which of them lie inside the image (bit u)
+        float pk0[8], pk1[8], pk2[8], qk0[8], qk1[8];
+        if (LIN2) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { pk0[j] = a.dy.k0[n0 + nchunk * 8 + j]; pk1[j] = a.dy.k1[n0 + nchunk * 8 + j]; pk2[j] = a.dy.k2[n0 + nchunk * 8 + j]; }
+        }
+        if (QMODE == PA_LD_BNRELU) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { qk0[j] = a.x.k0[c0 + cchunk * 8 + j]; qk1[j] = a.x.k1[c0 + cchunk * 8 + j]; }
+        }
+        auto coords = [&](int tile, int& b, int& y0, int& x0) {
+            b = y0 = x0 = 0;
+            if (TAPS == 9) { int t = tile; x0 = (t % tiles_x) * 16; t /= tiles_x; y0 = (t % tiles_y) * 8; b = t / tiles_y; }
+        };
+        // request every 16-byte chunk of a tile (clamped, unconditional loads: out-of-range chunks read element 0 and are zeroed at staging)
+        auto request = [&](int tile) {
+            int b, y0, x0; coords(tile, b, y0, x0);
+#pragma unroll
+            for (int u = 0; u < PASS_N; ++u) {
+                const int r = u * (256 / CPN) + tid / CPN;
+                int m; bool ok;
+                if (TAPS == 9) { m = (b * a.H + y0 + (r >> 4)) * a.W + x0 + (r & 15); ok = true; }
+                else { m = tile * 128 + r; ok = m < M; }
+                const size_t idx = ok ? (size_t)m * a.Cout + n0 + nchunk * 8 : 0;
+                rp[u] = *reinterpret_cast<const bf16x8*>(a.dy.p + idx);
+                if (LIN2) rq[u] = *reinterpret_cast<const bf16x8*>(a.dy.q + idx);
+            }
+            if constexpr (STEM) {
+                // 7x7 stride-2 stem (see the plain form below): the thread's pixel of pass 0 by two divisions per TILE, then walked
+                const int m0 = tile * 128 + tid / CPC, HWo = a.H * a.W;
+                int sb = m0 / HWo; const int rem = m0 - sb * HWo; int sy = rem / a.W, sx = rem - sy * a.W;
+                const int chunk = c0 / 8 + cchunk, ky = chunk >> 2, q = chunk & 3;
+                const int Hin = 2 * a.H, Win = 2 * a.W;
+                lokm = hokm = 0;
+#pragma unroll
+                for (int u = 0; u < PASS_C; ++u) {
+                    const int hp = u * (256 / CPC) + tid / CPC;
+                    const bool ok = tile * 128 + hp < M;
+                    const int bb = ok ? sb : 0, y = ok ? sy : 0, x = ok ? sx : 0;
+                    sx += 256 / CPC;                 // the next pass's pixel
+                    while (sx >= a.W) { sx -= a.W; if (++sy >= a.H) { sy = 0; ++sb; } }
+                    const int yi = 2 * y + ky - 3, xi = 2 * x + 2 * q - 3;
+                    const bool rowok = ok && ky < 7 && (unsigned)yi < (unsigned)Hin;
+                    const bool lok = rowok && (unsigned)xi < (unsigned)Win, hok = rowok && (unsigned)(xi + 1) < (unsigned)Win;
+                    const bf16* rowp = a.x.p + ((size_t)bb * Hin + (rowok ? yi : 0)) * Win * 4;
+                    rxl[u] = *reinterpret_cast<const bf16x4*>(rowp + (size_t)(lok ? xi : 0) * 4);          // clamped, unconditional
+                    rxh[u] = *reinterpret_cast<const bf16x4*>(rowp + (size_t)(hok ? xi + 1 : 0) * 4);
+                    lokm |= (lok ? 1u : 0u) << u; hokm |= (hok ? 1u : 0u) << u;
+                }
+            } else {
+#pragma unroll
+            for (int u = 0; u < PASS_C; ++u) {
+                const int hp = u * (256 / CPC) + tid / CPC;
+                int m; bool ok;
+                if (TAPS == 9) {
+                    const int hy = hp / PW, hx = hp - hy * PW;
+                    const int y = y0 + hy - 1, x = x0 + hx - 1;
+                    ok = hp < HP && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
+                    m = (b * a.H + y) * a.W + x;
+                } else { m = tile * 128 + hp; ok = m < M; }
+                const size_t idx = ok ? (size_t)m * a.Cin + c0 + cchunk * 8 : 0;
+                rx[u] = *reinterpret_cast<const bf16x8*>(a.x.p + idx);
+            }
+            }
+        };
+        // transform the requested chunks and write them to the LDS images (the same arithmetic, element for element, as the plain form)
+        auto stage = [&](int tile) {
+            int b, y0, x0; coords(tile, b, y0, x0);
+#pragma unroll
+            for (int u = 0; u < PASS_N; ++u) {
+                const int r = u * (256 / CPN) + tid / CPN;
+                const bool ok = TAPS == 9 ? true : (tile * 128 + r < M);
+                bf16x8 o;
+                if (LIN2) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) o[j] = (bf16)fmaf(pk0[j], (float)rp[u][j], fmaf(pk1[j], (float)rq[u][j], pk2[j]));
+                } else {
+                    o = rp[u];
+                }
+                if (!ok) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) o[j] = (bf16)0.f;
+                }
+                if (DB && want_db) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) colsum[j] += (float)o[j];
+                }
+                *reinterpret_cast<bf16x8*>(dyT + r * NB + (((nchunk >> 1) ^ wg_sw<NB>(r)) << 4) + (nchunk & 1) * 8) = o;
+            }
+            if constexpr (STEM) {
+                const bf16x4 z = {(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
+#pragma unroll
+                for (int u = 0; u < PASS_C; ++u) {
+                    const int hp = u * (256 / CPC) + tid / CPC;
+                    const bf16x4 lo = ((lokm >> u) & 1u) ? rxl[u] : z, hi4 = ((hokm >> u) & 1u) ? rxh[u] : z;
+                    const bf16x8 o = __builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
+                    *reinterpret_cast<bf16x8*>(xT + hp * CB + (((cchunk >> 1) ^ wg_sw<CB>(hp)) << 4) + (cchunk & 1) * 8) = o;
+                }
+            } else {
+#pragma unroll
+            for (int u = 0; u < PASS_C; ++u) {
+                const int hi = u * (256 / CPC) + tid / CPC;
+                bool ok;
+                if (TAPS == 9) {
+                    const int hy = hi / PW, hx = hi - hy * PW;
+                    const int y = y0 + hy - 1, x = x0 + hx - 1;
+                    ok = hi < HP && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
+                } else { ok = tile * 128 + hi < M; }
+                const int hp = TAPS == 9 ? (hi / PW) * PWL + hi % PW : hi;          // pixel index in the LDS image
+                if (hi < HP) {
+                    bf16x8 o;
+                    if (QMODE == PA_LD_BNRELU) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) o[j] = (bf16)fmaxf(fmaf(qk0[j], (float)rx[u][j], qk1[j]), 0.f);
+                    } else {
+                        o = rx[u];
+                    }
+                    if (!ok) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) o[j] = (bf16)0.f;
+                    }
+                    *reinterpret_cast<bf16x8*>(xT + hp * CB + (((cchunk >> 1) ^ wg_sw<CB>(hp)) << 4) + (cchunk & 1) * 8) = o;
+                }
+            }
+            }
+        };
+        if (split < ntiles) request(split);
+        for (int tile = split; tile < ntiles; tile += S) {
+            if (tile != split) wg_lds_barrier();          // the previous tile's fragments have been read
+            stage(tile);                                   // (the compiler's vmcnt waits sit here, behind a whole MFMA section)
+            if (tile + S < ntiles) request(tile + S);      // in flight during this tile's MFMA section
+            __builtin_amdgcn_sched_barrier(0);
+            wg_lds_barrier();
+            mfma_tile();
+        }
+    } else
     for (int tile = split; tile < ntiles; tile += S) {
         int b = 0, y0 = 0, x0 = 0;
         if (TAPS == 9) {
@@ -215,55 +422,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile_kernel(PaWgradArgs a, int n
         }
         __syncthreads();
         // ---- MFMA: 4 steps of 32 pixels
-        if (TAPS == 9) {
-            // per-lane element offsets for k-step 0 / halo row 0; everything else is a compile-time offset
-            int doff[NF][2], xoff[3][2];
-#pragma unroll
-            for (int hh = 0; hh < 2; ++hh) {
-                const int kl = 8 * (lane >> 4) + 4 * hh + ((lane & 15) >> 2);
-#pragma unroll
-                for (int f = 0; f < NF; ++f) doff[f][hh] = kl * NB + (((wn * NF + f) ^ wg_sw<NB>(kl)) << 4) + 4 * (lane & 3);
-#pragma unroll
-                for (int d = 0; d < 3; ++d) {
-                    const int col = (kl & 15) + d;                                   // + 1 + dx, dx = d - 1
-                    xoff[d][hh] = ((kl >> 4) * PWL + col) * CB + ((wc ^ wg_sw<CB>(col)) << 4) + 4 * (lane & 3);
-                }
-            }
-            auto tr8 = [&](const bf16* base, int o0, int o1) {
-                s16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + o0));
-                s16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + o1));
-                s16x8 v = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
-                return __builtin_bit_cast(bf16x8, v);
-            };
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                bf16x8 fd[NF];
-#pragma unroll
-                for (int f = 0; f < NF; ++f) fd[f] = tr8(dyT + ks * 32 * NB, doff[f][0], doff[f][1]);
-#pragma unroll
-                for (int t = 0; t < 9; ++t) {
-                    const int row = 2 * ks + 1 + (t / 3 - 1);                        // halo row of the first 16 pixels
-                    bf16x8 fx = tr8(xT + row * PWL * CB, xoff[t % 3][0], xoff[t % 3][1]);
-#pragma unroll
-                    for (int f = 0; f < NF; ++f)
-                        acc[t][0][f] = PA_MFMA_16x16x32(fx, fd[f], acc[t][0][f]);
-                }
-            }
-        } else {
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                bf16x8 fd[NF];
-#pragma unroll
-                for (int f = 0; f < NF; ++f) fd[f] = wg_tr_frag<NB>(dyT, wn * NF + f, [&](int kl) { return 32 * ks + kl; });
-#pragma unroll
-                for (int cf = 0; cf < CF; ++cf) {
-                    bf16x8 fx = wg_tr_frag<CB>(xT, wc * CF + cf, [&](int kl) { return 32 * ks + kl; });
-#pragma unroll
-                    for (int f = 0; f < NF; ++f)
-                        acc[0][cf][f] = PA_MFMA_16x16x32(fx, fd[f], acc[0][cf][f]);
-                }
-            }
-        }
+        mfma_tile();
     }
 
     // ---- partial slab part[split][n][tap*Cin + c]: D rows = c (4 consecutive per lane), columns = n
@@ -323,9 +482,18 @@ static bool wg_tile_cfg(int B, int H, int W, int Cin, int Cout, int taps, WgTile
     if (s < 1) s = 1;
     if (s > c.ntiles) s = c.ntiles;
     int per = (c.ntiles + s - 1) / s;                // tiles per workgroup
-    static int minper = -1;
-    if (minper < 0) { const char* e = pa_getenv("PA_WGRAD_MINPER"); minper = e ? atoi(e) : 1; }      // experiment: fewer, longer splits (fewer fp32 slabs) at the low-resolution levels
+    // fewer, longer splits: a pipelined workgroup (PIPE above) runs at its MFMA / per-CU load rate from the second tile on, so a launch
+    // of few workgroups with many tiles each takes about as long as one that spreads the same tiles over every CU -- on a fraction of
+    // the CUs and with that fraction of the fp32 slabs (at 32x32 and below the slabs were 3 - 9 x the operand bytes)
+    static int minper1 = -1, minper9 = -1;
+    if (minper1 < 0) {
+        const char* e = pa_getenv("PA_WGRAD_MINPER"); const int both = e ? atoi(e) : 0;
+        e = pa_getenv("PA_WGRAD_MINPER1"); minper1 = e ? atoi(e) : (both ? both : PA_WGRAD_MINPER1_DEFAULT);
+        e = pa_getenv("PA_WGRAD_MINPER9"); minper9 = e ? atoi(e) : (both ? both : PA_WGRAD_MINPER9_DEFAULT);
+    }
+    const int minper = taps == 9 ? minper9 : minper1;
     if (per < minper) per = minper;
+    if (per > c.ntiles) per = c.ntiles;
     c.splits = (c.ntiles + per - 1) / per;           // balanced
     return true;
 }
@@ -335,14 +503,38 @@ int pa_wgrad_tile_splits(int B, int H, int W, int Cin, int Cout, int taps) {
     return wg_tile_cfg(B, H, W, Cin, Cout, taps, c) ? c.splits : 0;
 }
 
-template <int TAPS, int NF, int CF, int WNW>
-static void launch_wt_modes(const PaWgradArgs& a, dim3 grid, int ntiles, hipStream_t st) {
+// Launch flags of the tile weight gradients (hip_ext.h): Net::flush_wgrads sets hipExtAnyOrderLaunch for the 2nd, 3rd ... launch of a
+// group of INDEPENDENT weight gradients behind one event.  Measured on gfx950 / ROCm 7.2 (tools/ubench/anyorder.hip): the flag never
+// overlaps two kernels of a stream, but the next one starts the moment the previous one's last wave ends instead of 3.6 us later (256
+// workgroups) -- the completion signal / cache write-back / acquire round trip between two kernels that share no data.
+static thread_local unsigned g_wt_launch_flags = 0;
+void pa_wgrad_set_launch_flags(unsigned flags) { g_wt_launch_flags = flags; }
+
+template <int TAPS, int NF, int CF, int WNW, bool PIPE, int OCC = 1>
+static void launch_wt_modes2(const PaWgradArgs& a, dim3 grid, int ntiles, hipStream_t st) {
     const bool lin2 = a.dy.mode == PA_LD_LIN2, bnrelu = a.x.mode == PA_LD_BNRELU;
     constexpr bool DB = TAPS == 1;          // bias gradients: only convs without a BatchNorm behind them (all 1x1 here)
-    if (lin2 && bnrelu) hipLaunchKernelGGL((wgrad_tile_kernel<TAPS, NF, CF, WNW, PA_LD_LIN2, PA_LD_BNRELU, DB>), grid, dim3(256), 0, st, a, ntiles);
-    else if (lin2) hipLaunchKernelGGL((wgrad_tile_kernel<TAPS, NF, CF, WNW, PA_LD_LIN2, PA_LD_PLAIN, DB>), grid, dim3(256), 0, st, a, ntiles);
-    else if (bnrelu) hipLaunchKernelGGL((wgrad_tile_kernel<TAPS, NF, CF, WNW, PA_LD_PLAIN, PA_LD_BNRELU, DB>), grid, dim3(256), 0, st, a, ntiles);
-    else hipLaunchKernelGGL((wgrad_tile_kernel<TAPS, NF, CF, WNW, PA_LD_PLAIN, PA_LD_PLAIN, DB>), grid, dim3(256), 0, st, a, ntiles);
+    const unsigned fl = g_wt_launch_flags;
+    auto go = [&](auto kernel) {
+        if (fl) hipExtLaunchKernelGGL(kernel, grid, dim3(256), 0, st, nullptr, nullptr, fl, a, ntiles);
+        else hipLaunchKernelGGL(kernel, grid, dim3(256), 0, st, a, ntiles);
+    };
+    if (lin2 && bnrelu) go(wgrad_tile_kernel<TAPS, NF, CF, WNW, PA_LD_LIN2, PA_LD_BNRELU, DB, PIPE, OCC>);
+    else if (lin2) go(wgrad_tile_kernel<TAPS, NF, CF, WNW, PA_LD_LIN2, PA_LD_PLAIN, DB, PIPE, OCC>);
+    else if (bnrelu) go(wgrad_tile_kernel<TAPS, NF, CF, WNW, PA_LD_PLAIN, PA_LD_BNRELU, DB, PIPE, OCC>);
+    else go(wgrad_tile_kernel<TAPS, NF, CF, WNW, PA_LD_PLAIN, PA_LD_PLAIN, DB, PIPE, OCC>);
+}
+
+// the pipelined form wherever a workgroup walks over at least two tiles (one tile: nothing to prefetch, and the plain form's two
+// workgroups per CU are the better shape for launches with more workgroups than CUs)
+template <int TAPS, int NF, int CF, int WNW>
+static void launch_wt_modes(const PaWgradArgs& a, dim3 grid, int ntiles, hipStream_t st) {
+    static int nopipe = -1, occ = 1;
+    if (nopipe < 0) { nopipe = pa_getenv("PA_WGRAD_NOPIPE") ? 1 : 0; const char* e = pa_getenv("PA_WGRAD_PIPE_OCC"); occ = e ? atoi(e) : 1; }
+    if (!nopipe && ntiles >= 2 * (int)grid.x) {
+        if (occ == 2 && TAPS == 1) launch_wt_modes2<TAPS, NF, CF, WNW, true, TAPS == 1 ? 2 : 1>(a, grid, ntiles, st);      // (the 3x3 form spills at 256 registers)
+        else launch_wt_modes2<TAPS, NF, CF, WNW, true, 1>(a, grid, ntiles, st);
+    } else launch_wt_modes2<TAPS, NF, CF, WNW, false>(a, grid, ntiles, st);
 }
 
 // 7x7/2 stem weight gradient on the tile kernel: NB = 64 output channels x CB = 256 patch elements per workgroup, dy read once
@@ -352,6 +544,13 @@ int pa_launch_stem_wgrad_tile(const PaWgradArgs& a, hipStream_t st) {
     const int M = a.B * a.H * a.W, ntiles = (M + 127) / 128;
     if (off || a.Cin != 256 || a.Cout != 64 || a.splits > ntiles) return -1;
     dim3 grid(a.splits, 1, 1);
+    static int nopipe = -1;
+    if (nopipe < 0) nopipe = (pa_getenv("PA_WGRAD_NOPIPE") || pa_getenv("PA_STEM_NOPIPE")) ? 1 : 0;
+    if (!nopipe && ntiles >= 2 * a.splits) {
+        if (a.dy.mode == PA_LD_LIN2) hipLaunchKernelGGL((wgrad_tile_kernel<1, 2, 8, 2, PA_LD_LIN2, PA_WG_STEM, false, true>), grid, dim3(256), 0, st, a, ntiles);
+        else hipLaunchKernelGGL((wgrad_tile_kernel<1, 2, 8, 2, PA_LD_PLAIN, PA_WG_STEM, false, true>), grid, dim3(256), 0, st, a, ntiles);
+        return (int)hipGetLastError();
+    }
     if (a.dy.mode == PA_LD_LIN2) hipLaunchKernelGGL((wgrad_tile_kernel<1, 2, 8, 2, PA_LD_LIN2, PA_WG_STEM, false>), grid, dim3(256), 0, st, a, ntiles);
     else hipLaunchKernelGGL((wgrad_tile_kernel<1, 2, 8, 2, PA_LD_PLAIN, PA_WG_STEM, false>), grid, dim3(256), 0, st, a, ntiles);
     return (int)hipGetLastError();

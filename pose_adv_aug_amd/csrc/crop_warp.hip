@@ -518,6 +518,17 @@ static CropLayout crop_layout(int B, int Hs, int Ws, int res) {
 
 size_t pa_crop_workspace_size(int B, int Hs, int Ws, int res) { return crop_layout(B, Hs, Ws, res).total; }
 
+// Upper bound of the bytes a pa_launch_crop call moves, from the geometry of its own buffers (bench.py's floor): every stage reads its
+// input image once and writes its output image once at the WORST-CASE window sizes of the layout above (the actual windows depend on
+// the per-sample scale and are smaller; the pre-downscale stages only run for scale * 200 / res >= 2).
+void pa_crop_bytes_bound(int B, int Hs, int Ws, int res, double* rd, double* wr) {
+    const CropLayout L = crop_layout(B, Hs, Ws, res);
+    const double frame3 = (double)Hs * Ws * 3, frame4 = (double)Hs * Ws * 4, t1 = (double)Hs * L.nw_b * 4, d = (double)L.nw_b * L.nw_b * 4,
+                 u = (double)L.cw_max * L.cw_max * 4, t2 = (double)L.cw_max * res * 4, out = (double)res * res * 4 * 2;
+    *rd = B * (frame3 + frame4 + t1 + d + u + t2) + (double)B * 4 * L.axis_max * CW_ENTRY * sizeof(int) * 3;      // (coefficient tables: three passes read them)
+    *wr = B * (frame4 + t1 + d + u + t2 + out) + (double)B * 4 * L.axis_max * CW_ENTRY * sizeof(int);
+}
+
 int pa_launch_crop(const unsigned char* src, int Hs, int Ws, const int* sizes, const double* params, int B, int res, void* workspace,
                    bf16* out4, float* outf, unsigned char* out8, hipStream_t st) {
     const CropLayout L = crop_layout(B, Hs, Ws, res);

@@ -885,6 +885,27 @@ int pa_launch_rmsprop(float* p, const float* g, float* v, size_t n, float lr, fl
     return (int)hipGetLastError();
 }
 
+// plain streaming copy, 16 bytes per lane, 4 independent loads per thread and iteration: what "just moving the bytes" reaches on this
+// part at a given size (bench.py roofline.floor calibrates with it instead of a framework kernel)
+__global__ __launch_bounds__(256) void copy16_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16) {
+    const size_t stride = (size_t)gridDim.x * 256;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 3 * stride < n16; i += 4 * stride) {
+        const uint4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+        dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
+    }
+    for (; i < n16; i += stride) dst[i] = src[i];
+}
+
+int pa_launch_copy16(void* dst, const void* src, size_t bytes, hipStream_t st) {
+    const size_t n16 = bytes / 16;
+    if (n16 == 0) return 0;
+    size_t blocks = (n16 + 1023) / 1024;                 // 4 chunks per thread
+    if (blocks > 256 * 16) blocks = 256 * 16;            // 16 workgroups per CU, grid-stride beyond
+    hipLaunchKernelGGL(copy16_kernel, dim3((unsigned)blocks), dim3(256), 0, st, reinterpret_cast<const uint4*>(src), reinterpret_cast<uint4*>(dst), n16);
+    return (int)hipGetLastError();
+}
+
 int pa_rmsprop_skipped(const int* state, long long* out, hipStream_t st) {
     int h[2] = {0, 0};
 #ifdef PA_FP16

@@ -49,6 +49,7 @@ int pa_wgrad_splits(int M, int H, int W, int Cin, int Cout, int taps);
 int pa_wgrad_tile_splits(int B, int H, int W, int Cin, int Cout, int taps);
 int pa_launch_stem_wgrad_tile(const PaWgradArgs& a, hipStream_t st);   // -1: not handled
 int pa_launch_wgrad_tile(const PaWgradArgs& a, hipStream_t st);
+void pa_wgrad_set_launch_flags(unsigned flags);      // hipExtAnyOrderLaunch for the tile weight gradients launched next by this thread (0 = in-order)
 
 // reduce partial slabs into the fp32 gradient in PyTorch layout  dst[n][c][tap]  (real_cin/real_cout
 // select the un-padded sub-block for the 16-channel head layers)
@@ -95,6 +96,7 @@ int pa_launch_stem_wgrad_reduce(const float* part, int splits, float* dst, hipSt
 
 // ---- optimizer / weight preparation
 int pa_launch_rmsprop(float* p, const float* g, float* v, size_t n, float lr, float alpha, float eps, float gscale, int* state, hipStream_t st);   // state: the optimizer's own {flag, skipped} device pair or NULL (process-wide pair)
+int pa_launch_copy16(void* dst, const void* src, size_t bytes, hipStream_t st);      // plain 16-B/lane streaming copy (bandwidth calibration)
 int pa_rmsprop_skipped(const int* state, long long* out, hipStream_t st);     // half-precision build: steps skipped for a non-finite gradient
 struct PaPrepJob { const float* w; bf16* wf; bf16* wb; int Cout, Cin, taps, pad_cout, pad_cin; };
 int pa_launch_weight_prep(const PaPrepJob* jobs_dev, int njobs, int max_elems, hipStream_t st);

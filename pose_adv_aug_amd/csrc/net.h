@@ -212,6 +212,7 @@ struct Net {
     // at the end of the backward pass (or in front of the next forward pass), so every later reader on the main stream is ordered behind them.
     hipStream_t mstream = nullptr; hipEvent_t ev_mfork = nullptr, ev_meter = nullptr;
     bool meters_async = false, meter_pending = false;
+    bool capturing = false;                     // inside train_step_graph's stream capture
     int meter_stream(hipStream_t* out);         // the stream the meters are launched on now (forks mstream from st when meters_async)
     int meter_done(hipStream_t ms);             // records the join event when ms is the meter stream
     int join_meters();                          // the main stream waits for the pending meters

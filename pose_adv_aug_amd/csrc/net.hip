@@ -501,9 +501,17 @@ int Net::flush_wgrads() {
         PA_CHECK(hipEventRecord(ev, st));
         PA_CHECK(hipStreamWaitEvent(ws, ev, 0));
     }
+    // the launches of a group share no data: from the second on they need no completion / cache round trip behind their predecessor
+    // (hipExtAnyOrderLaunch, conv_wgrad_tile.hip; not with the per-launch event timing, not with one slab shared by all layers)
+    static int any_order = -1;
+    if (any_order < 0) { const char* e = pa_getenv("PA_WGRAD_ANYORDER"); any_order = e ? atoi(e) : 1; }
+    bool first = true;
     for (PendingWgrad& p : pending_wgrads) {
         ProfEntry* pe = prof.begin(p.cls, p.bytes, p.flops, ws);
+        pa_wgrad_set_launch_flags((any_order && !first && !prof.on && !immediate_reduce && !capturing) ? 1u : 0u);
         int rc = p.stem ? pa_launch_stem_wgrad(p.a, ws) : pa_launch_wgrad(p.a, ws);
+        pa_wgrad_set_launch_flags(0u);
+        first = false;
         prof.end(pe, ws);
         if (rc) { pending_wgrads.clear(); return rc; }
         if (immediate_reduce) {            // ONE slab shared by all layers: reduce before the next launch overwrites it
@@ -973,11 +981,13 @@ int Net::train_step_graph(bool train) {
         PA_CHECK(hipStreamCreateWithFlags(&cap, hipStreamNonBlocking));
         st = cap;
         hipError_t e = hipStreamBeginCapture(cap, hipStreamCaptureModeRelaxed);
+        capturing = e == hipSuccess;          // (extension launches -- any-order weight gradients -- stay out of a capture)
         if (e != hipSuccess) { st = caller; (void)hipStreamDestroy(cap); pa_set_error("hipStreamBeginCapture", e, __FILE__, __LINE__); return (int)e; }
         int rc = forward_pose(nullptr, img4, pts_dev, train, nullptr);
         if (!rc) rc = backward_pose();
         hipGraph_t g = nullptr;
         e = hipStreamEndCapture(cap, &g);
+        capturing = false;
         st = caller;
         (void)hipStreamDestroy(cap);
         if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }

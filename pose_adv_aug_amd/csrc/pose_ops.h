@@ -28,5 +28,6 @@ int pa_launch_flip_tta_merge(const float* a, const float* b, float* out, int B, 
 int pa_launch_sample_dropout_masks(const float* logits, int B, int K, int k, unsigned long long seed, unsigned long long step,
                                    const double* uniforms, float* probs, float* masks, int* indexes, hipStream_t st);
 size_t pa_crop_workspace_size(int B, int Hs, int Ws, int res);
+void pa_crop_bytes_bound(int B, int Hs, int Ws, int res, double* rd, double* wr);
 int pa_launch_crop(const unsigned char* src, int Hs, int Ws, const int* sizes, const double* params, int B, int res, void* workspace,
                    bf16* out4, float* outf, unsigned char* out8, hipStream_t st);

@@ -52,6 +52,23 @@ def test_flat_gradient_allreduce_world2():
     assert torch.allclose(p0, pref)
 
 
+def test_flat_gradient_allreduce_world4():
+    """the same exchange typed for N not in {1, 2} (joint-train-pose-s-r-agent.py:62,90 run on 4 / 8 GPUs): 1/4 scaling, replicas
+    identical on every rank, equal to one process stepping on the mean of the four shard gradients"""
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(4, file_init_method(), out), nprocs=4, join=True)
+    assert all(out[r][2] == 0.25 for r in range(4))
+    for r in range(1, 4):
+        assert torch.equal(out[0][0], out[r][0]) and torch.equal(out[0][1], out[r][1]) and torch.equal(out[0][3], out[r][3])
+    ref = sum(torch.randn(1000, generator=torch.Generator().manual_seed(100 + r)) for r in range(4))
+    assert torch.allclose(out[0][1], ref, atol=1e-6)
+    assert torch.equal(out[0][3], torch.zeros(4))                                       # rank 0's buffers everywhere
+    pref = torch.randn(1000, generator=torch.Generator().manual_seed(7))
+    ostep.rmsprop_update(pref, ref * 0.25, torch.zeros(1000), 2.5e-4)
+    assert torch.allclose(out[0][0], pref)
+
+
 def _main_worker(rank, world, init, exp_dir, out):
     """stack_hg.main() -- the REAL host control flow -- on 2 gloo ranks with the engine stubbed at the C ABI."""
     set_env(rank, world, init)

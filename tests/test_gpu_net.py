@@ -249,6 +249,42 @@ def test_c2_size_step_matches_oracle():
     assert a2[0] > 0.3
 
 
+def test_c1_plumbing_config_step_matches_oracle():
+    """BASELINE configs[0] on the HIP path: stack-hg.py's 1-stack hourglass, chan 256, bs = 2, 256x256 (stack-hg.py:40-41 with
+    num_stacks = 1) -- the reference's own CPU-runnable plumbing case, whose shapes no other GPU test visits (B = 2 makes the 4x4
+    level a 32-pixel map at mid-width 128: generic kernels, one or two statistics rows).  One training step against the fp32 oracle
+    on the same weights and inputs: loss 1 %, the head's gradients (out_conv.0, linear.0.1) 5 % / cosine .998, PCK of the engine
+    equal to the oracle's on the engine's maps (1e-4)."""
+    torch.set_num_threads(max(8, torch.get_num_threads()))
+    B, res, chan = 2, 256, 256
+    ref, net = _hg_pair(1, chan, B, res, seed=23)
+    img = t(inputs.images(51, B, res))
+    c, s, r, gpts, norm = inputs.person_meta(52, B)
+    pts = np.stack([opl.transform_pts(gpts[i], c[i], s[i], r[i], 64) for i in range(B)])
+    pts[gpts[..., 0] <= 0] = 0
+    heat = t(inputs.heatmaps_from_pts(pts, res=64))
+    ref.train(); net.train()
+    out_ref, loss_ref = ostep.pose_loss_and_grads(ref, img, heat)
+    loss, outs = net.loss_and_backward(img.cuda(), t(pts).cuda(), want_outputs=True)
+    assert abs(float(loss) - float(loss_ref)) / float(loss_ref) < 1e-2, (float(loss), float(loss_ref))
+    gref = dict(ref.named_parameters())
+    checked = 0
+    for name, g in net.named_grads():
+        if name.startswith('out_conv.0.') or name.startswith('linear.0.1.'):
+            assert rel_rms(g.cpu(), gref[name].grad) < 5e-2 and cosine(g.cpu(), gref[name].grad) > 0.998, name
+            checked += 1
+    assert checked == 4
+    assert bool(torch.isfinite(net.flat_grads).all())
+    idx = [0, 1, 2, 3, 4, 5, 10, 11, 14, 15]
+    om_ = outs[-1].cpu()
+    assert np.allclose(net.accuracy(idx).cpu().numpy(), opl.accuracy(om_, heat, idx).numpy(), atol=1e-4)
+    cT, sT, rT = t(c).float(), t(s).float().view(B, 1), t(r).float().view(B, 1)
+    acc = net.pckh_origin_res(cT.cuda(), t(s).float().cuda(), t(r).float().cuda(), t(gpts).float().cuda(), t(norm).float().cuda())
+    acc = acc[0] if isinstance(acc, (tuple, list)) else acc
+    acc_ref = opl.accuracy_origin_res(om_, cT, sT, [64, 64], t(gpts).float(), t(norm).float(), rT)
+    assert np.allclose(acc.cpu().numpy(), acc_ref.numpy(), atol=1e-4), (acc.cpu().numpy(), acc_ref.numpy())
+
+
 def test_eight_stack_384_config_matches_oracle_loss():
     """SURVEY.md config C5 shape (8-stack, 384x384 -> 96x96 maps; here B=2): map sizes 96, 48, 24, 12, 6 exercise the
     halo-tile kernels (96, 48) AND the generic ones (24, 12, 6: not multiples of 8x16).  Loss vs the fp32 oracle,
@@ -501,17 +537,18 @@ def _blob_dataset(n, res, seed):
     return np.clip(img, 0, 1), pts
 
 
-def test_training_trajectory_tracks_the_oracle_over_150_steps():
+@pytest.mark.parametrize('wseed,dseed', [(23, 5), (29, 6), (31, 7)])
+def test_training_trajectory_tracks_the_oracle_over_150_steps(wseed, dseed):
     """The "PCKh-matching" half of the metric at TRAINING level: a 1-stack hourglass (chan 128, B = 4, 128x128) trained for
     150 RMSprop steps on a small learnable set (colour-coded blobs at the joints), engine (bf16 storage) and fp32 oracle
     from the same weights on the same batches.  Both learn: loss falls by > 3x and PCKh@0.5 in heat-map space
     (Evaluation.accuracy, computed by the ORACLE code on each side's own heat maps of a held-out batch) rises; at the end
-    the two agree: smoothed loss within 15 %, held-out PCKh within 0.12, held-out loss within 20 %."""
+    the two agree on each of three seeds (weights, data): smoothed loss within 9 %, held-out PCKh within 0.10, held-out loss within 17 %."""
     from pose_adv_aug_amd.utils.optim import RMSprop
     torch.set_num_threads(16)
     B, res, chan, steps = 4, 128, 128, 150
-    ref, net = _hg_pair(1, chan, B, res, seed=23)
-    imgs, pts = _blob_dataset(24, res, seed=5)
+    ref, net = _hg_pair(1, chan, B, res, seed=wseed)
+    imgs, pts = _blob_dataset(24, res, seed=dseed)
     heat = inputs.heatmaps_from_pts(pts, res=res // 4)
     opt_ref = ostep.make_optimizer(ref)
     opt = RMSprop(net, lr=2.5e-4, alpha=0.99, eps=1e-8)
@@ -524,7 +561,9 @@ def test_training_trajectory_tracks_the_oracle_over_150_steps():
     assert abs(l_dev[0] - l_ref[0]) / l_ref[0] < 1e-2
     tail = lambda v: float(np.mean(v[-20:]))
     assert tail(l_ref) < l_ref[0] / 3 and tail(l_dev) < l_dev[0] / 3, (l_ref[0], tail(l_ref), l_dev[0], tail(l_dev))
-    assert abs(tail(l_dev) - tail(l_ref)) / tail(l_ref) < 0.05, (tail(l_dev), tail(l_ref))       # observed 0.021 (round 4, three runs: deterministic)
+    # bars = 2 x the spread observed over the three seeds (round 5: tail loss 0.0005 / 0.018 / 0.044, held-out PCKh 0.052 / 0.000 / 0.016,
+    # held-out mse 0.085 / 0.013 / 0.072 relative -- 150 bf16 steps amplify a last-bit difference; one seed's value says little)
+    assert abs(tail(l_dev) - tail(l_ref)) / tail(l_ref) < 0.09, (tail(l_dev), tail(l_ref))
     # held-out batch, eval mode (running statistics of 150 steps), PCKh by the oracle's Evaluation on each side's maps
     sl = slice(20, 24)
     ref.eval(); net.eval()
@@ -537,9 +576,7 @@ def test_training_trajectory_tracks_the_oracle_over_150_steps():
     print('TRAJECTORY observed: tail loss dev %.6g ref %.6g (rel %.4f); held-out PCKh dev %.4f ref %.4f; held-out mse dev %.6g ref %.6g (rel %.4f)'
           % (tail(l_dev), tail(l_ref), abs(tail(l_dev) - tail(l_ref)) / tail(l_ref), a_dev, a_ref, v_dev, v_ref, abs(v_dev - v_ref) / v_ref))
     assert a_ref > 0.2 and a_dev > 0.2, (a_ref, a_dev)
-    # observed with two summation orders of the BatchNorm partial rows (128 / 64 row slices per finalize workgroup): PCKh 0.036 / 0.052,
-    # held-out mse 0.016 / 0.085 -- 150 bf16 steps amplify a last-bit difference, and the engine's mse is the LOWER one both times
-    assert abs(a_dev - a_ref) <= 0.08 and abs(v_dev - v_ref) / v_ref < 0.12, (a_ref, a_dev, v_ref, v_dev)
+    assert abs(a_dev - a_ref) <= 0.10 and abs(v_dev - v_ref) / v_ref < 0.17, (a_ref, a_dev, v_ref, v_dev)
     # ... and the engine's own metric kernel on its own maps says the same as the oracle code on those maps
     assert abs(float(net.accuracy(idx)[0]) - a_dev) < 1e-4
 

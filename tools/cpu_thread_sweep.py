@@ -3,7 +3,7 @@
 host: justifies the thread count bench.py uses (SURVEY.md section 8d asks for the host's cores; PyTorch's CPU convolutions stop scaling
 well before the core count of a GPU host).  Writes profiles-style JSON to stdout.
 
-    python tools/cpu_thread_sweep.py [--threads 16 32 64 128 256] [--bs 8] > gpurun_out/cpu_thread_sweep.json"""
+    python tools/cpu_thread_sweep.py [--threads 4 8 12 16 24 32 64] [--bs 24] > gpurun_out/cpu_thread_sweep.json"""
 import argparse
 import json
 import os
@@ -17,8 +17,8 @@ import torch  # noqa: E402
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--threads', type=int, nargs='+', default=[16, 32, 64, 128, 256])
-    ap.add_argument('--bs', type=int, default=8, help='images per step of the sample (the network is never shrunk)')
+    ap.add_argument('--threads', type=int, nargs='+', default=[4, 8, 12, 16, 24, 32, 64])
+    ap.add_argument('--bs', type=int, default=24, help='images per step of the sample (the network is never shrunk)')
     ap.add_argument('--steps', type=int, default=2)
     args = ap.parse_args()
     from oracle import model as om, step as ostep
