@@ -27,20 +27,27 @@ PA_STAMP_DECL(pa_conv1t_clk, pa_debug_conv1t_clocks)
 #define PA_STAMPT(i) do { } while (0)
 #endif
 
+#define PA_CONV1_K32_DEFAULT 1
 #define PA_GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 #define PA_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 
-template <int CIN, int BM, int BN, int LDMODE>
-__global__ __launch_bounds__(256, (CIN == 128 && BM == 64) ? 3 : 2) void conv1x1_tile_kernel(PaConvArgs a, int nb_per_wg) {
+// KS: channels per weight slice of the ring.  64 (two 32-wide MFMA steps per slice) everywhere but the 256-channel, 64-row instance of
+// round 5 (KS = 32): its LDS is 32 KB of activations + 2 x 8 KB of ring (+ 4 KB table) = 52 KB and its registers <= 168, so that THREE
+// workgroups share a CU like the 128-channel instance's -- these kernels are chains of memory round trips (stage, slices, epilogue) and
+// what a CU moves is proportional to the chains it interleaves (128-channel instance: 5.4 TB/s hot, the two-workgroup 256-channel one 4.0)
+template <int CIN, int BM, int BN, int LDMODE, int KS = 64>
+__global__ __launch_bounds__(256, ((CIN == 128 || KS == 32) && BM == 64) ? 3 : 2) void conv1x1_tile_kernel(PaConvArgs a, int nb_per_wg) {
     constexpr int CPP = CIN / 8;                     // 16-byte chunks per pixel row
     constexpr int NI = BN / 32, MI = BM / 32;
-    constexpr int KT = CIN / 64;
+    constexpr int KT = CIN / KS;
+    constexpr int WRI = 512 / KS;                    // weight rows per LDS-DMA wave instruction (1 KB)
+    constexpr int NIW = (BN / 4) / WRI;              // ... and instructions per wave and slice
     constexpr int PSTEP = 256 / CPP;                 // rows staged per pass
     constexpr int NPASS = BM / PSTEP;
     // ONE shared object: [A tile][2 weight slices]; the epilogue borrows the ring half that was read last
     // 128 input channels + BatchNorm-backward: 4 KB more for the epilogue's constant table (3 workgroups x 52 KB still fit a CU)
-    constexpr bool CTAB = CIN == 128 && BM == 64 && LDMODE == PA_LD_LIN2;
-    __shared__ __attribute__((aligned(16))) bf16 lds[BM * CIN + 2 * BN * 64 + (CTAB ? 2 * BN * 8 : 0)];
+    constexpr bool CTAB = BM == 64 && ((CIN == 128 && LDMODE == PA_LD_LIN2) || KS == 32);      // (the table form is the only BatchNorm-backward epilogue these instances carry)
+    __shared__ __attribute__((aligned(16))) bf16 lds[BM * CIN + 2 * BN * KS + (CTAB ? 2 * BN * 8 : 0)];
     bf16* As = lds;
     bf16* wbuf = lds + BM * CIN;
 
@@ -54,19 +61,21 @@ __global__ __launch_bounds__(256, (CIN == 128 && BM == 64) ? 3 : 2) void conv1x1
     PA_STAMPT(0);
 
     // ---- weight slices: iteration it -> n-block nb0 + it / KT, k-slice it % KT
-    int wrow[NI], wcol[NI];
+    // slot swizzle of a slice row: 128-byte rows (KS = 64): 16-byte slot ^ (row & 7); 64-byte rows (KS = 32): slot ^ 3 * bit 3 of the row --
+    // the four lane groups of a ds_read_b128 (16 rows x one slot per quarter wave) then hit 16 distinct 16-byte bank groups
+    int wrow[NIW], wcol[NIW];
 #pragma unroll
-    for (int i = 0; i < NI; ++i) {
-        const int lr = wave * (BN / 4) + i * 8 + (lane >> 3);
+    for (int i = 0; i < NIW; ++i) {
+        const int lr = wave * (BN / 4) + i * WRI + (KS == 64 ? (lane >> 3) : (lane >> 2));
         wrow[i] = pa_weight_row_of_lds_row<BN, NI>(lr);
-        wcol[i] = ((lane & 7) ^ (lr & 7)) << 3;
+        wcol[i] = KS == 64 ? (((lane & 7) ^ (lr & 7)) << 3) : (((lane & 3) ^ (((lr >> 3) & 1) * 3)) << 3);
     }
     auto issue_w = [&](int it, int buf) {
         const int nb = nb0 + it / KT, kh = it % KT;
 #pragma unroll
-        for (int i = 0; i < NI; ++i)
-            __builtin_amdgcn_global_load_lds(PA_GLOBAL_PTR(a.w + (size_t)(nb * BN + wrow[i]) * CIN + kh * 64 + wcol[i]),
-                                             PA_LDS_PTR(wbuf + buf * (BN * 64) + (wave * (BN / 4) + i * 8) * 64), 16, 0, 0);
+        for (int i = 0; i < NIW; ++i)
+            __builtin_amdgcn_global_load_lds(PA_GLOBAL_PTR(a.w + (size_t)(nb * BN + wrow[i]) * CIN + kh * KS + wcol[i]),
+                                             PA_LDS_PTR(wbuf + buf * (BN * KS) + (wave * (BN / 4) + i * WRI) * KS), 16, 0, 0);
     };
     issue_w(0, 0);
 
@@ -131,15 +140,20 @@ __global__ __launch_bounds__(256, (CIN == 128 && BM == 64) ? 3 : 2) void conv1x1
         for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (KS == 32 && nbi > 0) {                    // (the epilogue of the previous block used the WHOLE ring: this block's first slice starts here)
+            issue_w(nbi * KT, (nbi * KT) & 1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
 #pragma unroll
         for (int kh = 0; kh < KT; ++kh) {
             const int it = nbi * KT + kh;
-            if (it + 1 < nit) issue_w(it + 1, (it + 1) & 1);
-            const bf16* Bs = wbuf + (it & 1) * (BN * 64);
+            if (it + 1 < nit && (KS == 64 || kh + 1 < KT)) issue_w(it + 1, (it + 1) & 1);
+            const bf16* Bs = wbuf + (it & 1) * (BN * KS);
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
+            for (int kk = 0; kk < KS / 32; ++kk) {
                 bf16x8 fa[MI], fw[NI];
-                const int chunk = kh * 8 + kk * 4 + fchk;
+                const int chunk = kh * (KS / 8) + kk * 4 + fchk;
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi) {
                     const int row = wm * (BM / 2) + mi * 16 + frow;
@@ -149,7 +163,8 @@ __global__ __launch_bounds__(256, (CIN == 128 && BM == 64) ? 3 : 2) void conv1x1
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni) {
                     const int row = wn * (BN / 2) + ni * 16 + frow;
-                    fw[ni] = *reinterpret_cast<const bf16x8*>(Bs + row * 64 + (((fchk + 4 * kk) ^ (row & 7)) << 3));
+                    fw[ni] = KS == 64 ? *reinterpret_cast<const bf16x8*>(Bs + row * 64 + (((fchk + 4 * kk) ^ (row & 7)) << 3))
+                                      : *reinterpret_cast<const bf16x8*>(Bs + row * 32 + ((fchk ^ (((row >> 3) & 1) * 3)) << 3));
                 }
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni)
@@ -162,28 +177,31 @@ __global__ __launch_bounds__(256, (CIN == 128 && BM == 64) ? 3 : 2) void conv1x1
         }
         if (nbi == 0) PA_STAMPT(4);                   // K loop of the first channel block
         // the ring half that the last K step read is free now (the other one holds the next block's first slice)
-        float* T = reinterpret_cast<float*>(wbuf + ((nbi * KT + KT - 1) & 1) * (BN * 64));
-        // BatchNorm-backward epilogue through LDS only for 256 input channels (cold 70 vs 76 us); the 128-channel kernels
-        // (3 workgroups per CU, 168 registers) spill with it: 98 vs 70 us
-        pa_conv_epilogue_auto<BN, NI, MI, (CIN == 256 || CTAB), CTAB, 256, (BN < 128)>(a, acc, (nb0 + nbi) * BN, wm, wn,
+        // (KS = 32: a ring half is 8 KB, an epilogue pass of 32 pixel rows x 128 channels needs 16 -- the whole ring, so the next block's
+        // first slice is not requested across the epilogue)
+        float* T = reinterpret_cast<float*>(KS == 32 ? wbuf : wbuf + ((nbi * KT + KT - 1) & 1) * (BN * KS));
+        // BatchNorm-backward epilogue through LDS for 256 input channels (cold 70 vs 76 us) and for 64 (round 5: the 128 x 128 maps of
+        // residual1, where the direct form's 64-byte runs are HALF a pixel row); the 128-channel kernels (3 workgroups per CU,
+        // 168 registers) spill with the plain LDS form (98 vs 70 us) and take the table form (CTAB)
+        pa_conv_epilogue_auto<BN, NI, MI, (CIN == 256 || CIN == 64 || CTAB), CTAB, 256, (BN < 128)>(a, acc, (nb0 + nbi) * BN, wm, wn,
                                          [&](int wr, int mi, int p) { const int m = m0 + wr * (BM / 2) + mi * 16 + p; return m < M ? m : -1; },
-                                         T, (int)blockIdx.x, CTAB ? reinterpret_cast<float4*>(lds + BM * CIN + 2 * BN * 64) : nullptr);
+                                         T, (int)blockIdx.x, CTAB ? reinterpret_cast<float4*>(lds + BM * CIN + 2 * BN * KS) : nullptr);
         if (nbi == 0) PA_STAMPT(5);                   // its epilogue
         __syncthreads();            // T is handed back to the weight ring
     }
     PA_STAMPT(6);
 }
 
-template <int CIN, int BM, int BN>
+template <int CIN, int BM, int BN, int KS = 64>
 static void launch_row_ld(const PaConvArgs& a0, dim3 grid, int nbw, hipStream_t st) {
     PaConvArgs a = a0;
     static int dbg = -1;
     if (dbg < 0) { const char* e = pa_getenv("PA_CONV1T_DBG"); dbg = e ? atoi(e) : 0; }      // tuning builds: cycle stamps
     a.dbg = dbg;
     switch (a.in.mode) {
-        case PA_LD_PLAIN: hipLaunchKernelGGL((conv1x1_tile_kernel<CIN, BM, BN, PA_LD_PLAIN>), grid, dim3(256), 0, st, a, nbw); break;
-        case PA_LD_BNRELU: hipLaunchKernelGGL((conv1x1_tile_kernel<CIN, BM, BN, PA_LD_BNRELU>), grid, dim3(256), 0, st, a, nbw); break;
-        default: hipLaunchKernelGGL((conv1x1_tile_kernel<CIN, BM, BN, PA_LD_LIN2>), grid, dim3(256), 0, st, a, nbw); break;
+        case PA_LD_PLAIN: hipLaunchKernelGGL((conv1x1_tile_kernel<CIN, BM, BN, PA_LD_PLAIN, KS>), grid, dim3(256), 0, st, a, nbw); break;
+        case PA_LD_BNRELU: hipLaunchKernelGGL((conv1x1_tile_kernel<CIN, BM, BN, PA_LD_BNRELU, KS>), grid, dim3(256), 0, st, a, nbw); break;
+        default: hipLaunchKernelGGL((conv1x1_tile_kernel<CIN, BM, BN, PA_LD_LIN2, KS>), grid, dim3(256), 0, st, a, nbw); break;
     }
 }
 
@@ -215,7 +233,11 @@ int pa_launch_conv1x1_tile(const PaConvArgs& a, hipStream_t st, int* stat_rows) 
     const int nb = a.Cout / (bigN ? 128 : 64);
     const int nbw = tiles >= 512 ? nb : 1;          // enough row tiles: loop over the channel blocks inside (input read once)
     dim3 grid(tiles, nb / nbw);
-    if (a.Cin == 256) { if (bigN) launch_row_ld<256, 64, 128>(a, grid, nbw, st); else launch_row_ld<256, 64, 64>(a, grid, nbw, st); }
+    static int k32 = -1;
+    if (k32 < 0) { const char* e = pa_getenv("PA_CONV1_K32"); k32 = e ? atoi(e) : PA_CONV1_K32_DEFAULT; }
+    // 256 channels: the three-workgroup instance (32-channel weight slices) unless the launch needs the direct BatchNorm-backward epilogue
+    const bool three = k32 && bigN && !(a.ep.mode == PA_OUT_BWD && !pa_bwd_epilogue_lds_ok(a));
+    if (a.Cin == 256) { if (bigN && three) launch_row_ld<256, 64, 128, 32>(a, grid, nbw, st); else if (bigN) launch_row_ld<256, 64, 128>(a, grid, nbw, st); else launch_row_ld<256, 64, 64>(a, grid, nbw, st); }
     else if (a.Cin == 128 && bm == 64) { if (bigN) launch_row_ld<128, 64, 128>(a, grid, nbw, st); else launch_row_ld<128, 64, 64>(a, grid, nbw, st); }
     else if (a.Cin == 128) { if (bigN) launch_row_ld<128, 128, 128>(a, grid, nbw, st); else launch_row_ld<128, 128, 64>(a, grid, nbw, st); }
     else { if (bigN) launch_row_ld<64, 128, 128>(a, grid, nbw, st); else launch_row_ld<64, 128, 64>(a, grid, nbw, st); }

@@ -21,6 +21,7 @@
 #include <stdlib.h>
 #include <hip/hip_ext.h>
 
+#define PA_WG_GROUP_DEFAULT 1
 #define PA_WGRAD_MINPER1_DEFAULT 1
 #define PA_WGRAD_MINPER9_DEFAULT 1
 #define PA_WG_STEM 3          // QMODE of the stem: x is the 4-channel image, gathered as 7x7/2 patches (K = 256)
@@ -59,8 +60,14 @@ __device__ __forceinline__ void wg_lds_barrier() { asm volatile("s_waitcnt lgkmc
 // order as the plain form: bitwise the same slabs.
 // OCC: workgroups per CU the register allocation must leave room for (PIPE only; 1 = up to 512 registers, the CU is this kernel's alone;
 // 2 = at most 256, another queue's workgroup fits beside it)
-template <int TAPS, int NF, int CF, int WNW, int PMODE, int QMODE, bool DB, bool PIPE = false, int OCC = 1>
-__global__ __launch_bounds__(256, PIPE ? OCC : 2) void wgrad_tile_kernel(PaWgradArgs a, int ntiles) {
+// LDS elements of an instance: dy tile [128][NB] + x tile / halo image [HPL][CB]
+template <int TAPS, int NF, int CF, int WNW>
+constexpr int wg_lds_elems() { return 128 * (16 * NF * WNW) + (TAPS == 9 ? 10 * 32 : 128) * (16 * CF * (4 / WNW)); }
+
+// The work of ONE workgroup: partial gradient block (by, bz) of split `split` of S (tiles split, split + S, ...).  Called by the
+// one-layer kernel below with its block indices and by the grouped kernel (several layers in one launch) with a decoded job.
+template <int TAPS, int NF, int CF, int WNW, int PMODE, int QMODE, bool DB, bool PIPE>
+__device__ __forceinline__ void wgrad_tile_body(const PaWgradArgs& a, int ntiles, int split, int S, int by, int bz, bf16* lds) {
     constexpr int WCW = 4 / WNW;
     constexpr int NB = 16 * NF * WNW, CB = 16 * CF * WCW;
     // 3x3: 10 x 18 halo pixels, stored with a row pitch of 32 pixels: the swizzle bits (<= bit 3) and the pixel-in-row
@@ -70,15 +77,14 @@ __global__ __launch_bounds__(256, PIPE ? OCC : 2) void wgrad_tile_kernel(PaWgrad
     constexpr int CPN = NB / 8, CPC = CB / 8;                   // 16-byte chunks per row
     constexpr int PASS_N = 128 * CPN / 256;                     // dy chunks per thread
     constexpr int PASS_C = (HP * CPC + 255) / 256;              // x chunks per thread
-    __shared__ __attribute__((aligned(16))) bf16 lds[128 * NB + HPL * CB];
+    static_assert(128 * NB + HPL * CB == wg_lds_elems<TAPS, NF, CF, WNW>(), "LDS size");
     bf16* dyT = lds;
     bf16* xT = lds + 128 * NB;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wave % WNW, wc = wave / WNW;
-    const int split = blockIdx.x, S = gridDim.x;
-    const int n0 = blockIdx.y * NB, c0 = blockIdx.z * CB;
+    const int n0 = by * NB, c0 = bz * CB;
     const int M = a.B * a.H * a.W;
     const int tiles_x = TAPS == 9 ? a.W / 16 : 1, tiles_y = TAPS == 9 ? a.H / 8 : 1;
     const int Kfull = TAPS * a.Cin;
@@ -86,7 +92,7 @@ __global__ __launch_bounds__(256, PIPE ? OCC : 2) void wgrad_tile_kernel(PaWgrad
     // a thread always handles the same channel chunk; its transform constants are re-read per tile
     // (L1 hits) so that they are not live across the MFMA section
     const int nchunk = tid % CPN, cchunk = tid % CPC;
-    const bool want_db = DB && a.dbpart != nullptr && blockIdx.z == 0;
+    const bool want_db = DB && a.dbpart != nullptr && bz == 0;
     float colsum[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) colsum[j] = 0.f;
@@ -454,6 +460,39 @@ __global__ __launch_bounds__(256, PIPE ? OCC : 2) void wgrad_tile_kernel(PaWgrad
     }
 }
 
+// one layer per launch: grid (splits, n-blocks, c-blocks)
+template <int TAPS, int NF, int CF, int WNW, int PMODE, int QMODE, bool DB, bool PIPE = false, int OCC = 1>
+__global__ __launch_bounds__(256, PIPE ? OCC : 2) void wgrad_tile_kernel(PaWgradArgs a, int ntiles) {
+    __shared__ __attribute__((aligned(16))) bf16 lds[wg_lds_elems<TAPS, NF, CF, WNW>()];
+    wgrad_tile_body<TAPS, NF, CF, WNW, PMODE, QMODE, DB, PIPE>(a, ntiles, (int)blockIdx.x, (int)gridDim.x, (int)blockIdx.y, (int)blockIdx.z, lds);
+}
+
+// The three weight gradients of a residual block (reference models/asn_stacked_hg.py:17-24: conv3 1x1, conv2 3x3, conv1 1x1) in ONE
+// launch: job 0 = conv2 (3x3, plain dz2 x BatchNorm+ReLU(x1)), job 1 = conv3 (1x1, plain dz3 x BatchNorm+ReLU(x2)), job 2 = conv1
+// (1x1, BatchNorm-backward(x1.grad, x1) x BatchNorm+ReLU(in)).  A pipelined workgroup keeps its CU busy from the second tile on, so the
+// three layers run SIDE BY SIDE on a share of the CUs each with few, long splits -- a third of the fp32 slabs of three chip-wide
+// launches one after the other, and the launch is as long as its longest job instead of the sum of three.
+struct PaWgradGroup {
+    PaWgradArgs a[3];
+    int ntiles[3], S[3], ny[3];
+    int begin[4];              // first workgroup of job j (begin[3] = grid size)
+};
+
+// P9 / P3: how conv2's / conv3's dy operand arrives -- PA_LD_PLAIN where the data gradient stored the BatchNorm-backward gradient (dz2 /
+// dz3: the 64x64 and 32x32 row-tile / halo-tile kernels), PA_LD_LIN2 where it did not (the low-resolution variants)
+template <bool PIPE, int P9, int P3>
+__global__ __launch_bounds__(256, PIPE ? 1 : 2) void wgrad_group_kernel(PaWgradGroup g) {
+    constexpr int L9 = wg_lds_elems<9, 4, 1, 1>(), L1 = wg_lds_elems<1, 4, 4, 2>();
+    __shared__ __attribute__((aligned(16))) bf16 lds[L9 > L1 ? L9 : L1];
+    const int id = (int)blockIdx.x;
+    const int j = id < g.begin[1] ? 0 : (id < g.begin[2] ? 1 : 2);
+    const int local = id - g.begin[j];
+    const int S = g.S[j], split = local % S, rest = local / S, by = rest % g.ny[j], bz = rest / g.ny[j];
+    if (j == 0) wgrad_tile_body<9, 4, 1, 1, P9, PA_LD_BNRELU, false, PIPE>(g.a[0], g.ntiles[0], split, S, by, bz, lds);
+    else if (j == 1) wgrad_tile_body<1, 4, 4, 2, P3, PA_LD_BNRELU, true, PIPE>(g.a[1], g.ntiles[1], split, S, by, bz, lds);
+    else wgrad_tile_body<1, 4, 4, 2, PA_LD_LIN2, PA_LD_BNRELU, true, PIPE>(g.a[2], g.ntiles[2], split, S, by, bz, lds);
+}
+
 // ------------------------------------------------------------------------------------------------ host side
 struct WgTileCfg { int nb, cb, ntiles, splits; };
 
@@ -544,9 +583,12 @@ int pa_launch_stem_wgrad_tile(const PaWgradArgs& a, hipStream_t st) {
     const int M = a.B * a.H * a.W, ntiles = (M + 127) / 128;
     if (off || a.Cin != 256 || a.Cout != 64 || a.splits > ntiles) return -1;
     dim3 grid(a.splits, 1, 1);
-    static int nopipe = -1;
-    if (nopipe < 0) nopipe = (pa_getenv("PA_WGRAD_NOPIPE") || pa_getenv("PA_STEM_NOPIPE")) ? 1 : 0;
-    if (!nopipe && ntiles >= 2 * a.splits) {
+    // the pipelined form needs the CU to itself (297 registers): with the stem's 512 splits that is two rounds of workgroups, 95 us
+    // against 45 us for the plain form at two workgroups per CU (measured in the step, where this launch is the tail everything waits
+    // for); it pays at <= 256 splits only
+    static int pipe = -1;
+    if (pipe < 0) { const char* e = pa_getenv("PA_STEM_PIPE"); pipe = e ? atoi(e) : 0; if (pa_getenv("PA_WGRAD_NOPIPE")) pipe = 0; }
+    if (pipe && ntiles >= 2 * a.splits) {
         if (a.dy.mode == PA_LD_LIN2) hipLaunchKernelGGL((wgrad_tile_kernel<1, 2, 8, 2, PA_LD_LIN2, PA_WG_STEM, false, true>), grid, dim3(256), 0, st, a, ntiles);
         else hipLaunchKernelGGL((wgrad_tile_kernel<1, 2, 8, 2, PA_LD_PLAIN, PA_WG_STEM, false, true>), grid, dim3(256), 0, st, a, ntiles);
         return (int)hipGetLastError();
@@ -559,13 +601,89 @@ int pa_launch_stem_wgrad_tile(const PaWgradArgs& a, hipStream_t st) {
 // returns -1 when the shape is not handled here (caller falls back to conv_wgrad.hip)
 int pa_launch_wgrad_tile(const PaWgradArgs& a, hipStream_t st) {
     WgTileCfg c;
-    if (!wg_tile_cfg(a.B, a.H, a.W, a.Cin, a.Cout, a.taps, c) || c.splits != a.splits) return -1;
+    if (!wg_tile_cfg(a.B, a.H, a.W, a.Cin, a.Cout, a.taps, c) || a.splits < 1 || a.splits > c.ntiles) return -1;
     if (a.taps == 9 && a.dbpart) return -1;
+    c.splits = a.splits;                 // (the layer's slab was laid out for this count: wg_tile_cfg's own, or the grouped policy's)
     dim3 grid(c.splits, a.Cout / c.nb, a.Cin / c.cb);
     if (a.taps == 9) launch_wt_modes<9, 4, 1, 1>(a, grid, c.ntiles, st);
     else if (c.nb == 128 && c.cb == 128) launch_wt_modes<1, 4, 4, 2>(a, grid, c.ntiles, st);
     else if (c.nb == 128) launch_wt_modes<1, 4, 2, 2>(a, grid, c.ntiles, st);
     else if (c.cb == 128) launch_wt_modes<1, 2, 4, 2>(a, grid, c.ntiles, st);
     else launch_wt_modes<1, 2, 2, 2>(a, grid, c.ntiles, st);
+    return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ grouped launch
+// split counts of a residual block whose three weight gradients share one launch (0 = the block is not eligible): conv2 3x3 mid -> mid,
+// conv3 1x1 mid -> cout, conv1 1x1 cin -> mid
+static int wg_group_on() {
+    static int on = -1;
+    if (on < 0) { const char* e = pa_getenv("PA_WG_GROUP"); on = e ? atoi(e) : PA_WG_GROUP_DEFAULT; }
+    return on;
+}
+
+bool pa_wgrad_group_splits(int B, int H, int W, int cin, int mid, int cout, int* s9, int* s3, int* s1) {
+    if (!wg_group_on()) return false;
+    WgTileCfg c9, c3, c1;
+    if (!wg_tile_cfg(B, H, W, mid, mid, 9, c9) || !wg_tile_cfg(B, H, W, mid, cout, 1, c3) || !wg_tile_cfg(B, H, W, cin, mid, 1, c1)) return false;
+    if (c9.nb != 64 || c9.cb != 64 || c3.nb != 128 || c3.cb != 128 || c1.nb != 128 || c1.cb != 128) return false;      // the grouped kernel's three instances
+    static int gs9 = -1, gs1 = -1, mp9 = -1, mp1 = -1;
+    if (gs9 < 0) {
+        const char* e = pa_getenv("PA_WG_GROUP_S9"); gs9 = e ? atoi(e) : 32;
+        e = pa_getenv("PA_WG_GROUP_S1"); gs1 = e ? atoi(e) : 96;
+        e = pa_getenv("PA_WG_GROUP_MINPER9"); mp9 = e ? atoi(e) : 4;
+        e = pa_getenv("PA_WG_GROUP_MINPER1"); mp1 = e ? atoi(e) : 2;
+    }
+    auto pick = [](int ntiles, int want, int minper) {
+        int s = want;
+        if (s * minper > ntiles) s = ntiles / minper;
+        if (s < 1) s = 1;
+        const int per = (ntiles + s - 1) / s;
+        return (ntiles + per - 1) / per;             // balanced
+    };
+    *s9 = pick(c9.ntiles, gs9, mp9);
+    *s3 = pick(c3.ntiles, gs1, mp1);
+    *s1 = pick(c1.ntiles, gs1, mp1);
+    return true;
+}
+
+// returns -1 when the three launches do not form a group this kernel takes (the caller launches them one by one)
+int pa_launch_wgrad_group(const PaWgradArgs& a9, const PaWgradArgs& a3, const PaWgradArgs& a1, hipStream_t st) {
+    if (!wg_group_on()) return -1;
+    if (a9.taps != 9 || a3.taps != 1 || a1.taps != 1 || a9.dbpart) return -1;
+    if ((a9.dy.mode != PA_LD_PLAIN && a9.dy.mode != PA_LD_LIN2) || a9.x.mode != PA_LD_BNRELU || (a3.dy.mode != PA_LD_PLAIN && a3.dy.mode != PA_LD_LIN2) ||
+        a3.x.mode != PA_LD_BNRELU || a1.dy.mode != PA_LD_LIN2 || a1.x.mode != PA_LD_BNRELU) return -1;
+    WgTileCfg c9, c3, c1;
+    if (!wg_tile_cfg(a9.B, a9.H, a9.W, a9.Cin, a9.Cout, 9, c9) || !wg_tile_cfg(a3.B, a3.H, a3.W, a3.Cin, a3.Cout, 1, c3) ||
+        !wg_tile_cfg(a1.B, a1.H, a1.W, a1.Cin, a1.Cout, 1, c1)) return -1;
+    if (c9.nb != 64 || c9.cb != 64 || c3.nb != 128 || c3.cb != 128 || c1.nb != 128 || c1.cb != 128) return -1;
+    if (a9.splits < 1 || a9.splits > c9.ntiles || a3.splits < 1 || a3.splits > c3.ntiles || a1.splits < 1 || a1.splits > c1.ntiles) return -1;
+    PaWgradGroup g;
+    const PaWgradArgs* as[3] = {&a9, &a3, &a1};
+    const WgTileCfg* cs[3] = {&c9, &c3, &c1};
+    int begin = 0;
+    for (int j = 0; j < 3; ++j) {
+        g.a[j] = *as[j]; g.ntiles[j] = cs[j]->ntiles; g.S[j] = as[j]->splits; g.ny[j] = as[j]->Cout / cs[j]->nb;
+        g.begin[j] = begin;
+        begin += as[j]->splits * (as[j]->Cout / cs[j]->nb) * (as[j]->Cin / cs[j]->cb);
+    }
+    g.begin[3] = begin;
+    static int pipe = -1;
+    // plain (two workgroups per CU, <= 242 registers) rather than pipelined bodies: 6.27 vs 6.31 ms per step -- a pipelined workgroup
+    // owns its CU's registers, and the main chain's kernels then find no room beside the group
+    if (pipe < 0) { const char* e = pa_getenv("PA_WG_GROUP_PIPE"); pipe = e ? atoi(e) : 0; }
+    const bool l9 = a9.dy.mode == PA_LD_LIN2, l3 = a3.dy.mode == PA_LD_LIN2;
+    auto go = [&](auto kernel) { hipLaunchKernelGGL(kernel, dim3(begin), dim3(256), 0, st, g); };
+    if (pipe) {
+        if (!l9 && !l3) go(wgrad_group_kernel<true, PA_LD_PLAIN, PA_LD_PLAIN>);
+        else if (!l9) go(wgrad_group_kernel<true, PA_LD_PLAIN, PA_LD_LIN2>);
+        else if (!l3) go(wgrad_group_kernel<true, PA_LD_LIN2, PA_LD_PLAIN>);
+        else go(wgrad_group_kernel<true, PA_LD_LIN2, PA_LD_LIN2>);
+    } else {
+        if (!l9 && !l3) go(wgrad_group_kernel<false, PA_LD_PLAIN, PA_LD_PLAIN>);
+        else if (!l9) go(wgrad_group_kernel<false, PA_LD_PLAIN, PA_LD_LIN2>);
+        else if (!l3) go(wgrad_group_kernel<false, PA_LD_LIN2, PA_LD_PLAIN>);
+        else go(wgrad_group_kernel<false, PA_LD_LIN2, PA_LD_LIN2>);
+    }
     return (int)hipGetLastError();
 }

@@ -13,8 +13,8 @@ L.pa_conv2d_time.argtypes = [C.c_int] * 9 + [C.c_void_p, C.POINTER(C.c_float), C
 ws = torch.zeros(4 << 30, dtype=torch.uint8, device='cuda')
 names = ['entry', 'loads issued', 'staged', 'barrier', 'K loop 0', 'epilogue 0', 'end']
 for mode, mname in ((0, 'fwd'), (1, 'dgrad')):
-    for cin, cout in ((256, 128), (128, 256)):
-        for H in (64, 32):
+    for cin, cout, Hs in ((256, 128, (64, 32)), (128, 256, (64, 32)), (64, 64, (128,)), (64, 128, (128,))):
+        for H in Hs:
             for variant in ((0, 3, 7) if mode == 0 else (0, 3, 7)):
                 for cold in (0, 16):
                     ms = C.c_float()

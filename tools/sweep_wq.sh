@@ -7,7 +7,7 @@ import json, sys
 l = [l for l in sys.stdin if l.startswith('{')]
 print(json.loads(l[0])['ms_per_step'] if l else 'FAILED')"; }
 T=$GRAFT_REPO_ROOT/tune
-run() { echo -n "$*: "; (cd $T; env "$@" bash -c "$(declare -f one); one"); }
+run() { echo -n "$*: "; (cd $T; env $@ bash -c "$(declare -f one); one"); }
 base() { echo -n "round-4 tree: "; (cd $GRAFT_REPO_ROOT/ab_base; one); }
 base; run X=0
 for kv in "$@"; do run $kv; done
