@@ -28,6 +28,7 @@ PA_STAMP_DECL(pa_conv1t_clk, pa_debug_conv1t_clocks)
 #endif
 
 #define PA_CONV1_K32_DEFAULT 1
+#define PA_CONV1_C64_BM64_DEFAULT 1
 #define PA_GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 #define PA_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 
@@ -36,7 +37,7 @@ PA_STAMP_DECL(pa_conv1t_clk, pa_debug_conv1t_clocks)
 // workgroups share a CU like the 128-channel instance's -- these kernels are chains of memory round trips (stage, slices, epilogue) and
 // what a CU moves is proportional to the chains it interleaves (128-channel instance: 5.4 TB/s hot, the two-workgroup 256-channel one 4.0)
 template <int CIN, int BM, int BN, int LDMODE, int KS = 64>
-__global__ __launch_bounds__(256, ((CIN == 128 || KS == 32) && BM == 64) ? 3 : 2) void conv1x1_tile_kernel(PaConvArgs a, int nb_per_wg) {
+__global__ __launch_bounds__(256, (((CIN == 128 || KS == 32) && BM == 64) || (CIN == 64 && (BN == 64 || BM == 64))) ? 3 : 2) void conv1x1_tile_kernel(PaConvArgs a, int nb_per_wg) {
     constexpr int CPP = CIN / 8;                     // 16-byte chunks per pixel row
     constexpr int NI = BN / 32, MI = BM / 32;
     constexpr int KT = CIN / KS;
@@ -46,7 +47,9 @@ __global__ __launch_bounds__(256, ((CIN == 128 || KS == 32) && BM == 64) ? 3 : 2
     constexpr int NPASS = BM / PSTEP;
     // ONE shared object: [A tile][2 weight slices]; the epilogue borrows the ring half that was read last
     // 128 input channels + BatchNorm-backward: 4 KB more for the epilogue's constant table (3 workgroups x 52 KB still fit a CU)
-    constexpr bool CTAB = BM == 64 && ((CIN == 128 && LDMODE == PA_LD_LIN2) || KS == 32);      // (the table form is the only BatchNorm-backward epilogue these instances carry)
+    // (the table form is the only BatchNorm-backward epilogue these instances carry; 64 input channels -- the 128 x 128 maps of residual1:
+    // 64 output channels in 128-row tiles or 128 in 64-row tiles, three workgroups per CU either way)
+    constexpr bool CTAB = (BM == 64 && ((CIN == 128 && LDMODE == PA_LD_LIN2) || KS == 32)) || (CIN == 64 && (BN == 64 || BM == 64));
     __shared__ __attribute__((aligned(16))) bf16 lds[BM * CIN + 2 * BN * KS + (CTAB ? 2 * BN * 8 : 0)];
     bf16* As = lds;
     bf16* wbuf = lds + BM * CIN;
@@ -217,6 +220,8 @@ bool pa_conv1x1_tile_supported(const PaConvArgs& a) {
     if (a.taps != 1 || (a.Cin != 64 && a.Cin != 128 && a.Cin != 256) || a.Cout % 64 != 0) return false;
     const int M = a.B * a.H * a.W;
     if ((size_t)M * (size_t)(a.Cin > a.Cout ? a.Cin : a.Cout) >= ((size_t)1 << 31)) return false;      // 32-bit element offsets in the epilogue
+    // (64 -> 64 channels: every instance carries the table form of the BatchNorm-backward epilogue only)
+    if (a.Cin == 64 && a.Cout % 128 != 0 && a.ep.mode == PA_OUT_BWD && !pa_bwd_epilogue_lds_ok(a)) return false;
     return (M + row_bm(a.Cin) - 1) / row_bm(a.Cin) >= 192;          // smaller problems: generic kernel with 64x64 tiles
 }
 
@@ -224,6 +229,10 @@ int pa_launch_conv1x1_tile(const PaConvArgs& a, hipStream_t st, int* stat_rows) 
     if (!pa_conv1x1_tile_supported(a)) { pa_set_error_msg("pa_launch_conv1x1_tile: unsupported shape"); return 1; }
     const int M = a.B * a.H * a.W;
     int bm = row_bm(a.Cin);
+    // 64 input channels, 128 output channels: 64-row tiles at three workgroups per CU (the 128-row instance spills at 168 registers)
+    static int c64bm = -1;
+    if (c64bm < 0) { const char* e = pa_getenv("PA_CONV1_C64_BM64"); c64bm = e ? atoi(e) : PA_CONV1_C64_BM64_DEFAULT; }
+    if (a.Cin == 64 && a.Cout % 128 == 0 && c64bm && !(a.ep.mode == PA_OUT_BWD && !pa_bwd_epilogue_lds_ok(a))) bm = 64;
     // the 64-row, 128-channel BatchNorm-backward instance (3 workgroups per CU) has the LDS epilogue only
     if (a.Cin == 128 && bm == 64 && a.in.mode == PA_LD_LIN2 && a.ep.mode == PA_OUT_BWD && !pa_bwd_epilogue_lds_ok(a)) bm = 128;
     const int tiles = (M + bm - 1) / bm;
@@ -240,6 +249,7 @@ int pa_launch_conv1x1_tile(const PaConvArgs& a, hipStream_t st, int* stat_rows) 
     if (a.Cin == 256) { if (bigN && three) launch_row_ld<256, 64, 128, 32>(a, grid, nbw, st); else if (bigN) launch_row_ld<256, 64, 128>(a, grid, nbw, st); else launch_row_ld<256, 64, 64>(a, grid, nbw, st); }
     else if (a.Cin == 128 && bm == 64) { if (bigN) launch_row_ld<128, 64, 128>(a, grid, nbw, st); else launch_row_ld<128, 64, 64>(a, grid, nbw, st); }
     else if (a.Cin == 128) { if (bigN) launch_row_ld<128, 128, 128>(a, grid, nbw, st); else launch_row_ld<128, 128, 64>(a, grid, nbw, st); }
+    else if (bm == 64) launch_row_ld<64, 64, 128>(a, grid, nbw, st);
     else { if (bigN) launch_row_ld<64, 128, 128>(a, grid, nbw, st); else launch_row_ld<64, 128, 64>(a, grid, nbw, st); }
     return (int)hipGetLastError();
 }

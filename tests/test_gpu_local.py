@@ -14,6 +14,8 @@ Tolerances: forward rel-rms 1e-2 (one op's worth of bf16 rounding, 2^-9 ~ 2e-3, 
 renormalisation); gradients rel-rms 4e-2 / cosine 0.999 (gradient tensors are stored in bf16 too)."""
 import ctypes as C
 
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -51,9 +53,39 @@ class Probe(object):
         return self.get(name, 1)
 
 
+_ALL = []          # every comparison of the running test (POSEADV_TEST_VERBOSE=1 prints the ones nearest their tolerance)
+
+
+_SAMPLES = [None]  # (batch, top map size) of the running test: lets _close see how many pixels a BatchNorm of the named node averages over
+
+
+def _few_samples(what):
+    """True for gradients of the 8 x 8 / 4 x 4 levels when they hold fewer than 256 pixels per channel (B = 2: 128 / 32).  There ONE
+    element whose pre-activation rounds to the other side of zero in bf16 (the engine masks on its stored bf16 tensor, the oracle's
+    emulation on its own) moves a channel's BatchNorm sums by ~1 / sqrt(n) of their size, and everything behind the BatchNorm backward
+    with it: observed over six weight seeds 0.5 - 3 % at the higher levels but up to 10 % (one seed in six, either tiling of the stem) at
+    the 32-pixel level -- the bar there is 3 x the usual one."""
+    import re
+    if _SAMPLES[0] is None:
+        return False
+    B, top = _SAMPLES[0]
+    m = re.search(r'(down|up|skip|pool|merge)(\d)', what)
+    if m:
+        k = int(m.group(2))
+        size = top >> (k - 1 if m.group(1) in ('skip', 'merge') else k)
+    elif 'neck' in what:
+        size = top >> 4
+    else:
+        return False
+    return B * size * size < 256
+
+
 def _close(errs, what, got, ref, tol, cos=None):
     e = rel_rms(got, ref)
     c = cosine(got, ref)
+    if cos is not None and _few_samples(what):
+        tol, cos = 3 * tol, 1 - 9 * (1 - cos)
+    _ALL.append((e / tol, what, round(e, 4), round(c, 5)))
     if not (e < tol and (cos is None or c > cos)):
         errs.append((what, round(e, 4), round(c, 5)))
 
@@ -68,7 +100,8 @@ def test_every_node_of_the_training_graph_matches_locally():
     torch.set_num_threads(8)
     bf16_emul.ROUND_GRADS = True        # the engine stages gradient operands in bf16 (standard mixed precision)
     stacks, B, res, chan = 2, 2, 256, 128
-    ref, net = _hg_pair(stacks, chan, B, res, seed=7)
+    _SAMPLES[0] = (B, res // 4)
+    ref, net = _hg_pair(stacks, chan, B, res, seed=int(os.environ.get('POSEADV_TEST_SEED', '7')))
     img = t(inputs.images(8, B, res))
     pts = inputs.heat_pts(9, B, res=res // 4)
     heat_t = t(inputs.heatmaps_from_pts(pts, res=res // 4))
@@ -187,6 +220,10 @@ def test_every_node_of_the_training_graph_matches_locally():
         # the stack input: skip1 + pool1 (+ identity into the next stack's input)
         total = contrib['xin%d' % i] + (a_x.grad if inner else 0)
         node_grad('xin%d' % i, total, pending_bn=(i == 0))
+    if os.environ.get('POSEADV_TEST_VERBOSE'):
+        print('NEAREST THE TOLERANCE:', sorted(_ALL, reverse=True)[:8])
+    del _ALL[:]
+    _SAMPLES[0] = None
     assert not errs, '%d local mismatches, first: %s' % (len(errs), errs[:15])
 
 
@@ -230,6 +267,10 @@ def test_blocks_of_every_resolution_match_locally_at_the_benchmark_size():
             inner = tap[out_name + k]
             _close(errs, 'dz ' + out_name + k, P.grad(out_name + k), inner.grad * (inner.detach() > 0).float(), GRAD_TOL, GRAD_COS)
     assert sizes == [64, 32, 16, 8, 4]
+    if os.environ.get('POSEADV_TEST_VERBOSE'):
+        print('NEAREST THE TOLERANCE:', sorted(_ALL, reverse=True)[:8])
+    del _ALL[:]
+    _SAMPLES[0] = None
     assert not errs, '%d local mismatches, first: %s' % (len(errs), errs[:15])
 
 
@@ -294,6 +335,10 @@ def test_stem_second_stack_and_head_layers_match_locally_at_the_benchmark_size()
                 continue
             _close(errs, 'grad ' + prefix + n, hip_grads[prefix + n], p.grad, GRAD_TOL, GRAD_COS)
     _close(errs, 'node-grad post0', P.grad('post0'), a_post.grad * (P.act('post0') > 0).float(), GRAD_TOL, GRAD_COS)
+    if os.environ.get('POSEADV_TEST_VERBOSE'):
+        print('NEAREST THE TOLERANCE:', sorted(_ALL, reverse=True)[:8])
+    del _ALL[:]
+    _SAMPLES[0] = None
     assert not errs, '%d local mismatches, first: %s' % (len(errs), errs[:15])
 
 
