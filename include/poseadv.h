@@ -237,6 +237,10 @@ int pa_hg_bucket_wait(pa_net* net, int stack, void* stream);
  * own input buffers first (the graph's pointers are fixed).  Not available while dropout masks are set or the launch
  * profiler runs.  The gradient lands in the bound flat array; loss_per_stack (device, [num_stacks]) may be NULL. */
 int pa_hg_train_step(pa_net* net, const void* img4, const double* pts, int train, int use_graph, float* loss_per_stack);
+/* total_dev (device float, or NULL = off): every later pa_hg_forward / pa_hg_train_step that is given `pts` also writes
+ * sum_stacks loss there -- `loss = sum(criterion(o, target))` of stack-hg.py:156-159 as one device scalar, so that the caller needs no
+ * reduction launch of its own between the backward pass and the optimizer. */
+int pa_hg_set_loss_total(pa_net* net, float* total_dev);
 
 /* Half-hourglass forward (models/asn_stacked_hg.py:300-304 with is_half_hg): stem + the down path of
  * hg[0] up to the neck -- everything the agent reads.  train != 0 updates the BatchNorm running

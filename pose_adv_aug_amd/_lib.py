@@ -119,6 +119,7 @@ _PROTOS = {
     'pa_hg_bucket_range': (_i, [_vp, _i, C.POINTER(_sz), C.POINTER(_sz)]),
     'pa_hg_bucket_wait': (_i, [_vp, _i, _vp]),
     'pa_hg_train_step': (_i, [_vp, _vp, _vp, _i, _i, _vp]),
+    'pa_hg_set_loss_total': (_i, [_vp, _vp]),
     'pa_hg_accuracy': (_i, [_vp, _i, _vp, _i, _vp, _vp]),
     'pa_hg_forward_half': (_i, [_vp, _vp, _vp, _i]),
     'pa_asn_forward': (_i, [_vp, _vp, _i, _vp, _vp]),

@@ -533,9 +533,15 @@ int pa_hg_train_step(pa_net* net, const void* img4, const double* pts, int train
     if (img4 != n.img4) PA_CHECK(hipMemcpyAsync(n.img4, img4, (size_t)n.B * n.res * n.res * 4 * sizeof(bf16), hipMemcpyDeviceToDevice, n.st));
     if (pts != n.pts_dev) PA_CHECK(hipMemcpyAsync(n.pts_dev, pts, (size_t)n.B * n.classes * 2 * sizeof(double), hipMemcpyDeviceToDevice, n.st));
     TRY(n.train_step_graph(train != 0));
-    if (loss_per_stack) PA_CHECK(hipMemcpyAsync(loss_per_stack, n.loss_dev, n.stacks * sizeof(float), hipMemcpyDeviceToDevice, n.st));
+    if (loss_per_stack) PA_CHECK(hipMemcpyAsync(loss_per_stack, n.loss_keep, n.stacks * sizeof(float), hipMemcpyDeviceToDevice, n.st));
+    if (n.loss_total_out) PA_CHECK(hipMemcpyAsync(n.loss_total_out, n.loss_keep + n.stacks, sizeof(float), hipMemcpyDeviceToDevice, n.st));
     return 0;
 }
+
+// total_dev: a device float that every later pa_hg_forward / pa_hg_train_step with `pts` also writes the SUM of the per-stack losses to
+// (NULL: off).  The reference sums them on the host side of autograd (stack-hg.py:156-159); here the caller gets the scalar without a
+// reduction launch of its own between the backward pass and the optimizer.
+int pa_hg_set_loss_total(pa_net* net, float* total_dev) { g_err[0] = 0; net->n.loss_total_out = total_dev; net->n.release_graph(); return 0; }
 
 int pa_hg_accuracy(pa_net* net, int stack, const int32_t* idxs, int nidx, float* acc, float* scratch) {
     g_err[0] = 0;

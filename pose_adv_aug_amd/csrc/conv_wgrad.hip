@@ -357,9 +357,10 @@ int pa_launch_wgrad_reduce(const PaWgradReduceJob* jobs_dev, int njobs, int max_
 
 // one workgroup per output channel n: 1024 threads = 256 patch elements k (coalesced 1 KB rows) x 4 slices of the
 // split range, LDS tree over the slices, scatter into dst[n][c][ky][kx]
-__global__ __launch_bounds__(1024) void stem_wgrad_reduce_kernel(const float* part, int splits, float* dst) {
+__global__ __launch_bounds__(1024) void stem_wgrad_reduce_kernel(const float* part, int splits, float* dst, float* zero64) {
     __shared__ float red[4][256];
     const int n = blockIdx.x, k = threadIdx.x & 255, sl = threadIdx.x >> 8;
+    if (zero64 && n == 0 && threadIdx.x < 64) zero64[threadIdx.x] = 0.f;          // the stem's bias gradient (a BatchNorm follows: exactly zero) -- was a 6 us memset launch at the very end of the step
     const float* src = part + (size_t)n * 256 + k;
     float s = 0.f;
 #pragma unroll 8
@@ -372,7 +373,7 @@ __global__ __launch_bounds__(1024) void stem_wgrad_reduce_kernel(const float* pa
     }
 }
 
-int pa_launch_stem_wgrad_reduce(const float* part, int splits, float* dst, hipStream_t st) {
-    hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3(64), dim3(1024), 0, st, part, splits, dst);
+int pa_launch_stem_wgrad_reduce(const float* part, int splits, float* dst, hipStream_t st, float* zero64) {
+    hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3(64), dim3(1024), 0, st, part, splits, dst, zero64);
     return (int)hipGetLastError();
 }

@@ -479,18 +479,21 @@ struct PaWgradGroup {
 };
 
 // P9 / P3: how conv2's / conv3's dy operand arrives -- PA_LD_PLAIN where the data gradient stored the BatchNorm-backward gradient (dz2 /
-// dz3: the 64x64 and 32x32 row-tile / halo-tile kernels), PA_LD_LIN2 where it did not (the low-resolution variants)
-template <bool PIPE, int P9, int P3>
-__global__ __launch_bounds__(256, PIPE ? 1 : 2) void wgrad_group_kernel(PaWgradGroup g) {
+// dz3: the 64x64 and 32x32 row-tile / halo-tile kernels), PA_LD_LIN2 where it did not (the low-resolution variants); Q1: conv1's x operand
+// -- the block input with its BatchNorm+ReLU pending (the previous block's x3) or a plain tensor (pooled / merged maps).
+// Plain (two workgroups per CU, <= 242 registers) rather than pipelined bodies: 6.27 vs 6.31 ms per step -- a pipelined workgroup owns its
+// CU's registers, and the main chain's kernels then find no room beside the group.
+template <int P9, int P3, int Q1>
+__global__ __launch_bounds__(256, 2) void wgrad_group_kernel(PaWgradGroup g) {
     constexpr int L9 = wg_lds_elems<9, 4, 1, 1>(), L1 = wg_lds_elems<1, 4, 4, 2>();
     __shared__ __attribute__((aligned(16))) bf16 lds[L9 > L1 ? L9 : L1];
     const int id = (int)blockIdx.x;
     const int j = id < g.begin[1] ? 0 : (id < g.begin[2] ? 1 : 2);
     const int local = id - g.begin[j];
     const int S = g.S[j], split = local % S, rest = local / S, by = rest % g.ny[j], bz = rest / g.ny[j];
-    if (j == 0) wgrad_tile_body<9, 4, 1, 1, P9, PA_LD_BNRELU, false, PIPE>(g.a[0], g.ntiles[0], split, S, by, bz, lds);
-    else if (j == 1) wgrad_tile_body<1, 4, 4, 2, P3, PA_LD_BNRELU, true, PIPE>(g.a[1], g.ntiles[1], split, S, by, bz, lds);
-    else wgrad_tile_body<1, 4, 4, 2, PA_LD_LIN2, PA_LD_BNRELU, true, PIPE>(g.a[2], g.ntiles[2], split, S, by, bz, lds);
+    if (j == 0) wgrad_tile_body<9, 4, 1, 1, P9, PA_LD_BNRELU, false, false>(g.a[0], g.ntiles[0], split, S, by, bz, lds);
+    else if (j == 1) wgrad_tile_body<1, 4, 4, 2, P3, PA_LD_BNRELU, true, false>(g.a[1], g.ntiles[1], split, S, by, bz, lds);
+    else wgrad_tile_body<1, 4, 4, 2, PA_LD_LIN2, Q1, true, false>(g.a[2], g.ntiles[2], split, S, by, bz, lds);
 }
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -629,10 +632,10 @@ bool pa_wgrad_group_splits(int B, int H, int W, int cin, int mid, int cout, int*
     if (c9.nb != 64 || c9.cb != 64 || c3.nb != 128 || c3.cb != 128 || c1.nb != 128 || c1.cb != 128) return false;      // the grouped kernel's three instances
     static int gs9 = -1, gs1 = -1, mp9 = -1, mp1 = -1;
     if (gs9 < 0) {
-        const char* e = pa_getenv("PA_WG_GROUP_S9"); gs9 = e ? atoi(e) : 32;
-        e = pa_getenv("PA_WG_GROUP_S1"); gs1 = e ? atoi(e) : 96;
+        const char* e = pa_getenv("PA_WG_GROUP_S9"); gs9 = e ? atoi(e) : 24;
+        e = pa_getenv("PA_WG_GROUP_S1"); gs1 = e ? atoi(e) : 64;
         e = pa_getenv("PA_WG_GROUP_MINPER9"); mp9 = e ? atoi(e) : 4;
-        e = pa_getenv("PA_WG_GROUP_MINPER1"); mp1 = e ? atoi(e) : 2;
+        e = pa_getenv("PA_WG_GROUP_MINPER1"); mp1 = e ? atoi(e) : 4;
     }
     auto pick = [](int ntiles, int want, int minper) {
         int s = want;
@@ -652,7 +655,7 @@ int pa_launch_wgrad_group(const PaWgradArgs& a9, const PaWgradArgs& a3, const Pa
     if (!wg_group_on()) return -1;
     if (a9.taps != 9 || a3.taps != 1 || a1.taps != 1 || a9.dbpart) return -1;
     if ((a9.dy.mode != PA_LD_PLAIN && a9.dy.mode != PA_LD_LIN2) || a9.x.mode != PA_LD_BNRELU || (a3.dy.mode != PA_LD_PLAIN && a3.dy.mode != PA_LD_LIN2) ||
-        a3.x.mode != PA_LD_BNRELU || a1.dy.mode != PA_LD_LIN2 || a1.x.mode != PA_LD_BNRELU) return -1;
+        a3.x.mode != PA_LD_BNRELU || a1.dy.mode != PA_LD_LIN2 || (a1.x.mode != PA_LD_BNRELU && a1.x.mode != PA_LD_PLAIN)) return -1;
     WgTileCfg c9, c3, c1;
     if (!wg_tile_cfg(a9.B, a9.H, a9.W, a9.Cin, a9.Cout, 9, c9) || !wg_tile_cfg(a3.B, a3.H, a3.W, a3.Cin, a3.Cout, 1, c3) ||
         !wg_tile_cfg(a1.B, a1.H, a1.W, a1.Cin, a1.Cout, 1, c1)) return -1;
@@ -668,22 +671,18 @@ int pa_launch_wgrad_group(const PaWgradArgs& a9, const PaWgradArgs& a3, const Pa
         begin += as[j]->splits * (as[j]->Cout / cs[j]->nb) * (as[j]->Cin / cs[j]->cb);
     }
     g.begin[3] = begin;
-    static int pipe = -1;
-    // plain (two workgroups per CU, <= 242 registers) rather than pipelined bodies: 6.27 vs 6.31 ms per step -- a pipelined workgroup
-    // owns its CU's registers, and the main chain's kernels then find no room beside the group
-    if (pipe < 0) { const char* e = pa_getenv("PA_WG_GROUP_PIPE"); pipe = e ? atoi(e) : 0; }
-    const bool l9 = a9.dy.mode == PA_LD_LIN2, l3 = a3.dy.mode == PA_LD_LIN2;
+    const bool l9 = a9.dy.mode == PA_LD_LIN2, l3 = a3.dy.mode == PA_LD_LIN2, q1 = a1.x.mode == PA_LD_BNRELU;
     auto go = [&](auto kernel) { hipLaunchKernelGGL(kernel, dim3(begin), dim3(256), 0, st, g); };
-    if (pipe) {
-        if (!l9 && !l3) go(wgrad_group_kernel<true, PA_LD_PLAIN, PA_LD_PLAIN>);
-        else if (!l9) go(wgrad_group_kernel<true, PA_LD_PLAIN, PA_LD_LIN2>);
-        else if (!l3) go(wgrad_group_kernel<true, PA_LD_LIN2, PA_LD_PLAIN>);
-        else go(wgrad_group_kernel<true, PA_LD_LIN2, PA_LD_LIN2>);
+    if (q1) {
+        if (!l9 && !l3) go(wgrad_group_kernel<PA_LD_PLAIN, PA_LD_PLAIN, PA_LD_BNRELU>);
+        else if (!l9) go(wgrad_group_kernel<PA_LD_PLAIN, PA_LD_LIN2, PA_LD_BNRELU>);
+        else if (!l3) go(wgrad_group_kernel<PA_LD_LIN2, PA_LD_PLAIN, PA_LD_BNRELU>);
+        else go(wgrad_group_kernel<PA_LD_LIN2, PA_LD_LIN2, PA_LD_BNRELU>);
     } else {
-        if (!l9 && !l3) go(wgrad_group_kernel<false, PA_LD_PLAIN, PA_LD_PLAIN>);
-        else if (!l9) go(wgrad_group_kernel<false, PA_LD_PLAIN, PA_LD_LIN2>);
-        else if (!l3) go(wgrad_group_kernel<false, PA_LD_LIN2, PA_LD_PLAIN>);
-        else go(wgrad_group_kernel<false, PA_LD_LIN2, PA_LD_LIN2>);
+        if (!l9 && !l3) go(wgrad_group_kernel<PA_LD_PLAIN, PA_LD_PLAIN, PA_LD_PLAIN>);
+        else if (!l9) go(wgrad_group_kernel<PA_LD_PLAIN, PA_LD_LIN2, PA_LD_PLAIN>);
+        else if (!l3) go(wgrad_group_kernel<PA_LD_LIN2, PA_LD_PLAIN, PA_LD_PLAIN>);
+        else go(wgrad_group_kernel<PA_LD_LIN2, PA_LD_LIN2, PA_LD_PLAIN>);
     }
     return (int)hipGetLastError();
 }

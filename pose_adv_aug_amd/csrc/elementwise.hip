@@ -1119,6 +1119,23 @@ int pa_launch_cell_mask(const PaOperand& x, const float* mask, const PaEpilogue&
     return (int)hipGetLastError();
 }
 
+// end of a pose forward pass: hand the per-stack losses out (keep: the engine's own copy [n + 1]; out: the caller's [n], may be NULL), their
+// sum (keep[n], *total -- the reference's `loss = sum over stacks`, stack-hg.py:156-159, without a framework reduction kernel between the
+// backward pass and the optimizer) and clear the accumulators for the next pass (was a memset launch in front of every step)
+__global__ void loss_out_kernel(float* acc, float* keep, float* out, float* total, int n) {
+    if (threadIdx.x == 0) {
+        float s = 0.f;
+        for (int i = 0; i < n; ++i) { const float v = acc[i]; s += v; keep[i] = v; if (out) out[i] = v; acc[i] = 0.f; }
+        keep[n] = s;
+        if (total) *total = s;
+    }
+}
+
+int pa_launch_loss_out(float* acc, float* keep, float* out, float* total, int n, hipStream_t st) {
+    hipLaunchKernelGGL(loss_out_kernel, dim3(1), dim3(64), 0, st, acc, keep, out, total, n);
+    return (int)hipGetLastError();
+}
+
 __global__ void fill_kernel(float* p, float v, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
 }

@@ -95,10 +95,11 @@ int pa_launch_upadd_bwd(const bf16* dout, const PaEpilogue& ep_low, bf16* dlow, 
 int pa_launch_stem_conv(const PaConvArgs& a, hipStream_t st, int* stat_rows = nullptr);
 int pa_launch_stem_wgrad(const PaWgradArgs& a, hipStream_t st);
 // reduce the stem's partial slabs [splits][64][256] into PyTorch layout dst[64][3][7][7]
-int pa_launch_stem_wgrad_reduce(const float* part, int splits, float* dst, hipStream_t st);
+int pa_launch_stem_wgrad_reduce(const float* part, int splits, float* dst, hipStream_t st, float* zero64 = nullptr);      // zero64: 64 floats the launch also clears (the stem's bias gradient)
 
 // ---- optimizer / weight preparation
 int pa_launch_rmsprop(float* p, const float* g, float* v, size_t n, float lr, float alpha, float eps, float gscale, int* state, hipStream_t st);   // state: the optimizer's own {flag, skipped} device pair or NULL (process-wide pair)
+int pa_launch_loss_out(float* acc, float* keep, float* out, float* total, int n, hipStream_t st);      // per-stack losses + their sum out, accumulators cleared
 int pa_launch_copy16(void* dst, const void* src, size_t bytes, hipStream_t st);      // plain 16-B/lane streaming copy (bandwidth calibration)
 int pa_rmsprop_skipped(const int* state, long long* out, hipStream_t st);     // half-precision build: steps skipped for a non-finite gradient
 struct PaPrepJob { const float* w; bf16* wf; bf16* wb; int Cout, Cin, taps, pad_cout, pad_cin; };

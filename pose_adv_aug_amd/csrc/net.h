@@ -132,7 +132,10 @@ struct Net {
     size_t workspace_bytes = 0;
     float *stats_arena = nullptr;
     size_t stats_arena_floats = 0;
-    float* loss_dev = nullptr;                 // [stacks] per-stack loss, part of the stats arena
+    float* loss_dev = nullptr;                 // [stacks] per-stack loss accumulators (atomics of head_fwd), part of the stats arena
+    float* loss_keep = nullptr;                // [stacks + 1] the last pose forward pass's losses and their sum (loss_out_kernel)
+    float* loss_total_out = nullptr;           // caller's device float that also receives the sum (pa_hg_set_loss_total), or NULL
+    bool loss_self_clearing = false;           // pose nets: the accumulators are cleared by loss_out_kernel, begin_step() skips its memset
     // device job tables
     PaPrepJob* prep_jobs = nullptr; int n_prep = 0, prep_max = 0;
     PaWgradReduceJob* red_jobs = nullptr; int n_red = 0, red_max = 0;

@@ -14,6 +14,7 @@ static int ablate() { static int v = -1; if (v < 0) { const char* e = pa_getenv(
 // bits 128 / 256 / 512: forward convolutions + finalize / data gradients + backward finalize / weight gradients of maps up to
 // PA_ABLATE_H (default 8) pixels high are skipped: what the low-resolution stretch costs the step at most (wrong results)
 static int ablate_h() { static int v = -1; if (v < 0) { const char* e = pa_getenv("PA_ABLATE_H"); v = e ? atoi(e) : 8; } return v; }
+#define PA_STEM_ON_MAIN_DEFAULT 0
 #define TRY(x) do { int _r = (x); if (_r) return _r; } while (0)
 
 PaOperand pa_plain(const bf16* p) { PaOperand o; o.p = p; o.q = nullptr; o.k0 = o.k1 = o.k2 = nullptr; o.mode = PA_LD_PLAIN; return o; }
@@ -201,6 +202,8 @@ size_t Net::layout_all(char* base) {
     a.take(0);
     stats_arena = base ? reinterpret_cast<float*>(base + zero_begin) : nullptr;
     stats_arena_floats = (a.off - zero_begin) / sizeof(float);
+    loss_keep = a.get<float>(64);
+    loss_self_clearing = true;                 // (the workspace is zero-filled when it is bound: the first pass starts from zero too)
     // job tables
     prep_jobs = a.get<PaPrepJob>(convs.size());
     red_jobs = a.get<PaWgradReduceJob>(convs.size());
@@ -467,7 +470,11 @@ int Net::conv_wgrad(ConvLayer& c, const PaOperand& dy, const PaOperand& x, int B
     if ((ablate() & 512) && H <= ablate_h()) return 0;
     { const double M = (double)B_ * H * W, slab = 4.0 * (double)c.splits * a.Cout * a.taps * a.Cin;      // slabs written, read back by the reducer, gradient written
       cnt((c.k == 7 ? 2.0 * B_ * 4.0 * H * W * 4 : opb(x, M * a.Cin)) + opb(dy, M * a.Cout) + slab, slab + 4.0 * a.Cout * a.taps * a.Cin); }
-    if (multi_stream && wstream) {        // deferred: flush_wgrads() launches it on the weight-gradient stream
+    static int stem_main = -1;
+    if (stem_main < 0) { const char* e = pa_getenv("PA_STEM_ON_MAIN"); stem_main = e ? atoi(e) : PA_STEM_ON_MAIN_DEFAULT; }
+    // (the stem's weight gradient is the last launch of the step: on the main stream, idle by then, it runs beside the weight-gradient
+    // queue's last reduction instead of behind it)
+    if (multi_stream && wstream && !(c.k == 7 && stem_main && reduce_early && !immediate_reduce)) {        // deferred: flush_wgrads() launches it on the weight-gradient stream
         PendingWgrad p; p.a = a; p.cls = cls; p.bytes = wb; p.flops = wf; p.stem = c.k == 7; p.c = &c; p.grp = c.group_splits > 0 ? grp : nullptr; p.role = role;
         pending_wgrads.push_back(p);
         return 0;
@@ -476,10 +483,13 @@ int Net::conv_wgrad(ConvLayer& c, const PaOperand& dy, const PaOperand& x, int B
     int rc = (c.k == 7) ? pa_launch_stem_wgrad(a, st) : pa_launch_wgrad(a, st);
     prof.end(pe, st);
     if (rc) return rc;
+    if (c.k == 7 && multi_stream && wstream && stem_main && reduce_early && !immediate_reduce) {
+        TRY(pa_launch_stem_wgrad_reduce(c.part, c.splits, grads + c.p_w, st, grads + c.p_b));
+        return 0;
+    }
     if (immediate_reduce) {
         if (c.k == 7) {
-            TRY(pa_launch_stem_wgrad_reduce(c.part, c.splits, grads + c.p_w, st));
-            PA_CHECK(hipMemsetAsync(grads + c.p_b, 0, 64 * sizeof(float), st));
+            TRY(pa_launch_stem_wgrad_reduce(c.part, c.splits, grads + c.p_w, st, grads + c.p_b));
         } else {
             TRY(pa_launch_wgrad_reduce(red_jobs + c.red_index, 1, c.Cout * c.Cin * c.taps() + c.Cout, st));
         }
@@ -532,8 +542,7 @@ int Net::flush_wgrads() {
         if (rc) { pending_wgrads.clear(); return rc; }
         if (immediate_reduce) {            // ONE slab shared by all layers: reduce before the next launch overwrites it
             if (p.stem) {
-                TRY(pa_launch_stem_wgrad_reduce(p.c->part, p.c->splits, grads + p.c->p_w, ws));
-                PA_CHECK(hipMemsetAsync(grads + p.c->p_b, 0, 64 * sizeof(float), ws));
+                TRY(pa_launch_stem_wgrad_reduce(p.c->part, p.c->splits, grads + p.c->p_w, ws, grads + p.c->p_b));
             } else {
                 TRY(pa_launch_wgrad_reduce(red_jobs + p.c->red_index, 1, p.c->Cout * p.c->Cin * p.c->taps() + p.c->Cout, ws));
             }
@@ -543,8 +552,7 @@ int Net::flush_wgrads() {
         int lo = 1 << 30, hi = -1, cnt = 0, mx = 0;
         for (PendingWgrad& p : pending_wgrads) {
             if (p.stem) {
-                TRY(pa_launch_stem_wgrad_reduce(p.c->part, p.c->splits, grads + p.c->p_w, ws));
-                PA_CHECK(hipMemsetAsync(grads + p.c->p_b, 0, 64 * sizeof(float), ws));
+                TRY(pa_launch_stem_wgrad_reduce(p.c->part, p.c->splits, grads + p.c->p_w, ws, grads + p.c->p_b));
                 continue;
             }
             const int ri = p.c->red_index, el = p.c->Cout * p.c->Cin * p.c->taps() + p.c->Cout;
@@ -827,7 +835,7 @@ int Net::prepare_weights() { return pa_launch_weight_prep(prep_jobs, n_prep, pre
 
 int Net::begin_step() {
     dbytes_rd = dbytes_wr = 0;
-    PA_CHECK(hipMemsetAsync(stats_arena, 0, stats_arena_floats * sizeof(float), st));
+    if (!loss_self_clearing) PA_CHECK(hipMemsetAsync(stats_arena, 0, stats_arena_floats * sizeof(float), st));
     return 0;
 }
 
@@ -898,7 +906,7 @@ int Net::forward_pose(const float* img_nchw, const bf16* img4_in, const double* 
             TRY(conv_fwd(inc[i], pa_plain(heat64[i]), B, Hh, Hh, pa_plain(forth_tmp[i]), pa_none(), xin[i + 1].raw, nullptr));
         }
     }
-    if (loss_out_dev) PA_CHECK(hipMemcpyAsync(loss_out_dev, loss_dev, stacks * sizeof(float), hipMemcpyDeviceToDevice, st));
+    if (pts) TRY(pa_launch_loss_out(loss_dev, loss_keep, loss_out_dev, loss_total_out, stacks, st));
     return 0;
 }
 
@@ -1039,8 +1047,7 @@ int Net::reduce_grads() {
     if (immediate_reduce) return 0;             // every layer was reduced right after its weight-gradient launch
     TRY(pa_launch_wgrad_reduce(red_jobs, n_red, red_max, st));
     if (!is_agent) {
-        TRY(pa_launch_stem_wgrad_reduce(stem_conv.part, stem_conv.splits, grads + stem_conv.p_w, st));
-        PA_CHECK(hipMemsetAsync(grads + stem_conv.p_b, 0, 64 * sizeof(float), st));
+        TRY(pa_launch_stem_wgrad_reduce(stem_conv.part, stem_conv.splits, grads + stem_conv.p_w, st, grads + stem_conv.p_b));
     }
     return 0;
 }

@@ -247,6 +247,12 @@ class HourglassNet(_HipModule):
         p = pts.to(torch.float64).contiguous() if pts is not None else None
         losses = torch.empty(self.num_stacks, dtype=torch.float32, device=self.flat_params.device) if pts is not None else None   # (fully overwritten)
         keep = self._set_masks(h, dropout_masks)
+        # the sum over the stacks comes from the engine (pa_hg_set_loss_total): one of 16 rotating device floats, valid until 16 calls later
+        if getattr(self, '_loss_ring', None) is None:
+            self._loss_ring, self._loss_slot = torch.zeros(16, dtype=torch.float32, device=self.flat_params.device), 0
+        self._loss_slot = (self._loss_slot + 1) % 16
+        total = self._loss_ring[self._loss_slot:self._loss_slot + 1]
+        check(lib().pa_hg_set_loss_total(h, ptr(total)), 'pa_hg_set_loss_total')
         try:
             check(lib().pa_hg_forward(h, ptr(x.contiguous().float()) if x is not None else None, ptr(img4), ptr(p),
                                       1 if self.training else 0, ptr(losses)), 'pa_hg_forward')
@@ -291,6 +297,12 @@ class HourglassNet(_HipModule):
                 self._nbt += 1
             return losses.sum(), (self.heatmaps(B) if want_outputs else None)
         keep = self._set_masks(h, dropout_masks)
+        # the sum over the stacks comes from the engine (pa_hg_set_loss_total): one of 16 rotating device floats, valid until 16 calls later
+        if getattr(self, '_loss_ring', None) is None:
+            self._loss_ring, self._loss_slot = torch.zeros(16, dtype=torch.float32, device=self.flat_params.device), 0
+        self._loss_slot = (self._loss_slot + 1) % 16
+        total = self._loss_ring[self._loss_slot:self._loss_slot + 1]
+        check(lib().pa_hg_set_loss_total(h, ptr(total)), 'pa_hg_set_loss_total')
         try:
             check(lib().pa_hg_forward(h, ptr(x.contiguous().float()) if x is not None else None, ptr(img4), ptr(p),
                                       1 if self.training else 0, ptr(losses)), 'pa_hg_forward')
@@ -313,6 +325,7 @@ class HourglassNet(_HipModule):
             self._meter_keep = None                             # (the backward pass has enqueued the join: later users of these blocks are ordered behind the meters)
             outs = self.heatmaps(B) if want_outputs else None
         finally:
+            lib().pa_hg_set_loss_total(h, None)
             if keep is not None:
                 self._set_masks(h, None)
             if getattr(self, '_meter_keep', None) is not None:
@@ -320,7 +333,7 @@ class HourglassNet(_HipModule):
                 # buffers go back to the allocator, and stop collecting (later accuracy() calls would grow the list for ever).
                 torch.cuda.synchronize()
                 self._meter_keep = None
-        return losses.sum(), outs
+        return total.view(()), outs
 
     def accuracy(self, idxs, stack=-1):
         """Evaluation.accuracy (pylib/Evaluation.py:54-75) of the last forward's heat maps against the
