@@ -19,11 +19,13 @@
 #include "common.h"
 #include "kernels.h"
 #include <stdlib.h>
+#include <string.h>
 #include <hip/hip_ext.h>
 
 #define PA_WG_GROUP_DEFAULT 1
 #define PA_WGRAD_MINPER1_DEFAULT 1
 #define PA_WGRAD_MINPER9_DEFAULT 1
+#define PA_WG_RT 7            // PMODE / QMODE "decided at run time from the operand" (the grouped kernel: one body per tile shape)
 #define PA_WG_STEM 3          // QMODE of the stem: x is the 4-channel image, gathered as 7x7/2 patches (K = 256)
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
@@ -93,6 +95,10 @@ __device__ __forceinline__ void wgrad_tile_body(const PaWgradArgs& a, int ntiles
     // (L1 hits) so that they are not live across the MFMA section
     const int nchunk = tid % CPN, cchunk = tid % CPC;
     const bool want_db = DB && a.dbpart != nullptr && bz == 0;
+    // operand modes: template constants, or (PA_WG_RT, plain form) read from the operands -- wave-uniform branches
+    const bool p_lin2 = PMODE == PA_LD_LIN2 || (PMODE == PA_WG_RT && a.dy.mode == PA_LD_LIN2);
+    const bool q_bnrelu = QMODE == PA_LD_BNRELU || (QMODE == PA_WG_RT && a.x.mode == PA_LD_BNRELU);
+    static_assert(!PIPE || (PMODE != PA_WG_RT && QMODE != PA_WG_RT), "run-time modes: plain form only");
     float colsum[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) colsum[j] = 0.f;
@@ -312,7 +318,7 @@ __device__ __forceinline__ void wgrad_tile_body(const PaWgradArgs& a, int ntiles
             bf16x8 rp[PASS_N], rq[PASS_N];
             bool ok[PASS_N];
             float pk0[8], pk1[8], pk2[8];
-            if (PMODE == PA_LD_LIN2) {
+            if (p_lin2) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     pk0[j] = a.dy.k0[n0 + nchunk * 8 + j]; pk1[j] = a.dy.k1[n0 + nchunk * 8 + j]; pk2[j] = a.dy.k2[n0 + nchunk * 8 + j];
@@ -331,14 +337,14 @@ __device__ __forceinline__ void wgrad_tile_body(const PaWgradArgs& a, int ntiles
                     else { m = tile * 128 + r; ok[u] = m < M; }
                     const size_t idx = ok[u] ? (size_t)m * a.Cout + n0 + nchunk * 8 : 0;      // clamped, unconditional
                     rp[u] = *reinterpret_cast<const bf16x8*>(a.dy.p + idx);
-                    if (PMODE == PA_LD_LIN2) rq[u] = *reinterpret_cast<const bf16x8*>(a.dy.q + idx);
+                    if (p_lin2) rq[u] = *reinterpret_cast<const bf16x8*>(a.dy.q + idx);
                 }
 #pragma unroll
                 for (int v = 0; v < UNP; ++v) {
                     const int u = u0 + v;
                     const int r = u * (256 / CPN) + tid / CPN;
                     bf16x8 o;
-                    if (PMODE == PA_LD_LIN2) {
+                    if (p_lin2) {
 #pragma unroll
                         for (int j = 0; j < 8; ++j) o[j] = (bf16)fmaf(pk0[j], (float)rp[u][j], fmaf(pk1[j], (float)rq[u][j], pk2[j]));
                     } else {
@@ -361,7 +367,7 @@ __device__ __forceinline__ void wgrad_tile_body(const PaWgradArgs& a, int ntiles
             bf16x8 rx[PASS_C];
             bool ok[PASS_C];
             float qk0[8], qk1[8];
-            if (QMODE == PA_LD_BNRELU) {
+            if (q_bnrelu) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) { qk0[j] = a.x.k0[c0 + cchunk * 8 + j]; qk1[j] = a.x.k1[c0 + cchunk * 8 + j]; }
             }
@@ -412,7 +418,7 @@ __device__ __forceinline__ void wgrad_tile_body(const PaWgradArgs& a, int ntiles
                 const int hp = TAPS == 9 ? (hi / PW) * PWL + hi % PW : hi;          // pixel index in the LDS image
                 if (hi < HP) {
                     bf16x8 o;
-                    if (QMODE == PA_LD_BNRELU) {
+                    if (q_bnrelu) {
 #pragma unroll
                         for (int j = 0; j < 8; ++j) o[j] = (bf16)fmaxf(fmaf(qk0[j], (float)rx[u][j], qk1[j]), 0.f);
                     } else {
@@ -467,33 +473,41 @@ __global__ __launch_bounds__(256, PIPE ? OCC : 2) void wgrad_tile_kernel(PaWgrad
     wgrad_tile_body<TAPS, NF, CF, WNW, PMODE, QMODE, DB, PIPE>(a, ntiles, (int)blockIdx.x, (int)gridDim.x, (int)blockIdx.y, (int)blockIdx.z, lds);
 }
 
-// The three weight gradients of a residual block (reference models/asn_stacked_hg.py:17-24: conv3 1x1, conv2 3x3, conv1 1x1) in ONE
-// launch: job 0 = conv2 (3x3, plain dz2 x BatchNorm+ReLU(x1)), job 1 = conv3 (1x1, plain dz3 x BatchNorm+ReLU(x2)), job 2 = conv1
-// (1x1, BatchNorm-backward(x1.grad, x1) x BatchNorm+ReLU(in)).  A pipelined workgroup keeps its CU busy from the second tile on, so the
-// three layers run SIDE BY SIDE on a share of the CUs each with few, long splits -- a third of the fp32 slabs of three chip-wide
-// launches one after the other, and the launch is as long as its longest job instead of the sum of three.
+// Several INDEPENDENT weight gradients in ONE launch (the three or four of a residual block, reference models/asn_stacked_hg.py:17-24,
+// together with whatever else was waiting for the same event: the head's linear / out_conv / forth_conv / in_conv layers).  A launch per
+// layer spreads each layer over every CU as many short splits (one fp32 slab per workgroup) and runs the layers one after the other, each
+// with its own ramp and tail; here the layers run SIDE BY SIDE on a share of the CUs each, with few, long splits -- a third of the slab
+// bytes, and the launch lasts as long as its longest job instead of the sum.  One body per tile shape (kind), operand modes read at run time.
+// Plain (two workgroups per CU, <= 244 registers) rather than pipelined bodies: 6.27 vs 6.31 ms per step -- a pipelined workgroup owns its
+// CU's registers, and the main chain's kernels then find no room beside the group.
+#define PA_WG_MAXJOBS 8
+enum { PA_WGK_9_44 = 0, PA_WGK_9_44L, PA_WGK_1_44, PA_WGK_1_42, PA_WGK_1_24, PA_WGK_1_22, PA_WGK_N };      // 3x3 64 x 64 (n x c) with a plain / BatchNorm-backward dy operand (fixed modes: the 144-accumulator body has no registers to spare for both) | 1x1 128 x 128 | 128 x 64 | 64 x 128 | 64 x 64
 struct PaWgradGroup {
-    PaWgradArgs a[3];
-    int ntiles[3], S[3], ny[3];
-    int begin[4];              // first workgroup of job j (begin[3] = grid size)
+    PaWgradArgs a[PA_WG_MAXJOBS];
+    int ntiles[PA_WG_MAXJOBS], S[PA_WG_MAXJOBS], ny[PA_WG_MAXJOBS], kind[PA_WG_MAXJOBS];
+    int begin[PA_WG_MAXJOBS + 1];              // first workgroup of job j (begin[njobs] = grid size)
+    int njobs;
 };
 
-// P9 / P3: how conv2's / conv3's dy operand arrives -- PA_LD_PLAIN where the data gradient stored the BatchNorm-backward gradient (dz2 /
-// dz3: the 64x64 and 32x32 row-tile / halo-tile kernels), PA_LD_LIN2 where it did not (the low-resolution variants); Q1: conv1's x operand
-// -- the block input with its BatchNorm+ReLU pending (the previous block's x3) or a plain tensor (pooled / merged maps).
-// Plain (two workgroups per CU, <= 242 registers) rather than pipelined bodies: 6.27 vs 6.31 ms per step -- a pipelined workgroup owns its
-// CU's registers, and the main chain's kernels then find no room beside the group.
-template <int P9, int P3, int Q1>
 __global__ __launch_bounds__(256, 2) void wgrad_group_kernel(PaWgradGroup g) {
     constexpr int L9 = wg_lds_elems<9, 4, 1, 1>(), L1 = wg_lds_elems<1, 4, 4, 2>();
     __shared__ __attribute__((aligned(16))) bf16 lds[L9 > L1 ? L9 : L1];
     const int id = (int)blockIdx.x;
-    const int j = id < g.begin[1] ? 0 : (id < g.begin[2] ? 1 : 2);
+    int j = 0;
+#pragma unroll
+    for (int k = 1; k < PA_WG_MAXJOBS; ++k) if (k < g.njobs && id >= g.begin[k]) j = k;
     const int local = id - g.begin[j];
     const int S = g.S[j], split = local % S, rest = local / S, by = rest % g.ny[j], bz = rest / g.ny[j];
-    if (j == 0) wgrad_tile_body<9, 4, 1, 1, P9, PA_LD_BNRELU, false, false>(g.a[0], g.ntiles[0], split, S, by, bz, lds);
-    else if (j == 1) wgrad_tile_body<1, 4, 4, 2, P3, PA_LD_BNRELU, true, false>(g.a[1], g.ntiles[1], split, S, by, bz, lds);
-    else wgrad_tile_body<1, 4, 4, 2, PA_LD_LIN2, Q1, true, false>(g.a[2], g.ntiles[2], split, S, by, bz, lds);
+    const PaWgradArgs& a = g.a[j];
+    const int nt = g.ntiles[j];
+    switch (g.kind[j]) {
+        case PA_WGK_9_44: wgrad_tile_body<9, 4, 1, 1, PA_LD_PLAIN, PA_LD_BNRELU, false, false>(a, nt, split, S, by, bz, lds); break;
+        case PA_WGK_9_44L: wgrad_tile_body<9, 4, 1, 1, PA_LD_LIN2, PA_LD_BNRELU, false, false>(a, nt, split, S, by, bz, lds); break;
+        case PA_WGK_1_44: wgrad_tile_body<1, 4, 4, 2, PA_WG_RT, PA_WG_RT, true, false>(a, nt, split, S, by, bz, lds); break;
+        case PA_WGK_1_42: wgrad_tile_body<1, 4, 2, 2, PA_WG_RT, PA_WG_RT, true, false>(a, nt, split, S, by, bz, lds); break;
+        case PA_WGK_1_24: wgrad_tile_body<1, 2, 4, 2, PA_WG_RT, PA_WG_RT, true, false>(a, nt, split, S, by, bz, lds); break;
+        default: wgrad_tile_body<1, 2, 2, 2, PA_WG_RT, PA_WG_RT, true, false>(a, nt, split, S, by, bz, lds); break;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -617,72 +631,78 @@ int pa_launch_wgrad_tile(const PaWgradArgs& a, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------------------------------------ grouped launch
-// split counts of a residual block whose three weight gradients share one launch (0 = the block is not eligible): conv2 3x3 mid -> mid,
-// conv3 1x1 mid -> cout, conv1 1x1 cin -> mid
 static int wg_group_on() {
     static int on = -1;
     if (on < 0) { const char* e = pa_getenv("PA_WG_GROUP"); on = e ? atoi(e) : PA_WG_GROUP_DEFAULT; }
     return on;
 }
 
-bool pa_wgrad_group_splits(int B, int H, int W, int cin, int mid, int cout, int* s9, int* s3, int* s1) {
-    if (!wg_group_on()) return false;
-    WgTileCfg c9, c3, c1;
-    if (!wg_tile_cfg(B, H, W, mid, mid, 9, c9) || !wg_tile_cfg(B, H, W, mid, cout, 1, c3) || !wg_tile_cfg(B, H, W, cin, mid, 1, c1)) return false;
-    if (c9.nb != 64 || c9.cb != 64 || c3.nb != 128 || c3.cb != 128 || c1.nb != 128 || c1.cb != 128) return false;      // the grouped kernel's three instances
-    static int gs9 = -1, gs1 = -1, mp9 = -1, mp1 = -1;
-    if (gs9 < 0) {
-        const char* e = pa_getenv("PA_WG_GROUP_S9"); gs9 = e ? atoi(e) : 24;
-        e = pa_getenv("PA_WG_GROUP_S1"); gs1 = e ? atoi(e) : 64;
+static int wg_kind(const WgTileCfg& c, int taps, int pmode = PA_LD_PLAIN) {
+    if (taps == 9) return (c.nb == 64 && c.cb == 64) ? (pmode == PA_LD_LIN2 ? PA_WGK_9_44L : PA_WGK_9_44) : -1;
+    if (c.nb == 128 && c.cb == 128) return PA_WGK_1_44;
+    if (c.nb == 128 && c.cb == 64) return PA_WGK_1_42;
+    if (c.nb == 64 && c.cb == 128) return PA_WGK_1_24;
+    if (c.nb == 64 && c.cb == 64) return PA_WGK_1_22;
+    return -1;
+}
+
+// split count of a layer whose weight gradient is launched in a group (0: the shape is not one the grouped kernel takes -- the layer
+// keeps pa_wgrad_splits' count and its own launch): a WORKGROUP budget per job (3x3: 96, 1x1: 128 -- the measured optimum of the
+// 256 -> 128 -> 128 -> 256 blocks at 24 x 64 x 64: 24 / 64 splits), at least minper tiles per workgroup
+int pa_wgrad_group_splits(int B, int H, int W, int Cin, int Cout, int taps) {
+    if (!wg_group_on() || H <= 0 || W <= 0) return 0;
+    WgTileCfg c;
+    if (!wg_tile_cfg(B, H, W, Cin, Cout, taps, c) || wg_kind(c, taps) < 0) return 0;
+    static int wg9 = -1, wg1 = -1, mp9 = -1, mp1 = -1;
+    if (wg9 < 0) {
+        const char* e = pa_getenv("PA_WG_GROUP_WGS9"); wg9 = e ? atoi(e) : 96;
+        e = pa_getenv("PA_WG_GROUP_WGS1"); wg1 = e ? atoi(e) : 128;
         e = pa_getenv("PA_WG_GROUP_MINPER9"); mp9 = e ? atoi(e) : 4;
         e = pa_getenv("PA_WG_GROUP_MINPER1"); mp1 = e ? atoi(e) : 4;
     }
-    auto pick = [](int ntiles, int want, int minper) {
-        int s = want;
-        if (s * minper > ntiles) s = ntiles / minper;
-        if (s < 1) s = 1;
-        const int per = (ntiles + s - 1) / s;
-        return (ntiles + per - 1) / per;             // balanced
-    };
-    *s9 = pick(c9.ntiles, gs9, mp9);
-    *s3 = pick(c3.ntiles, gs1, mp1);
-    *s1 = pick(c1.ntiles, gs1, mp1);
-    return true;
+    const int types = (Cout / c.nb) * (Cin / c.cb);
+    int s = (taps == 9 ? wg9 : wg1) / types;
+    const int minper = taps == 9 ? mp9 : mp1;
+    if (s * minper > c.ntiles) s = c.ntiles / minper;
+    if (s < 1) s = 1;
+    const int per = (c.ntiles + s - 1) / s;
+    return (c.ntiles + per - 1) / per;               // balanced
 }
 
-// returns -1 when the three launches do not form a group this kernel takes (the caller launches them one by one)
-int pa_launch_wgrad_group(const PaWgradArgs& a9, const PaWgradArgs& a3, const PaWgradArgs& a1, hipStream_t st) {
-    if (!wg_group_on()) return -1;
-    if (a9.taps != 9 || a3.taps != 1 || a1.taps != 1 || a9.dbpart) return -1;
-    if ((a9.dy.mode != PA_LD_PLAIN && a9.dy.mode != PA_LD_LIN2) || a9.x.mode != PA_LD_BNRELU || (a3.dy.mode != PA_LD_PLAIN && a3.dy.mode != PA_LD_LIN2) ||
-        a3.x.mode != PA_LD_BNRELU || a1.dy.mode != PA_LD_LIN2 || (a1.x.mode != PA_LD_BNRELU && a1.x.mode != PA_LD_PLAIN)) return -1;
-    WgTileCfg c9, c3, c1;
-    if (!wg_tile_cfg(a9.B, a9.H, a9.W, a9.Cin, a9.Cout, 9, c9) || !wg_tile_cfg(a3.B, a3.H, a3.W, a3.Cin, a3.Cout, 1, c3) ||
-        !wg_tile_cfg(a1.B, a1.H, a1.W, a1.Cin, a1.Cout, 1, c1)) return -1;
-    if (c9.nb != 64 || c9.cb != 64 || c3.nb != 128 || c3.cb != 128 || c1.nb != 128 || c1.cb != 128) return -1;
-    if (a9.splits < 1 || a9.splits > c9.ntiles || a3.splits < 1 || a3.splits > c3.ntiles || a1.splits < 1 || a1.splits > c1.ntiles) return -1;
+// can this launch be a job of a group (its slab laid out with a grouped split count, tile shape known to the grouped kernel)?
+bool pa_wgrad_group_takes(const PaWgradArgs& a) {
+    if (!wg_group_on() || (a.taps == 9 && a.dbpart)) return false;
+    if (a.dy.mode != PA_LD_PLAIN && a.dy.mode != PA_LD_LIN2) return false;
+    if (a.x.mode != PA_LD_PLAIN && a.x.mode != PA_LD_BNRELU) return false;
+    if (a.taps == 9 && a.x.mode != PA_LD_BNRELU) return false;          // (the 3x3 bodies are compiled for a BatchNorm+ReLU x operand: every conv2 of the networks)
+    WgTileCfg c;
+    if (!wg_tile_cfg(a.B, a.H, a.W, a.Cin, a.Cout, a.taps, c) || wg_kind(c, a.taps) < 0) return false;
+    return a.splits >= 1 && a.splits <= c.ntiles;
+}
+
+// n <= PA_WG_MAXJOBS launches that pa_wgrad_group_takes() admitted, in one launch (the longest jobs first: their workgroups start first)
+int pa_launch_wgrad_group(const PaWgradArgs* const* as, int n, hipStream_t st) {
+    if (n < 1 || n > PA_WG_MAXJOBS) { pa_set_error_msg("pa_launch_wgrad_group: 1 .. 8 jobs"); return 1; }
     PaWgradGroup g;
-    const PaWgradArgs* as[3] = {&a9, &a3, &a1};
-    const WgTileCfg* cs[3] = {&c9, &c3, &c1};
+    memset(&g, 0, sizeof g);
+    int order[PA_WG_MAXJOBS]; long work[PA_WG_MAXJOBS];
+    WgTileCfg cs[PA_WG_MAXJOBS];
+    for (int j = 0; j < n; ++j) {
+        if (!pa_wgrad_group_takes(*as[j])) { pa_set_error_msg("pa_launch_wgrad_group: a job the grouped kernel does not take"); return 1; }
+        wg_tile_cfg(as[j]->B, as[j]->H, as[j]->W, as[j]->Cin, as[j]->Cout, as[j]->taps, cs[j]);
+        order[j] = j;
+        work[j] = (long)((cs[j].ntiles + as[j]->splits - 1) / as[j]->splits) * (as[j]->taps == 9 ? 3 : 2);      // tiles per workgroup x relative tile cost
+    }
+    for (int i = 1; i < n; ++i)                      // insertion sort, descending work
+        for (int k = i; k > 0 && work[order[k]] > work[order[k - 1]]; --k) { const int t = order[k]; order[k] = order[k - 1]; order[k - 1] = t; }
     int begin = 0;
-    for (int j = 0; j < 3; ++j) {
-        g.a[j] = *as[j]; g.ntiles[j] = cs[j]->ntiles; g.S[j] = as[j]->splits; g.ny[j] = as[j]->Cout / cs[j]->nb;
-        g.begin[j] = begin;
-        begin += as[j]->splits * (as[j]->Cout / cs[j]->nb) * (as[j]->Cin / cs[j]->cb);
+    for (int jj = 0; jj < n; ++jj) {
+        const int j = order[jj];
+        g.a[jj] = *as[j]; g.ntiles[jj] = cs[j].ntiles; g.S[jj] = as[j]->splits; g.ny[jj] = as[j]->Cout / cs[j].nb; g.kind[jj] = wg_kind(cs[j], as[j]->taps, as[j]->dy.mode);
+        g.begin[jj] = begin;
+        begin += as[j]->splits * (as[j]->Cout / cs[j].nb) * (as[j]->Cin / cs[j].cb);
     }
-    g.begin[3] = begin;
-    const bool l9 = a9.dy.mode == PA_LD_LIN2, l3 = a3.dy.mode == PA_LD_LIN2, q1 = a1.x.mode == PA_LD_BNRELU;
-    auto go = [&](auto kernel) { hipLaunchKernelGGL(kernel, dim3(begin), dim3(256), 0, st, g); };
-    if (q1) {
-        if (!l9 && !l3) go(wgrad_group_kernel<PA_LD_PLAIN, PA_LD_PLAIN, PA_LD_BNRELU>);
-        else if (!l9) go(wgrad_group_kernel<PA_LD_PLAIN, PA_LD_LIN2, PA_LD_BNRELU>);
-        else if (!l3) go(wgrad_group_kernel<PA_LD_LIN2, PA_LD_PLAIN, PA_LD_BNRELU>);
-        else go(wgrad_group_kernel<PA_LD_LIN2, PA_LD_LIN2, PA_LD_BNRELU>);
-    } else {
-        if (!l9 && !l3) go(wgrad_group_kernel<PA_LD_PLAIN, PA_LD_PLAIN, PA_LD_PLAIN>);
-        else if (!l9) go(wgrad_group_kernel<PA_LD_PLAIN, PA_LD_LIN2, PA_LD_PLAIN>);
-        else if (!l3) go(wgrad_group_kernel<PA_LD_LIN2, PA_LD_PLAIN, PA_LD_PLAIN>);
-        else go(wgrad_group_kernel<PA_LD_LIN2, PA_LD_LIN2, PA_LD_PLAIN>);
-    }
+    g.begin[n] = begin; g.njobs = n;
+    hipLaunchKernelGGL(wgrad_group_kernel, dim3(begin), dim3(256), 0, st, g);
     return (int)hipGetLastError();
 }

@@ -49,9 +49,11 @@ int pa_wgrad_splits(int M, int H, int W, int Cin, int Cout, int taps);
 int pa_wgrad_tile_splits(int B, int H, int W, int Cin, int Cout, int taps);
 int pa_launch_stem_wgrad_tile(const PaWgradArgs& a, hipStream_t st);   // -1: not handled
 int pa_launch_wgrad_tile(const PaWgradArgs& a, hipStream_t st);
-// a residual block's three weight gradients in one launch (conv_wgrad_tile.hip): split counts for the layout (false = not eligible), launch (-1 = not a group)
-bool pa_wgrad_group_splits(int B, int H, int W, int cin, int mid, int cout, int* s9, int* s3, int* s1);
-int pa_launch_wgrad_group(const PaWgradArgs& conv2, const PaWgradArgs& conv3, const PaWgradArgs& conv1, hipStream_t st);
+// several independent weight gradients in one launch (conv_wgrad_tile.hip): split count of a layer that will be a job (0 = its shape is not
+// taken), may this launch be a job, launch n <= 8 jobs
+int pa_wgrad_group_splits(int B, int H, int W, int Cin, int Cout, int taps);
+bool pa_wgrad_group_takes(const PaWgradArgs& a);
+int pa_launch_wgrad_group(const PaWgradArgs* const* jobs, int n, hipStream_t st);
 void pa_wgrad_set_launch_flags(unsigned flags);      // hipExtAnyOrderLaunch for the tile weight gradients launched next by this thread (0 = in-order)
 
 // reduce partial slabs into the fp32 gradient in PyTorch layout  dst[n][c][tap]  (real_cin/real_cout

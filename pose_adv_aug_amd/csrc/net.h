@@ -49,7 +49,6 @@ struct ConvLayer {
     bf16 *wf = nullptr, *wb = nullptr;
     float *part = nullptr, *dbpart = nullptr;
     int splits = 0;
-    int group_splits = 0;                  // > 0: split count when the block's three weight gradients share a launch (layout_conv uses it)
     int red_index = -1;                    // index of this layer's job in the reduce table
     size_t part_floats = 0, db_floats = 0;
     bool has_bn_after = true;
@@ -165,7 +164,7 @@ struct Net {
     hipEvent_t ev_wdone;
     // weight-gradient launches are collected and flushed in groups: ONE event record on the producing stream per group
     // (an event record between two kernels of a queue costs a 15-20 us bubble on it: ~100 records per step were 1.5 ms)
-    struct PendingWgrad { PaWgradArgs a; int cls; double bytes, flops; bool stem; ConvLayer* c; const void* grp; int role; };      // grp / role: residual block and conv number (3, 2, 1) of a groupable launch
+    struct PendingWgrad { PaWgradArgs a; int cls; double bytes, flops; bool stem; ConvLayer* c; };
     // the slabs of a group are summed right behind it on the weight-gradient stream (part of them still in the 256 MB
     // Infinity Cache) instead of by one 280 us reduction on the main stream at the end of the step: +1.1 % (PA_WREDUCE_LATE = old)
     bool reduce_early = true;
@@ -261,7 +260,7 @@ struct Net {
     int finish_grad_or_defer(const Act& a, bool defer);
     int finish_grad2_or_defer(const Act& a, bool defer_a, const Act& b, bool defer_b);
     bool x3_fin_ok(const Residual& r, const Act& in) const;     // can r.x3's backward finalize ride in conv3's data gradient?
-    int conv_wgrad(ConvLayer& c, const PaOperand& dy, const PaOperand& x, int B, int H, int W, const void* grp = nullptr, int role = 0);
+    int conv_wgrad(ConvLayer& c, const PaOperand& dy, const PaOperand& x, int B, int H, int W);
 
     int prepare_weights();
     int begin_step();

@@ -117,7 +117,11 @@ void Net::layout_conv(ConvLayer& c, Arena& a, int M, int H, int W) {
     const size_t wn = (size_t)c.pcout * (c.k == 7 ? 1 : c.taps()) * c.pcin;
     c.wf = a.get<bf16>(wn);
     c.wb = (c.k == 7) ? nullptr : a.get<bf16>(wn);
-    c.splits = c.k == 7 ? pa_wgrad_splits(M, 0, 0, c.pcin, c.pcout, 1) : (c.group_splits > 0 ? c.group_splits : pa_wgrad_splits(M, H, W, c.pcin, c.pcout, c.taps()));
+    c.splits = c.k == 7 ? pa_wgrad_splits(M, 0, 0, c.pcin, c.pcout, 1) : pa_wgrad_splits(M, H, W, c.pcin, c.pcout, c.taps());
+    if (c.k != 7 && H > 0 && B > 0 && M == B * H * W) {          // a layer the grouped weight-gradient kernel takes: few, long splits
+        const int gs = pa_wgrad_group_splits(B, H, W, c.pcin, c.pcout, c.taps());
+        if (gs > 0) c.splits = gs;
+    }
     if (c.k == 7) {                              // stem: 64 KB slabs, so two workgroups per CU (their load / MFMA phases overlap)
         static int ss = -1;
         if (ss < 0) { const char* e = pa_getenv("PA_STEM_SPLITS"); ss = e ? atoi(e) : 512; }       // 6.96 vs 7.00 ms (256)
@@ -158,11 +162,6 @@ Act Net::new_act(Arena& a, int B_, int H, int W, int C, BNLayer* bn, bool need_g
 
 void Residual::layout(Net& n, Arena& a, int B, int H, int W, bool need_grad) {
     const int M = B * H * W, mid = cout / 2;
-    {   // the three weight gradients in one launch where the grouped kernel takes the shapes: few, long splits per layer
-        int s9 = 0, s3 = 0, s1 = 0;
-        const bool grp = pa_wgrad_group_splits(B, H, W, c1.pcin, c2.pcin, c3.pcout, &s9, &s3, &s1);
-        c2.group_splits = grp ? s9 : 0; c3.group_splits = grp ? s3 : 0; c1.group_splits = grp ? s1 : 0;
-    }
     n.layout_conv(c1, a, M, H, W); n.layout_conv(c2, a, M, H, W); n.layout_conv(c3, a, M, H, W);      // explicit map size: the split counts depend on it
     n.layout_bn(b1, a, M); n.layout_bn(b2, a, M); n.layout_bn(b3, a, M);
     x1 = n.new_act(a, B, H, W, mid, &b1, need_grad);
@@ -457,7 +456,7 @@ int Net::conv_dgrad(ConvLayer& c, const PaOperand& dy, int B_, int H, int W, con
     return rc;
 }
 
-int Net::conv_wgrad(ConvLayer& c, const PaOperand& dy, const PaOperand& x, int B_, int H, int W, const void* grp, int role) {
+int Net::conv_wgrad(ConvLayer& c, const PaOperand& dy, const PaOperand& x, int B_, int H, int W) {
     PaWgradArgs a; memset(&a, 0, sizeof a);
     a.dy = dy; a.x = x; a.part = c.part; a.dbpart = c.dbpart;
     a.B = B_; a.H = H; a.W = W; a.Cin = c.pcin; a.Cout = c.pcout; a.taps = c.k == 7 ? 1 : c.taps(); a.splits = c.splits;
@@ -475,7 +474,7 @@ int Net::conv_wgrad(ConvLayer& c, const PaOperand& dy, const PaOperand& x, int B
     // (the stem's weight gradient is the last launch of the step: on the main stream, idle by then, it runs beside the weight-gradient
     // queue's last reduction instead of behind it)
     if (multi_stream && wstream && !(c.k == 7 && stem_main && reduce_early && !immediate_reduce)) {        // deferred: flush_wgrads() launches it on the weight-gradient stream
-        PendingWgrad p; p.a = a; p.cls = cls; p.bytes = wb; p.flops = wf; p.stem = c.k == 7; p.c = &c; p.grp = c.group_splits > 0 ? grp : nullptr; p.role = role;
+        PendingWgrad p; p.a = a; p.cls = cls; p.bytes = wb; p.flops = wf; p.stem = c.k == 7; p.c = &c;
         pending_wgrads.push_back(p);
         return 0;
     }
@@ -521,18 +520,29 @@ int Net::flush_wgrads() {
     static int any_order = -1;
     if (any_order < 0) { const char* e = pa_getenv("PA_WGRAD_ANYORDER"); any_order = e ? atoi(e) : 1; }
     bool first = true;
+    // every launch of the list the grouped kernel takes goes into group launches of up to 8 jobs (not while the per-launch event timing
+    // runs: its classes are per layer); the others -- the stem, shapes of the generic kernel -- are launched one by one behind them
+    std::vector<char> grouped(pending_wgrads.size(), 0);
+    if (!prof.on && !immediate_reduce) {
+        const PaWgradArgs* jobs[8]; int nj = 0;
+        auto fire = [&]() -> int {
+            if (nj == 0) return 0;
+            const int rc = nj == 1 ? pa_launch_wgrad(*jobs[0], ws) : pa_launch_wgrad_group(jobs, nj, ws);
+            nj = 0; first = false;
+            return rc;
+        };
+        for (size_t pi = 0; pi < pending_wgrads.size(); ++pi) {
+            PendingWgrad& p = pending_wgrads[pi];
+            if (p.stem || !pa_wgrad_group_takes(p.a)) continue;
+            grouped[pi] = 1;
+            jobs[nj++] = &p.a;
+            if (nj == 8) { const int rc = fire(); if (rc) { pending_wgrads.clear(); return rc; } }
+        }
+        { const int rc = fire(); if (rc) { pending_wgrads.clear(); return rc; } }
+    }
     for (size_t pi = 0; pi < pending_wgrads.size(); ++pi) {
         PendingWgrad& p = pending_wgrads[pi];
-        // conv3, conv2, conv1 of one residual block, in the order Residual::bwd_a queues them: one grouped launch (not while the
-        // per-launch event timing runs: its classes are per layer)
-        if (p.grp && p.role == 3 && pi + 2 < pending_wgrads.size() && !prof.on && !immediate_reduce) {
-            PendingWgrad &p2 = pending_wgrads[pi + 1], &p1 = pending_wgrads[pi + 2];
-            if (p2.grp == p.grp && p2.role == 2 && p1.grp == p.grp && p1.role == 1) {
-                const int rc = pa_launch_wgrad_group(p2.a, p.a, p1.a, ws);
-                if (rc > 0) { pending_wgrads.clear(); return rc; }
-                if (rc == 0) { pi += 2; first = false; continue; }
-            }
-        }
+        if (grouped[pi]) continue;
         ProfEntry* pe = prof.begin(p.cls, p.bytes, p.flops, ws);
         pa_wgrad_set_launch_flags((any_order && !first && !prof.on && !immediate_reduce && !capturing) ? 1u : 0u);
         int rc = p.stem ? pa_launch_stem_wgrad(p.a, ws) : pa_launch_wgrad(p.a, ws);
@@ -627,7 +637,7 @@ int Residual::bwd_a(Net& n, const Act& in) {
     dz3_valid = false;
     TRY(n.conv_dgrad(c3, g3, B, H, W, pa_none(), pa_none(), n.final_ep(x2), x2.grad, dz3, &dz3_valid, x3.bn));
     if (dz3_valid) g3 = pa_plain(dz3);
-    TRY(n.conv_wgrad(c3, g3, n.op(x2), B, H, W, this, 3));
+    TRY(n.conv_wgrad(c3, g3, n.op(x2), B, H, W));
     // (x2's BatchNorm-backward constants are first read by conv2's data gradient, which can compute them in its prologue; conv2's
     // weight gradient, on the weight-gradient stream, is launched behind it)
     TRY(n.finish_grad_or_defer(x2, (n.fin_mask & 2) && n.fin_consumer_ok(c2, B, H, W, true)));
@@ -635,12 +645,12 @@ int Residual::bwd_a(Net& n, const Act& in) {
     bool dz2_valid = false;
     TRY(n.conv_dgrad(c2, g2, B, H, W, pa_none(), pa_none(), n.final_ep(x1), x1.grad, dz2, &dz2_valid, x2.bn));
     if (dz2_valid) g2 = pa_plain(dz2);
-    TRY(n.conv_wgrad(c2, g2, n.op(x1), B, H, W, this, 2));
+    TRY(n.conv_wgrad(c2, g2, n.op(x1), B, H, W));
     // (x1's constants have two first readers -- conv1's weight gradient on the weight-gradient stream and conv1's data gradient in bwd_b:
     // queueing the weight gradient behind a data gradient that finalizes in its prologue measured +0.05 ms, round 4 -- a launch stays)
     TRY(n.finish_grad(x1));
     const PaOperand g1 = n.gradop(x1);
-    TRY(n.conv_wgrad(c1, g1, n.op(in), B, H, W, this, 1));
+    TRY(n.conv_wgrad(c1, g1, n.op(in), B, H, W));
     if (has_adapter) TRY(n.conv_wgrad(ad, g3, n.op(in), B, H, W));
     if (!n.on_side && (++n.flush_ctr % n.flush_every) != 0) return 0;
     return n.flush_wgrads();                   // one event for the block's 3-4 weight gradients
