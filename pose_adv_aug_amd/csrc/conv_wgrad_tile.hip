@@ -647,18 +647,18 @@ static int wg_kind(const WgTileCfg& c, int taps, int pmode = PA_LD_PLAIN) {
 }
 
 // split count of a layer whose weight gradient is launched in a group (0: the shape is not one the grouped kernel takes -- the layer
-// keeps pa_wgrad_splits' count and its own launch): a WORKGROUP budget per job (3x3: 96, 1x1: 128 -- the measured optimum of the
-// 256 -> 128 -> 128 -> 256 blocks at 24 x 64 x 64: 24 / 64 splits), at least minper tiles per workgroup
+// keeps pa_wgrad_splits' count and its own launch): a WORKGROUP budget per job (64 each: three jobs of a residual block stay below the
+// 256-workgroup cap of a group launch, Net::flush_wgrads -- 5.91 vs 5.98 ms for 96 / 128 without a cap), at least minper tiles per workgroup
 int pa_wgrad_group_splits(int B, int H, int W, int Cin, int Cout, int taps) {
     if (!wg_group_on() || H <= 0 || W <= 0) return 0;
     WgTileCfg c;
     if (!wg_tile_cfg(B, H, W, Cin, Cout, taps, c) || wg_kind(c, taps) < 0) return 0;
     static int wg9 = -1, wg1 = -1, mp9 = -1, mp1 = -1;
     if (wg9 < 0) {
-        const char* e = pa_getenv("PA_WG_GROUP_WGS9"); wg9 = e ? atoi(e) : 96;
-        e = pa_getenv("PA_WG_GROUP_WGS1"); wg1 = e ? atoi(e) : 128;
+        const char* e = pa_getenv("PA_WG_GROUP_WGS9"); wg9 = e ? atoi(e) : 64;
+        e = pa_getenv("PA_WG_GROUP_WGS1"); wg1 = e ? atoi(e) : 64;
         e = pa_getenv("PA_WG_GROUP_MINPER9"); mp9 = e ? atoi(e) : 4;
-        e = pa_getenv("PA_WG_GROUP_MINPER1"); mp1 = e ? atoi(e) : 4;
+        e = pa_getenv("PA_WG_GROUP_MINPER1"); mp1 = e ? atoi(e) : 2;
     }
     const int types = (Cout / c.nb) * (Cin / c.cb);
     int s = (taps == 9 ? wg9 : wg1) / types;
@@ -678,6 +678,12 @@ bool pa_wgrad_group_takes(const PaWgradArgs& a) {
     WgTileCfg c;
     if (!wg_tile_cfg(a.B, a.H, a.W, a.Cin, a.Cout, a.taps, c) || wg_kind(c, a.taps) < 0) return false;
     return a.splits >= 1 && a.splits <= c.ntiles;
+}
+
+int pa_wgrad_job_workgroups(const PaWgradArgs& a) {
+    WgTileCfg c;
+    if (!wg_tile_cfg(a.B, a.H, a.W, a.Cin, a.Cout, a.taps, c)) return 0;
+    return a.splits * (a.Cout / c.nb) * (a.Cin / c.cb);
 }
 
 // n <= PA_WG_MAXJOBS launches that pa_wgrad_group_takes() admitted, in one launch (the longest jobs first: their workgroups start first)

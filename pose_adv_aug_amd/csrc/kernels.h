@@ -53,6 +53,7 @@ int pa_launch_wgrad_tile(const PaWgradArgs& a, hipStream_t st);
 // taken), may this launch be a job, launch n <= 8 jobs
 int pa_wgrad_group_splits(int B, int H, int W, int Cin, int Cout, int taps);
 bool pa_wgrad_group_takes(const PaWgradArgs& a);
+int pa_wgrad_job_workgroups(const PaWgradArgs& a);          // workgroups of the launch as a job
 int pa_launch_wgrad_group(const PaWgradArgs* const* jobs, int n, hipStream_t st);
 void pa_wgrad_set_launch_flags(unsigned flags);      // hipExtAnyOrderLaunch for the tile weight gradients launched next by this thread (0 = in-order)
 

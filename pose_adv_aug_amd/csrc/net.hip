@@ -14,7 +14,8 @@ static int ablate() { static int v = -1; if (v < 0) { const char* e = pa_getenv(
 // bits 128 / 256 / 512: forward convolutions + finalize / data gradients + backward finalize / weight gradients of maps up to
 // PA_ABLATE_H (default 8) pixels high are skipped: what the low-resolution stretch costs the step at most (wrong results)
 static int ablate_h() { static int v = -1; if (v < 0) { const char* e = pa_getenv("PA_ABLATE_H"); v = e ? atoi(e) : 8; } return v; }
-#define PA_STEM_ON_MAIN_DEFAULT 0
+#define PA_STEM_ON_MAIN_DEFAULT 1
+#define PA_WG_GROUP_CAP_DEFAULT 256
 #define TRY(x) do { int _r = (x); if (_r) return _r; } while (0)
 
 PaOperand pa_plain(const bf16* p) { PaOperand o; o.p = p; o.q = nullptr; o.k0 = o.k1 = o.k2 = nullptr; o.mode = PA_LD_PLAIN; return o; }
@@ -531,12 +532,19 @@ int Net::flush_wgrads() {
             nj = 0; first = false;
             return rc;
         };
+        // a group launch is capped at `cap` workgroups: its workgroups live for tens of microseconds with 242 registers each, two of them
+        // close a CU to every other queue -- a launch of <= 256 leaves room for a workgroup of the main chain beside it on every CU
+        static int cap = -1;
+        if (cap < 0) { const char* e = pa_getenv("PA_WG_GROUP_CAP"); cap = e ? atoi(e) : PA_WG_GROUP_CAP_DEFAULT; }
+        int wgs = 0;
         for (size_t pi = 0; pi < pending_wgrads.size(); ++pi) {
             PendingWgrad& p = pending_wgrads[pi];
             if (p.stem || !pa_wgrad_group_takes(p.a)) continue;
+            const int w = pa_wgrad_job_workgroups(p.a);
+            if (nj > 0 && (nj == 8 || wgs + w > cap)) { const int rc = fire(); if (rc) { pending_wgrads.clear(); return rc; } wgs = 0; }
             grouped[pi] = 1;
             jobs[nj++] = &p.a;
-            if (nj == 8) { const int rc = fire(); if (rc) { pending_wgrads.clear(); return rc; } }
+            wgs += w;
         }
         { const int rc = fire(); if (rc) { pending_wgrads.clear(); return rc; } }
     }
