@@ -474,7 +474,11 @@ int Net::conv_wgrad(ConvLayer& c, const PaOperand& dy, const PaOperand& x, int B
     if (stem_main < 0) { const char* e = pa_getenv("PA_STEM_ON_MAIN"); stem_main = e ? atoi(e) : PA_STEM_ON_MAIN_DEFAULT; }
     // (the stem's weight gradient is the last launch of the step: on the main stream, idle by then, it runs beside the weight-gradient
     // queue's last reduction instead of behind it)
-    if (multi_stream && wstream && !(c.k == 7 && stem_main && reduce_early && !immediate_reduce)) {        // deferred: flush_wgrads() launches it on the weight-gradient stream
+    // single-stream mode (bench.py's roofline leg, debugging): the launches the grouped kernel takes are collected too and leave as the
+    // same group launches on the caller's stream -- per-class event times and the bitwise comparison of the stream modes then see the
+    // kernels of the real step
+    const bool defer_single = !(multi_stream && wstream) && !immediate_reduce && c.k != 7 && pa_wgrad_group_takes(a);
+    if (defer_single || (multi_stream && wstream && !(c.k == 7 && stem_main && reduce_early && !immediate_reduce))) {        // deferred: flush_wgrads() launches it (on the weight-gradient stream)
         PendingWgrad p; p.a = a; p.cls = cls; p.bytes = wb; p.flops = wf; p.stem = c.k == 7; p.c = &c;
         pending_wgrads.push_back(p);
         return 0;
@@ -510,8 +514,10 @@ int Net::release_held(int k) {
 
 int Net::flush_wgrads() {
     if (pending_wgrads.empty() || hold) return 0;
-    hipStream_t ws = wstreams[w_rr]; w_rr = (w_rr + 1) % n_w;
-    if (!(nosync() && (g_nosync & 4))) {
+    const bool ms = multi_stream && wstream;
+    hipStream_t ws = ms ? wstreams[w_rr] : st;
+    if (ms) w_rr = (w_rr + 1) % n_w;
+    if (ms && !(nosync() && (g_nosync & 4))) {
         hipEvent_t ev = ev_w[ev_w_next]; ev_w_next = (ev_w_next + 1) & 15;
         PA_CHECK(hipEventRecord(ev, st));
         PA_CHECK(hipStreamWaitEvent(ws, ev, 0));
@@ -524,11 +530,20 @@ int Net::flush_wgrads() {
     // every launch of the list the grouped kernel takes goes into group launches of up to 8 jobs (not while the per-launch event timing
     // runs: its classes are per layer); the others -- the stem, shapes of the generic kernel -- are launched one by one behind them
     std::vector<char> grouped(pending_wgrads.size(), 0);
-    if (!prof.on && !immediate_reduce) {
-        const PaWgradArgs* jobs[8]; int nj = 0;
+    if (!immediate_reduce) {
+        const PaWgradArgs* jobs[8]; int jidx[8]; int nj = 0;
         auto fire = [&]() -> int {
             if (nj == 0) return 0;
+            // (event timing: the launch counts for the class of its largest job, with the bytes / flops of all of them)
+            int big = 0; double bytes = 0.0, flops = 0.0;
+            for (int j = 0; j < nj; ++j) {
+                const PendingWgrad& q = pending_wgrads[jidx[j]];
+                bytes += q.bytes; flops += q.flops;
+                if (q.flops > pending_wgrads[jidx[big]].flops) big = j;
+            }
+            ProfEntry* pe = prof.begin(pending_wgrads[jidx[big]].cls, bytes, flops, ws);
             const int rc = nj == 1 ? pa_launch_wgrad(*jobs[0], ws) : pa_launch_wgrad_group(jobs, nj, ws);
+            prof.end(pe, ws);
             nj = 0; first = false;
             return rc;
         };
@@ -543,6 +558,7 @@ int Net::flush_wgrads() {
             const int w = pa_wgrad_job_workgroups(p.a);
             if (nj > 0 && (nj == 8 || wgs + w > cap)) { const int rc = fire(); if (rc) { pending_wgrads.clear(); return rc; } wgs = 0; }
             grouped[pi] = 1;
+            jidx[nj] = (int)pi;
             jobs[nj++] = &p.a;
             wgs += w;
         }
@@ -566,7 +582,7 @@ int Net::flush_wgrads() {
             }
         }
     }
-    if (reduce_early && !immediate_reduce && !(ablate() & 1)) {                    // the group's slabs are summed while they are still in the Infinity Cache
+    if (ms && reduce_early && !immediate_reduce && !(ablate() & 1)) {                    // the group's slabs are summed while they are still in the Infinity Cache (single-stream mode: reduce_grads() sums everything at the end)
         int lo = 1 << 30, hi = -1, cnt = 0, mx = 0;
         for (PendingWgrad& p : pending_wgrads) {
             if (p.stem) {

@@ -38,9 +38,11 @@ def classify(name):
     m = re.match(r'void conv1x1_oneshot_kernel<(\d+), (\d+),', name)
     if m:
         return 'conv_dgrad_1x1' if int(m.group(2)) == 2 else 'conv_fwd_1x1'
-    m = re.match(r'void conv1x1_tile_kernel<(\d+), (\d+), (\d+), (\d+)>', name)
+    m = re.match(r'void conv1x1_tile_kernel<(\d+), (\d+), (\d+), (\d+)[,>]', name)
     if m:
         return 'conv_dgrad_1x1' if int(m.group(4)) == 2 else 'conv_fwd_1x1'
+    if 'wgrad_group_kernel' in name:           # several layers in one launch (round 5): counted with the 3x3 class, whose job is the longest of a block's group
+        return 'conv_wgrad_3x3'
     m = re.match(r'void wgrad_tile_kernel<(\d+),', name)
     if m:
         return 'conv_wgrad_3x3' if int(m.group(1)) in (3, 9) else 'conv_wgrad_1x1'
@@ -83,7 +85,7 @@ def parse_pmc(fetch_csv, write_csv, steps):
                         for k, v in per_kernel.items()}}
 
 
-MFMA_KERNELS = ('conv1x1_tile_kernel', 'conv1x1_oneshot_kernel', 'conv3x3_tile_kernel', 'conv_igemm_kernel', 'wgrad_tile_kernel', 'conv_wgrad_kernel', 'stem_conv',
+MFMA_KERNELS = ('conv1x1_tile_kernel', 'conv1x1_oneshot_kernel', 'conv3x3_tile_kernel', 'conv_igemm_kernel', 'wgrad_tile_kernel', 'wgrad_group_kernel', 'conv_wgrad_kernel', 'stem_conv',
                 'stem_wgrad')
 
 

@@ -12,7 +12,7 @@ import json
 import sqlite3
 import sys
 
-MFMA_KERNELS = ('conv1x1_tile_kernel', 'conv1x1_oneshot_kernel', 'conv3x3_tile_kernel', 'conv_igemm_kernel', 'wgrad_tile_kernel', 'conv_wgrad_kernel',
+MFMA_KERNELS = ('conv1x1_tile_kernel', 'conv1x1_oneshot_kernel', 'conv3x3_tile_kernel', 'conv_igemm_kernel', 'wgrad_tile_kernel', 'wgrad_group_kernel', 'conv_wgrad_kernel',
                 'stem_conv', 'stem_wgrad')
 
 
