@@ -398,7 +398,7 @@ def main():
                        'whole_step': {'fetch_bytes_x2': round(measured_pmc['fetch_bytes_per_step_x2']), 'write_bytes': round(measured_pmc['write_bytes_per_step'])},
                        'source': 'measured in this run: rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) and --pmc WRITE_SIZE child passes of this command, 7 steps each; per class by launch order'}
         else:
-            for name in ('round4_pmc.json', 'round3_pmc.json', 'round2_pmc.json'):
+            for name in ('round5_pmc.json', 'round4_pmc.json', 'round3_pmc.json', 'round2_pmc.json'):
                 pmc_path = os.path.join(ROOT, 'profiles', name)
                 if is_c2 and os.path.isfile(pmc_path):
                     pmc = json.load(open(pmc_path))
@@ -410,7 +410,7 @@ def main():
         if measured_tr and dom['kernel'] in measured_tr:
             tr, tr_src = measured_tr[dom['kernel']], 'measured in this run: rocprofv3 --kernel-trace child pass of this command (single-stream roofline leg, 5 steps)'
         else:
-            for name in ('round4_trace_classes.json', 'round3_trace_classes.json', 'round2_trace_classes.json'):
+            for name in ('round5_trace_classes.json', 'round4_trace_classes.json', 'round3_trace_classes.json', 'round2_trace_classes.json'):
                 tr_path = os.path.join(ROOT, 'profiles', name)
                 if is_c2 and os.path.isfile(tr_path):
                     tr, tr_src = json.load(open(tr_path)).get(dom['kernel']), 'profiles/%s (recorded; not measured in this run)' % name
@@ -429,9 +429,15 @@ def main():
                     'launches_per_step': dom['launches'] // args.steps,
                     'alg_bytes_per_launch': dom['bytes'] / dom['launches'], 'alg_flops_per_launch': dom['flops'] / dom['launches'],
                     'mfma_kernels_ms_per_step': round(conv_ms, 3),
+                    'note': 'kernel = the MFMA-kernel class with the largest total HIP-event time in the single-stream leg.  conv_wgrad_3x3 launches are '
+                            'GROUP launches since round 5 (wgrad_group_kernel: the 3x3 + 1x1 weight gradients of a residual block, or the head\'s layers, '
+                            'in one launch of <= 256 workgroups, bytes / flops of all its jobs): built to run beside the main chain on a share of the CUs, '
+                            'so their time ALONE over-states what they cost the step; classes[conv_dgrad_1x1] is the main chain\'s largest class',
                     'classes': {r['kernel']: {'ms_per_step': round(r['ms_total'] / args.steps, 3),
                                               'tflops': round(r['flops'] / (r['ms_total'] * 1e-3) / 1e12, 1),
-                                              'gbps': round(r['bytes'] / (r['ms_total'] * 1e-3) / 1e9, 1)} for r in rows},
+                                              'gbps': round(r['bytes'] / (r['ms_total'] * 1e-3) / 1e9, 1),
+                                              'hbm_frac': round(r['bytes'] / (r['ms_total'] * 1e-3) / HBM_PEAK, 4), 'launches_per_step': r['launches'] // args.steps,
+                                              'avg_us': round(r['avg_us'], 2)} for r in rows},
                     'whole_step': ({'hbm_frac': round(value / world * 380.5e6 / HBM_PEAK, 4),
                                     'mfma_frac': round(value / world * 50.0e9 / MFMA_PEAK, 4)}
                                    if (args.stacks, args.chan, res) == (2, 256, 256) else None)}
