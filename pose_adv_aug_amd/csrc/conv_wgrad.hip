@@ -307,8 +307,7 @@ int pa_launch_wgrad(const PaWgradArgs& a, hipStream_t st) {
 
 // ------------------------------------------------------------------------------------------------
 // sum the split slabs and scatter into PyTorch layout  dst[n][c][tap]   (one job per conv layer)
-__global__ void wgrad_reduce_kernel(const PaWgradReduceJob* jobs) {
-    const PaWgradReduceJob j = jobs[blockIdx.y];
+__device__ __forceinline__ void wgrad_reduce_body(const PaWgradReduceJob j) {
     const int K = j.taps * j.Cin;
     const int total = j.real_cout * j.real_cin * j.taps;
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total + j.real_cout; e += gridDim.x * blockDim.x) {
@@ -362,6 +361,28 @@ __global__ void wgrad_reduce_kernel(const PaWgradReduceJob* jobs) {
             j.dbdst[n] = s;
         }
     }
+}
+
+__global__ void wgrad_reduce_kernel(const PaWgradReduceJob* jobs) {
+    wgrad_reduce_body(jobs[blockIdx.y]);
+}
+
+// the same reduction for an arbitrary set of <= PA_RED_LIST_MAX layers (job indices by value): the slabs of two or three consecutive
+// flushes of weight gradients in one launch (Net::flush_wgrads)
+__global__ void wgrad_reduce_list_kernel(const PaWgradReduceJob* jobs, PaRedList list) {
+    wgrad_reduce_body(jobs[list.idx[blockIdx.y]]);
+}
+
+int pa_launch_wgrad_reduce_list(const PaWgradReduceJob* jobs_dev, const int* idx, int n, int max_elems, hipStream_t st) {
+    if (n <= 0) return 0;
+    if (n > PA_RED_LIST_MAX) { pa_set_error_msg("pa_launch_wgrad_reduce_list: too many jobs"); return 1; }
+    PaRedList list;
+    for (int i = 0; i < PA_RED_LIST_MAX; ++i) list.idx[i] = idx[i < n ? i : 0];
+    int bx = (max_elems + 255) / 256;
+    if (bx > 576) bx = 576;
+    if (bx < 1) bx = 1;
+    hipLaunchKernelGGL(wgrad_reduce_list_kernel, dim3(bx, n), dim3(256), 0, st, jobs_dev, list);
+    return (int)hipGetLastError();
 }
 
 int pa_launch_wgrad_reduce(const PaWgradReduceJob* jobs_dev, int njobs, int max_elems, hipStream_t st) {

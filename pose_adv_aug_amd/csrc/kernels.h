@@ -64,6 +64,9 @@ struct PaWgradReduceJob {
     int Cout, Cin, taps, splits, real_cout, real_cin;
 };
 int pa_launch_wgrad_reduce(const PaWgradReduceJob* jobs_dev, int njobs, int max_elems, hipStream_t st);
+#define PA_RED_LIST_MAX 24
+struct PaRedList { int idx[PA_RED_LIST_MAX]; };
+int pa_launch_wgrad_reduce_list(const PaWgradReduceJob* jobs_dev, const int* idx, int n, int max_elems, hipStream_t st);      // any n <= 24 jobs of the table
 
 // ---- BatchNorm bookkeeping
 // forward: partial rows stats[rows][C][2] (sum, sumsq; over `count` values in total) -> scale/shift/mean/invstd,

@@ -171,6 +171,8 @@ struct Net {
     std::vector<PendingWgrad> pending_wgrads;
     int flush_every = 1, flush_ctr = 0; bool on_side = false;   // main-stream blocks flush every flush_every-th time (PA_WFLUSH_EVERY)
     int flush_wgrads();                        // record on `st`, make wstream wait, launch the collected weight gradients
+    std::vector<int> red_stash; int red_stash_mx = 0, red_stash_flushes = 0;      // reduce-table indices of flushed layers whose slabs are not summed yet
+    int flush_red_stash(hipStream_t ws);       // one reduction launch for the stash
     // hold the weight gradients of an hourglass' high-resolution levels back until its backward pass reaches level `hold_level`
     // (the low-resolution stretch, where the main chain leaves the GPU almost empty): 0 = off
     int hold_level = 0; bool hold = false;

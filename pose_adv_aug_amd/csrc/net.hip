@@ -16,6 +16,7 @@ static int ablate() { static int v = -1; if (v < 0) { const char* e = pa_getenv(
 static int ablate_h() { static int v = -1; if (v < 0) { const char* e = pa_getenv("PA_ABLATE_H"); v = e ? atoi(e) : 8; } return v; }
 #define PA_STEM_ON_MAIN_DEFAULT 1
 #define PA_WG_GROUP_CAP_DEFAULT 256
+#define PA_WREDUCE_LAG_DEFAULT 2
 #define TRY(x) do { int _r = (x); if (_r) return _r; } while (0)
 
 PaOperand pa_plain(const bf16* p) { PaOperand o; o.p = p; o.q = nullptr; o.k0 = o.k1 = o.k2 = nullptr; o.mode = PA_LD_PLAIN; return o; }
@@ -512,6 +513,14 @@ int Net::release_held(int k) {
     return flush_wgrads();
 }
 
+int Net::flush_red_stash(hipStream_t ws) {
+    red_stash_flushes = 0;
+    if (red_stash.empty()) return 0;
+    const int rc = pa_launch_wgrad_reduce_list(red_jobs, red_stash.data(), (int)red_stash.size(), red_stash_mx, ws);
+    red_stash.clear(); red_stash_mx = 0;
+    return rc;
+}
+
 int Net::flush_wgrads() {
     if (pending_wgrads.empty() || hold) return 0;
     const bool ms = multi_stream && wstream;
@@ -582,22 +591,19 @@ int Net::flush_wgrads() {
             }
         }
     }
-    if (ms && reduce_early && !immediate_reduce && !(ablate() & 1)) {                    // the group's slabs are summed while they are still in the Infinity Cache (single-stream mode: reduce_grads() sums everything at the end)
-        int lo = 1 << 30, hi = -1, cnt = 0, mx = 0;
+    if (ms && reduce_early && !immediate_reduce && !(ablate() & 1)) {
+        // the slabs of this flush join the stash; the stash is summed every `lag`-th flush (one launch for the layers of two or three
+        // blocks: 41 reduction launches per step were 0.3 - 0.6 ms of the weight-gradient queue), part of them still in the Infinity Cache
+        static int lag = -1;
+        if (lag < 0) { const char* e = pa_getenv("PA_WREDUCE_LAG"); lag = e ? atoi(e) : PA_WREDUCE_LAG_DEFAULT; if (lag < 1) lag = 1; }
         for (PendingWgrad& p : pending_wgrads) {
-            if (p.stem) {
-                TRY(pa_launch_stem_wgrad_reduce(p.c->part, p.c->splits, grads + p.c->p_w, ws, grads + p.c->p_b));
-                continue;
-            }
-            const int ri = p.c->red_index, el = p.c->Cout * p.c->Cin * p.c->taps() + p.c->Cout;
-            lo = ri < lo ? ri : lo; hi = ri > hi ? ri : hi; ++cnt; mx = el > mx ? el : mx;
+            if (p.stem) { TRY(pa_launch_stem_wgrad_reduce(p.c->part, p.c->splits, grads + p.c->p_w, ws, grads + p.c->p_b)); continue; }
+            const int el = p.c->Cout * p.c->Cin * p.c->taps() + p.c->Cout;
+            if ((int)red_stash.size() == PA_RED_LIST_MAX) TRY(flush_red_stash(ws));
+            red_stash.push_back(p.c->red_index);
+            red_stash_mx = el > red_stash_mx ? el : red_stash_mx;
         }
-        if (cnt > 0 && hi - lo + 1 == cnt) {
-            TRY(pa_launch_wgrad_reduce(red_jobs + lo, cnt, mx, ws));
-        } else {
-            for (PendingWgrad& p : pending_wgrads)
-                if (!p.stem) TRY(pa_launch_wgrad_reduce(red_jobs + p.c->red_index, 1, p.c->Cout * p.c->Cin * p.c->taps() + p.c->Cout, ws));
-        }
+        if (++red_stash_flushes >= lag || n_w > 1) TRY(flush_red_stash(ws));          // (several weight-gradient streams, tuning builds: no lag across streams)
     }
     pending_wgrads.clear();
     return 0;
@@ -1007,6 +1013,7 @@ int Net::mark_bucket(int stack) {
         bucket_events = true;
     }
     TRY(flush_wgrads());
+    if (multi_stream && wstream) TRY(flush_red_stash(wstreams[(w_rr + n_w - 1) % n_w]));
     if (multi_stream && wstream && (reduce_early || immediate_reduce)) {
         PA_CHECK(hipEventRecord(ev_bucket_main, st));
         for (int i = 0; i < n_w; ++i) PA_CHECK(hipStreamWaitEvent(wstreams[i], ev_bucket_main, 0));
@@ -1069,6 +1076,7 @@ void Net::release_graph() {
 
 int Net::reduce_grads() {
     TRY(flush_wgrads());
+    if (multi_stream && wstream) TRY(flush_red_stash(wstreams[(w_rr + n_w - 1) % n_w]));
     if (multi_stream && wstream) {              // all weight-gradient slabs are complete
         if (!(nosync() && (g_nosync & 8))) {
             for (int i = 0; i < n_w; ++i) {
