@@ -99,7 +99,8 @@ struct Residual {
     void layout(Net& n, Arena& a, int B, int H, int W, bool need_grad);
     int fwd(Net& n, const Act& in);
     int bwd(Net& n, const Act& in, const PaOperand& extra, bool in_needs_grad);
-    int bwd_a(Net& n, const Act& in);                                  // everything except the input gradient
+    int bwd_a(Net& n, const Act& in, const PaOperand* extra = nullptr);    // everything except the input gradient (extra: known already -- lets the adapter's data gradient start early)
+    bool ad_forked = false;                                            // the adapter's data gradient of this backward pass runs on the side stream
     int bwd_b(Net& n, const Act& in, const PaOperand& extra);           // input gradient (needs `extra`)
 };
 
@@ -155,6 +156,14 @@ struct Net {
     int n_side = 1;
     int fork_mask = 0xF;                       // bit k: hourglass level k forks its skip block (PA_FORK_LEVELS)
     bool forks(int k) const { return multi_stream && ((fork_mask >> k) & 1); }
+    // adapter convolutions of residual1 / residual3 on the side stream beside the block's main path (only outside a side branch, with the
+    // streams on).  Measured round 5: 5.917 vs 5.892 ms with them on the main chain (three interleaved pairs) -- the two event pairs per
+    // block cost more than the 38 + 78 us of hidden kernels return beside the weight-gradient queue; OFF, switch in tuning builds
+    bool adapter_parallel() const {
+        static int on = -1;
+        if (on < 0) { const char* e = pa_getenv("PA_ADAPTER_PAR"); on = e ? atoi(e) : 0; }
+        return on && multi_stream && side[0] != nullptr && !on_side;
+    }
     // weight-gradient launches only feed the slab reducer at the end of the backward pass: they run on their own
     // stream behind an event recorded where their operands are final, off the dgrad / BatchNorm critical chain
     hipStream_t wstream = nullptr;

@@ -639,15 +639,31 @@ template <class... A> static int c_heat_grad(Net& n, const float* heat, const do
 }
 
 // ------------------------------------------------------------------------------------------------
+// a scope whose launches go to stream `s` (a side branch)
+struct StreamScope {
+    Net& n; hipStream_t saved; bool saved_side;
+    StreamScope(Net& n_, hipStream_t s) : n(n_), saved(n_.st), saved_side(n_.on_side) { n.st = s; n.on_side = true; }
+    ~StreamScope() { n.st = saved; n.on_side = saved_side; }
+};
+
 // residual block (reference :30-49): x1 = conv1(a), x2 = conv3x3(relu bn1 x1), x3 = conv3(relu bn2 x2) + shortcut
 int Residual::fwd(Net& n, const Act& in) {
     const int B = in.B, H = in.H, W = in.W;
     // x1 / x2 have ONE reader each (conv2 / conv3): at the low-resolution levels their BatchNorm finalize runs in that reader's prologue
     const bool d1 = (n.fin_mask & 1) && n.fin_consumer_ok(c2, B, H, W, false), d2 = (n.fin_mask & 1) && n.fin_consumer_ok(c3, B, H, W, false);
+    // the adapter (residual1, residual3: in front of the hourglasses, the side stream is idle) depends on the block input only: it runs
+    // on the side stream beside conv1 / conv2 instead of between conv2 and conv3 on the main chain
+    const bool ad_par = has_adapter && n.adapter_parallel() ;
+    if (ad_par) {
+        TRY(n.fork_to(0));
+        { StreamScope sc(n, n.side[0]); TRY(n.conv_fwd(ad, n.op(in), B, H, W, pa_none(), pa_none(), adout, nullptr)); }
+        TRY(n.record_join(0));
+    }
     TRY(n.conv_fwd(c1, n.op(in), B, H, W, pa_none(), pa_none(), x1.raw, &b1, nullptr, d1));
     TRY(n.conv_fwd(c2, n.op(x1), B, H, W, pa_none(), pa_none(), x2.raw, &b2, &b1, d2));
     if (has_adapter) {
-        TRY(n.conv_fwd(ad, n.op(in), B, H, W, pa_none(), pa_none(), adout, nullptr));
+        if (ad_par) TRY(n.wait_join(0));
+        else TRY(n.conv_fwd(ad, n.op(in), B, H, W, pa_none(), pa_none(), adout, nullptr));
         TRY(n.conv_fwd(c3, n.op(x2), B, H, W, pa_plain(adout), pa_none(), x3.raw, &b3, &b2));
     } else {
         TRY(n.conv_fwd(c3, n.op(x2), B, H, W, n.op(in), pa_none(), x3.raw, &b3, &b2));
@@ -658,7 +674,7 @@ int Residual::fwd(Net& n, const Act& in) {
 // precondition: x3.grad holds the finished masked gradient and finish_grad(x3) has run.
 // bwd = bwd_a (parameter gradients and the inner data gradients) + bwd_b (gradient of the block input, the only
 // part that needs `extra`, the gradient arriving at the input from its other consumers)
-int Residual::bwd_a(Net& n, const Act& in) {
+int Residual::bwd_a(Net& n, const Act& in, const PaOperand* extra) {
     const int B = in.B, H = in.H, W = in.W;
     // conv3's data gradient goes first: its kernel also stores dz3 = BatchNorm-backward(x3.grad, x3.raw), and the weight
     // gradients / the shortcut addend after it read that one tensor instead of recomputing it from two
@@ -667,6 +683,15 @@ int Residual::bwd_a(Net& n, const Act& in) {
     dz3_valid = false;
     TRY(n.conv_dgrad(c3, g3, B, H, W, pa_none(), pa_none(), n.final_ep(x2), x2.grad, dz3, &dz3_valid, x3.bn));
     if (dz3_valid) g3 = pa_plain(dz3);
+    // the adapter's data gradient needs g3 and the gradient reaching the block input from elsewhere (`extra`) only: beside conv2's data
+    // gradient on the side stream when both are known here (residual1 / residual3: no other consumer of the input)
+    ad_forked = false;
+    if (has_adapter && extra && n.adapter_parallel()) {
+        TRY(n.fork_to(0));
+        { StreamScope sc(n, n.side[0]); TRY(n.conv_dgrad(ad, g3, B, H, W, *extra, pa_none(), ep_plain(), adgrad)); }
+        TRY(n.record_join(0));
+        ad_forked = true;
+    }
     TRY(n.conv_wgrad(c3, g3, n.op(x2), B, H, W));
     // (x2's BatchNorm-backward constants are first read by conv2's data gradient, which can compute them in its prologue; conv2's
     // weight gradient, on the weight-gradient stream, is launched behind it)
@@ -690,7 +715,8 @@ int Residual::bwd_b(Net& n, const Act& in, const PaOperand& extra) {
     const int B = in.B, H = in.H, W = in.W;
     const PaOperand g3 = dz3_valid ? pa_plain(dz3) : n.gradop(x3), g1 = n.gradop(x1);
     if (has_adapter) {
-        TRY(n.conv_dgrad(ad, g3, B, H, W, extra, pa_none(), ep_plain(), adgrad));
+        if (ad_forked) { TRY(n.wait_join(0)); ad_forked = false; }
+        else TRY(n.conv_dgrad(ad, g3, B, H, W, extra, pa_none(), ep_plain(), adgrad));
         TRY(n.conv_dgrad(c1, g1, B, H, W, pa_plain(adgrad), pa_none(), n.final_ep(in), in.grad));
     } else {
         TRY(n.conv_dgrad(c1, g1, B, H, W, g3, extra, n.final_ep(in), in.grad));
@@ -699,7 +725,7 @@ int Residual::bwd_b(Net& n, const Act& in, const PaOperand& extra) {
 }
 
 int Residual::bwd(Net& n, const Act& in, const PaOperand& extra, bool in_needs_grad) {
-    TRY(bwd_a(n, in));
+    TRY(bwd_a(n, in, in_needs_grad ? &extra : nullptr));
     return in_needs_grad ? bwd_b(n, in, extra) : 0;
 }
 
@@ -707,11 +733,6 @@ int Residual::bwd(Net& n, const Act& in, const PaOperand& extra, bool in_needs_g
 // hourglass (reference :139-157 down path, :192-203 up path)
 // The skip branch of level k (a full-resolution residual block) does not depend on the low-resolution path
 // below it: it is enqueued on side stream k and joined where its result is consumed.
-struct StreamScope {
-    Net& n; hipStream_t saved; bool saved_side;
-    StreamScope(Net& n_, hipStream_t s) : n(n_), saved(n_.st), saved_side(n_.on_side) { n.st = s; n.on_side = true; }
-    ~StreamScope() { n.st = saved; n.on_side = saved_side; }
-};
 
 int Hourglass::encode(Net& n, const Act& in) {
     const Act* cur = &in;
