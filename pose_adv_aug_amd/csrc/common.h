@@ -61,6 +61,14 @@ inline const char* pa_getenv(const char*) { return nullptr; }
 #define PA_STAMP_AT(sym, on, i) do { } while (0)
 #endif
 
+// wave priority of the main chain's convolution kernels (s_setprio: instruction-issue arbitration between the waves of a SIMD; the
+// weight-gradient group kernels that share CUs with them stay at 0).  Measured round 5, 8 interleaved runs each: 5.857 ms at 0, 5.836 at 2,
+// 5.838 at 3 (-DPA_MAIN_PRIO=n in PA_EXTRA; 0 = no instruction)
+#ifndef PA_MAIN_PRIO
+#define PA_MAIN_PRIO 2
+#endif
+#define PA_SET_MAIN_PRIO() do { if (PA_MAIN_PRIO > 0) __builtin_amdgcn_s_setprio(PA_MAIN_PRIO); } while (0)
+
 void pa_set_error(const char* what, hipError_t e, const char* file, int line);
 void pa_set_error_msg(const char* msg);
 

@@ -61,6 +61,7 @@ __global__ __launch_bounds__(256, (((CIN == 128 || KS == 32) && BM == 64) || (CI
     const int m0 = blockIdx.x * BM;
     const int nb0 = blockIdx.y * nb_per_wg;
     const int nit = nb_per_wg * KT;
+    PA_SET_MAIN_PRIO();
     PA_STAMPT(0);
 
     // ---- weight slices: iteration it -> n-block nb0 + it / KT, k-slice it % KT

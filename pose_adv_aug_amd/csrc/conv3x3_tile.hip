@@ -71,6 +71,7 @@ PA_STAMP_DECL(pa_conv3_clk, pa_debug_conv3_clocks)
 template <int CIN, int BN, int LDMODE, int TW = 16, int TH = 8, int SPS = 1, bool PF = false, int NT = 256, bool FIN = false>
 __global__ __launch_bounds__(NT, (NT >= 512 ? 1 : (TW == 16 ? (TH == 4 ? (SPS == 1 ? 3 : 2) : 2) : 1))) void conv3x3_tile_kernel(PaConvArgs a) {
     constexpr bool TRI = NT == 512 && TW == 16 && TH == 8;
+    PA_SET_MAIN_PRIO();
     PA_STAMP(0);
 #if defined(PA_TUNING) && !defined(PA_CONV3_CONSTDBG)      // (PA_EXTRA=-DPA_CONV3_CONSTDBG: the release code with the cycle stamps only)
     const int dbg = a.dbg;

@@ -215,6 +215,7 @@ __global__ __launch_bounds__(256, FIN ? 2 : 1) void conv_igemm_kernel(PaConvArgs
 // (the MFMA accumulation order over K is unchanged).
 template <int NK, int LDMODE, bool FIN>
 __global__ __launch_bounds__(256, 2) void conv1x1_oneshot_kernel(PaConvArgs a) {
+    PA_SET_MAIN_PRIO();
     PA_STAMP1(0);
     constexpr int BM = 64, BN = 64, AI = 2, BI = 2, MI = 2, NI = 2;
     __shared__ __attribute__((aligned(16))) bf16 lds[(BM + BN) * 64 * NK];
