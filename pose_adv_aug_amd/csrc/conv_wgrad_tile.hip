@@ -25,6 +25,18 @@
 #define PA_WG_GROUP_DEFAULT 1
 #define PA_WGRAD_MINPER1_DEFAULT 1
 #define PA_WGRAD_MINPER9_DEFAULT 1
+// operand loads / slab stores of the weight gradients: PA_WG_NT = 1 marks them non-temporal (streamed once: do not keep them in L2 / the
+// Infinity Cache, where the main chain's freshly produced tensors live)
+#ifndef PA_WG_NT
+#define PA_WG_NT 0
+#endif
+#if PA_WG_NT
+#define PA_WG_LOAD(p) __builtin_nontemporal_load(p)
+#define PA_WG_STORE(p, v) __builtin_nontemporal_store(v, p)
+#else
+#define PA_WG_LOAD(p) (*(p))
+#define PA_WG_STORE(p, v) (*(p) = (v))
+#endif
 #define PA_WG_RT 7            // PMODE / QMODE "decided at run time from the operand" (the grouped kernel: one body per tile shape)
 #define PA_WG_STEM 3          // QMODE of the stem: x is the 4-channel image, gathered as 7x7/2 patches (K = 256)
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -192,8 +204,8 @@ __device__ __forceinline__ void wgrad_tile_body(const PaWgradArgs& a, int ntiles
                 if (TAPS == 9) { m = (b * a.H + y0 + (r >> 4)) * a.W + x0 + (r & 15); ok = true; }
                 else { m = tile * 128 + r; ok = m < M; }
                 const size_t idx = ok ? (size_t)m * a.Cout + n0 + nchunk * 8 : 0;
-                rp[u] = *reinterpret_cast<const bf16x8*>(a.dy.p + idx);
-                if (LIN2) rq[u] = *reinterpret_cast<const bf16x8*>(a.dy.q + idx);
+                rp[u] = PA_WG_LOAD(reinterpret_cast<const bf16x8*>(a.dy.p + idx));
+                if (LIN2) rq[u] = PA_WG_LOAD(reinterpret_cast<const bf16x8*>(a.dy.q + idx));
             }
             if constexpr (STEM) {
                 // 7x7 stride-2 stem (see the plain form below): the thread's pixel of pass 0 by two divisions per TILE, then walked
@@ -229,7 +241,7 @@ __device__ __forceinline__ void wgrad_tile_body(const PaWgradArgs& a, int ntiles
                     m = (b * a.H + y) * a.W + x;
                 } else { m = tile * 128 + hp; ok = m < M; }
                 const size_t idx = ok ? (size_t)m * a.Cin + c0 + cchunk * 8 : 0;
-                rx[u] = *reinterpret_cast<const bf16x8*>(a.x.p + idx);
+                rx[u] = PA_WG_LOAD(reinterpret_cast<const bf16x8*>(a.x.p + idx));
             }
             }
         };
@@ -336,8 +348,8 @@ __device__ __forceinline__ void wgrad_tile_body(const PaWgradArgs& a, int ntiles
                     if (TAPS == 9) { m = (b * a.H + y0 + (r >> 4)) * a.W + x0 + (r & 15); ok[u] = true; }
                     else { m = tile * 128 + r; ok[u] = m < M; }
                     const size_t idx = ok[u] ? (size_t)m * a.Cout + n0 + nchunk * 8 : 0;      // clamped, unconditional
-                    rp[u] = *reinterpret_cast<const bf16x8*>(a.dy.p + idx);
-                    if (p_lin2) rq[u] = *reinterpret_cast<const bf16x8*>(a.dy.q + idx);
+                    rp[u] = PA_WG_LOAD(reinterpret_cast<const bf16x8*>(a.dy.p + idx));
+                    if (p_lin2) rq[u] = PA_WG_LOAD(reinterpret_cast<const bf16x8*>(a.dy.q + idx));
                 }
 #pragma unroll
                 for (int v = 0; v < UNP; ++v) {
@@ -410,7 +422,7 @@ __device__ __forceinline__ void wgrad_tile_body(const PaWgradArgs& a, int ntiles
                     continue;
                 }
                 const size_t idx = ok[u] ? (size_t)m * a.Cin + c0 + cchunk * 8 : 0;
-                rx[u] = *reinterpret_cast<const bf16x8*>(a.x.p + idx);
+                rx[u] = PA_WG_LOAD(reinterpret_cast<const bf16x8*>(a.x.p + idx));
             }
 #pragma unroll
             for (int u = 0; u < PASS_C; ++u) {
@@ -447,7 +459,7 @@ __device__ __forceinline__ void wgrad_tile_body(const PaWgradArgs& a, int ntiles
 #pragma unroll
             for (int cf = 0; cf < CF; ++cf) {
                 const int c = c0 + (wc * CF + cf) * 16 + (lane >> 4) * 4;
-                *reinterpret_cast<f32x4*>(slab + (size_t)n * Kfull + t * a.Cin + c) = acc[t][cf][f];
+                PA_WG_STORE(reinterpret_cast<f32x4*>(slab + (size_t)n * Kfull + t * a.Cin + c), acc[t][cf][f]);
             }
     }
     if (DB && want_db) {

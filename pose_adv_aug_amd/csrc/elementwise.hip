@@ -5,6 +5,11 @@
 // channel per workgroup.
 #include "common.h"
 #include "kernels.h"
+// wave priority of the main chain's finalize / pooling / upsampling kernels beside the weight-gradient group kernels (priority 0): 5.863 -> 5.842 ms (four interleaved pairs, round 5)
+#ifndef PA_ELT_PRIO
+#define PA_ELT_PRIO 2
+#endif
+#define PA_SET_ELT_PRIO() do { if (PA_ELT_PRIO > 0) __builtin_amdgcn_s_setprio(PA_ELT_PRIO); } while (0)
 #include "bn_fin.h"
 #include <type_traits>
 
@@ -108,6 +113,7 @@ __global__ __launch_bounds__(FT) void bn_finalize_kernel(const float* stats, int
                                                            float* rmean, float* rvar, float* scale, float* shift, float* mean,
                                                            float* invstd, int C, float count, float momentum, float eps,
                                                            int update_running) {
+    PA_SET_ELT_PRIO();
     __shared__ float sums[FC][2];
     const int c0 = blockIdx.x * FC;
     // the channel's parameters are requested BEFORE the reduction (after it they were one more dependent memory round trip of a kernel that
@@ -165,6 +171,7 @@ template <int FT, int FC>
 __global__ __launch_bounds__(FT) void bn_bwd_finalize_kernel(const float* bstats, int rows, const float* scale, const float* mean,
                                                                const float* invstd, float* kA, float* kB, float* kC,
                                                                float* dgamma, float* dbeta, int C, float count) {
+    PA_SET_ELT_PRIO();
     __shared__ float sums[FC][2];
     const int c0 = blockIdx.x * FC;
     const bool mine = threadIdx.x < FC && c0 + (int)threadIdx.x < C;
@@ -185,6 +192,7 @@ __global__ __launch_bounds__(FT) void bn_bwd_finalize_kernel(const float* bstats
 struct BwdFinArgs { const float* bstats; int rows; const float* scale; const float* mean; const float* invstd; float *kA, *kB, *kC, *dgamma, *dbeta; int C; float count; };
 template <int FT, int FC>
 __global__ __launch_bounds__(FT) void bn_bwd_finalize2_kernel(BwdFinArgs a0, BwdFinArgs a1) {
+    PA_SET_ELT_PRIO();
     const BwdFinArgs& a = blockIdx.y == 0 ? a0 : a1;
     __shared__ float sums[FC][2];
     const int c0 = blockIdx.x * FC;
@@ -353,6 +361,7 @@ __global__ void maxpool_fwd_kernel(PaOperand in, bf16* out, int B, int H, int W,
 // pixel x 8 channels (4 high-resolution pixels).  Operand modes PLAIN / BNRELU.
 template <int OP, int MA, int MB>
 __global__ __launch_bounds__(256) void pool_up_fwd_s_kernel(PaOperand a, PaOperand b, bf16* __restrict__ out, int rows, int W, int C) {
+    PA_SET_ELT_PRIO();
     // rows = B * H/2 (low-resolution rows); W = high-resolution width
     const int CG = C / 8, Wl = W / 2;
     const unsigned row_items = (unsigned)Wl * CG;
@@ -518,6 +527,7 @@ __global__ __launch_bounds__(1024) void maxpool_bwd_kernel(const bf16* dout, PaO
 template <int INMODE, bool HASADD, int EPMODE>
 __global__ __launch_bounds__(1024) void maxpool_bwd_s_kernel(const bf16* __restrict__ dout, PaOperand in, const bf16* __restrict__ add,
                                                              PaEpilogue ep, bf16* __restrict__ din, int rows, int W, int C) {
+    PA_SET_ELT_PRIO();
     extern __shared__ float red[];     // [nwaves][2*C] partial statistics, then constants: float4 {scale, shift, mean, invstd} or float2 {k0, k1}
     float4* cst = reinterpret_cast<float4*>(red + (blockDim.x / 64) * 2 * C);
     float2* kin = reinterpret_cast<float2*>(cst + (EPMODE == PA_OUT_BWD ? C : 0));
@@ -717,6 +727,7 @@ __global__ __launch_bounds__(1024) void upadd_bwd_kernel(const bf16* dout, PaEpi
 // issued before the first use, so that a 1024-thread workgroup keeps ~150 KB in flight.
 __global__ __launch_bounds__(1024) void upadd_bwd_bb_kernel(const bf16* __restrict__ dout, PaEpilogue epl, bf16* __restrict__ dlow,
                                                             PaEpilogue eps, bf16* __restrict__ dskip, int rows, int W, int C) {
+    PA_SET_ELT_PRIO();
     // rows = B * H/2 low-resolution rows; row r covers high-resolution rows 2r, 2r+1 (H = 2*Hl: no batch/row split needed).
     // blockDim is a multiple of the items of a row (Wl * C/8) or the other way round (launcher): no per-iteration division.
     extern __shared__ float red[];     // [nwaves][2*C] partial statistics, then the two constant tables
