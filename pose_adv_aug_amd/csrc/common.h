@@ -67,7 +67,10 @@ inline const char* pa_getenv(const char*) { return nullptr; }
 #ifndef PA_MAIN_PRIO
 #define PA_MAIN_PRIO 2
 #endif
-#define PA_SET_MAIN_PRIO() do { if (PA_MAIN_PRIO > 0) __builtin_amdgcn_s_setprio(PA_MAIN_PRIO); } while (0)
+#define PA_SET_MAIN_PRIO() do { if (PA_MAIN_PRIO > 0 && !(PA_SIDE_LOW && a.low_prio)) __builtin_amdgcn_s_setprio(PA_MAIN_PRIO); } while (0)
+#ifndef PA_SIDE_LOW
+#define PA_SIDE_LOW 0          // 1: launches marked low_prio (side branches) stay at priority 0
+#endif
 
 void pa_set_error(const char* what, hipError_t e, const char* file, int line);
 void pa_set_error_msg(const char* msg);

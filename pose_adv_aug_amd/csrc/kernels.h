@@ -15,6 +15,7 @@ struct PaConvArgs {
     bf16* dz_out;        // optional (1x1 row-tile kernel, LIN2 input): the transformed input tile is also stored here [M][Cin] --
                          // later consumers of the same BatchNorm-backward gradient read ONE tensor instead of recomputing it from two
     PaBnFin fin;         // pending BatchNorm finalize of `in`, done in the kernel's prologue (fin.rows > 0; only launches pa_conv_takes_fin() admits)
+    int low_prio;        // != 0: a launch of a side branch (skip blocks beside the main chain): the kernel keeps wave priority 0 instead of PA_MAIN_PRIO
     int dbg;             // tuning builds only (0 in the release library): conv3x3_tile.hip phase ablation bits 1 / 2 / 4, bit 8 = per-workgroup tap rotation
     int xcd;             // set by the launchers: workgroup i works on tile (i % 8) * (tiles / 8) + i / 8 (one contiguous range per XCD)
 };

@@ -412,7 +412,7 @@ int Net::conv_fwd(ConvLayer& c, const PaOperand& in, int B_, int H, int W, const
                   bf16* out, BNLayer* bn_after, BNLayer* pending_in, bool defer_after) {
     PaConvArgs a; memset(&a, 0, sizeof a);
     if (pending_in && pending_in->fin_pending) { a.fin = fin_fwd(*pending_in, B_ * H * W); pending_in->fin_pending = false; }
-    a.in = in; a.w = c.wf; a.bias = params + c.p_b; a.add1 = add1; a.add2 = add2; a.out = out;
+    a.in = in; a.w = c.wf; a.bias = params + c.p_b; a.add1 = add1; a.add2 = add2; a.out = out; a.low_prio = on_side ? 1 : 0;
     a.B = B_; a.H = H; a.W = W; a.Cin = c.pcin; a.Cout = c.pcout; a.taps = c.k == 7 ? 1 : c.taps();
     a.ep = ep_plain();
     if (bn_after && train_bn) { a.ep.mode = PA_OUT_STATS; a.ep.stats = bn_after->stats; a.ep.rows_out = &bn_after->stat_rows; }
@@ -437,7 +437,7 @@ int Net::conv_dgrad(ConvLayer& c, const PaOperand& dy, int B_, int H, int W, con
                     const PaEpilogue& ep, bf16* out, bf16* dz_out, bool* dz_done, BNLayer* pending_in) {
     PaConvArgs a; memset(&a, 0, sizeof a);
     if (pending_in && pending_in->bfin_pending) { a.fin = fin_bwd(*pending_in, B_ * H * W); pending_in->bfin_pending = false; }
-    a.in = dy; a.w = c.wb; a.bias = nullptr; a.add1 = add1; a.add2 = add2; a.out = out; a.ep = ep;
+    a.in = dy; a.w = c.wb; a.bias = nullptr; a.add1 = add1; a.add2 = add2; a.out = out; a.ep = ep; a.low_prio = on_side ? 1 : 0;
     a.B = B_; a.H = H; a.W = W; a.Cin = c.pcout; a.Cout = c.pcin; a.taps = c.taps();
     if (dz_done) *dz_done = false;
     if (dz_out && dy.mode == PA_LD_LIN2) {         // only the 1x1 row-tile kernel stores its transformed input

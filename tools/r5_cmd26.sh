@@ -5,5 +5,5 @@ l = [l for l in sys.stdin if l.startswith('{')]
 print(json.loads(l[0])['ms_per_step'] if l else 'FAILED')"; }
 for i in 1 2 3 4; do
   echo -n "base:   "; (cd $GRAFT_REPO_ROOT/tune; one)
-  echo -n "elt p2: "; (cd $GRAFT_REPO_ROOT/tune_p; one)
+  echo -n "sidelo: "; (cd $GRAFT_REPO_ROOT/tune_p; one)
 done
