@@ -171,6 +171,26 @@ size_t pa_conv2d_workspace_bytes(int B, int Cin, int Cout, int H, int W, int k);
 int pa_conv2d(int mode, const float* a_in, const float* b_in, const float* w, const float* bias, float* out, float* out2,
               int B, int Cin, int Cout, int H, int W, int k, void* ws, void* stream);
 
+/* Several INDEPENDENT weight gradients the way the training step submits them (the conv1 / conv2 / conv3 / adapter gradients of one
+ * _Residual, models/asn_stacked_hg.py:17-24, wait for one event and leave as ONE grouped launch): jobs[j] describes layer j
+ * (device pointers, NCHW fp32 operands, PyTorch-layout fp32 outputs).
+ *   dy_q / dy_k given: the dy operand arrives through the BatchNorm backward, dy_eff = kA[c] dy + kB[c] dy_q + kC[c], dy_k = [3][Cout]
+ *   x_k given        : the x operand arrives through BatchNorm + ReLU,        x_eff  = max(0, k0[c] x + k1[c]),     x_k  = [2][Cin]
+ *   db               : bias gradient (1x1 layers only) or NULL
+ * mode 0: every layer as a launch of its own; 1: one grouped launch (jobs ordered longest first, as the step does); 2: one grouped
+ * launch with the jobs in the caller's order.  Modes 1 / 2 return 2 when a job is not a shape / operand mode the grouped kernel takes
+ * (3x3: Cin, Cout % 64 == 0, H % 8 == 0, W % 16 == 0, >= 48 tiles of 8 x 16 pixels, x through BatchNorm + ReLU; 1x1: >= 3 tiles of 128 pixels).
+ * ws: pa_wgrad_group_workspace_bytes() bytes. */
+#define PA_WG_GROUP_MAX 8
+typedef struct pa_wgrad_job {
+    int B, Cin, Cout, H, W, k;
+    const float* dy;   const float* dy_q; const float* dy_k;
+    const float* x;    const float* x_k;
+    float* dw;         float* db;
+} pa_wgrad_job;
+size_t pa_wgrad_group_workspace_bytes(const pa_wgrad_job* jobs, int njobs);
+int pa_wgrad_group(const pa_wgrad_job* jobs, int njobs, int mode, void* ws, void* stream);
+
 /* NCHW fp32 <-> NHWC bf16 */
 int pa_nchw_to_nhwc(const float* src, void* dst_bf16, int B, int C, int H, int W, void* stream);
 int pa_nhwc_to_nchw(const void* src_bf16, float* dst, int B, int C, int H, int W, void* stream);

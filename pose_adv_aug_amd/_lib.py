@@ -133,6 +133,8 @@ _PROTOS = {
     'pa_net_design_bytes': (_i, [_vp, C.POINTER(C.c_double)]),
     'pa_copy_probe': (_i, [_vp, _vp, _sz, _vp]),
     'pa_net_set_fin_prologue': (_i, [_vp, _i]),
+    'pa_wgrad_group_workspace_bytes': (_sz, [_vp, _i]),
+    'pa_wgrad_group': (_i, [_vp, _i, _i, _vp, _vp]),
     'pa_conv2d_time': (_i, [_i] * 9 + [_vp, C.POINTER(C.c_float), _vp]),
     'pa_net_profile_classes': (_i, [_vp, C.POINTER(C.c_int32), _i]),
     'pa_net_set_multi_stream': (_i, [_vp, _i]),

@@ -249,6 +249,94 @@ int pa_conv2d(int mode, const float* a_in, const float* b_in, const float* w, co
     return 0;
 }
 
+// ---------------------------------------------------------------------------- grouped weight gradients
+// n <= 8 INDEPENDENT weight gradients (the three or four of a residual block, reference models/asn_stacked_hg.py:17-24) as the training
+// step submits them: ONE wgrad_group_kernel launch (conv_wgrad_tile.hip) + the slab reduction -- or, for comparison, the same layers
+// launched one by one.  The operator-level door to the group kernel for the parity tests (tests/test_gpu_conv.py).
+struct WgradGroupOp {
+    Net n; ConvLayer c[PA_WG_GROUP_MAX]; bf16 *dy[PA_WG_GROUP_MAX], *dyq[PA_WG_GROUP_MAX], *x[PA_WG_GROUP_MAX];
+    float *pbuf = nullptr, *gbuf = nullptr;
+    size_t build(const pa_wgrad_job* jobs, int nj, char* base) {
+        Arena a; a.base = base;
+        n.prep_jobs = a.get<PaPrepJob>(nj); n.red_jobs = a.get<PaWgradReduceJob>(nj); n.bneval_jobs = a.get<PaBnEvalJob>(1);
+        for (int j = 0; j < nj; ++j) {
+            const pa_wgrad_job& q = jobs[j];
+            n.B = q.B;                                      // (layout_conv picks the grouped split count for M == B * H * W)
+            n.layout_conv(c[j], a, q.B * q.H * q.W, q.H, q.W);
+            const size_t M = (size_t)q.B * q.H * q.W;
+            dy[j] = a.get<bf16>(M * c[j].pcout);
+            dyq[j] = q.dy_q ? a.get<bf16>(M * c[j].pcout) : nullptr;
+            x[j] = a.get<bf16>(M * c[j].pcin);
+        }
+        pbuf = a.get<float>(n.n_params + 8);
+        gbuf = a.get<float>(n.n_params + 8);
+        n.layout_shared(a);
+        a.take(0);
+        return a.off;
+    }
+    int declare(const pa_wgrad_job* jobs, int nj) {
+        if (nj < 1 || nj > PA_WG_GROUP_MAX) { pa_set_error_msg("pa_wgrad_group: 1 .. 8 jobs"); return 1; }
+        n.is_agent = true;
+        for (int j = 0; j < nj; ++j) {
+            const pa_wgrad_job& q = jobs[j];
+            if (q.Cin % 64 || q.Cout % 64 || (q.k != 1 && q.k != 3) || q.B < 1 || q.H < 1 || q.W < 1) { pa_set_error_msg("pa_wgrad_group: channels % 64 == 0, k in {1,3}"); return 1; }
+            if ((q.dy_q == nullptr) != (q.dy_k == nullptr)) { pa_set_error_msg("pa_wgrad_group: dy_q and dy_k come together"); return 1; }
+            char name[16]; snprintf(name, sizeof name, "j%d", j);
+            n.declare_conv(c[j], name, q.Cin, q.Cout, q.k, q.db == nullptr);
+        }
+        return 0;
+    }
+};
+
+size_t pa_wgrad_group_workspace_bytes(const pa_wgrad_job* jobs, int njobs) {
+    g_err[0] = 0;
+    WgradGroupOp op;
+    if (op.declare(jobs, njobs)) return 0;
+    return op.build(jobs, njobs, nullptr);
+}
+
+int pa_wgrad_group(const pa_wgrad_job* jobs, int njobs, int mode, void* ws, void* s) {
+    g_err[0] = 0;
+    WgradGroupOp op; Net& n = op.n;
+    TRY(op.declare(jobs, njobs));
+    n.st = ST(s);
+    op.build(jobs, njobs, reinterpret_cast<char*>(ws));
+    PA_CHECK(hipMemsetAsync(op.gbuf, 0, (n.n_params + 8) * sizeof(float), n.st));
+    n.params = op.pbuf; n.grads = op.gbuf; n.buffers = op.pbuf;
+    TRY(n.upload_tables());
+    PaWgradArgs args[PA_WG_GROUP_MAX]; const PaWgradArgs* ptrs[PA_WG_GROUP_MAX];
+    for (int j = 0; j < njobs; ++j) {
+        const pa_wgrad_job& q = jobs[j];
+        ConvLayer& c = op.c[j];
+        TRY(pa_launch_nchw_f32_to_nhwc_bf16(q.dy, op.dy[j], q.B, q.Cout, q.H, q.W, n.st));
+        if (q.dy_q) TRY(pa_launch_nchw_f32_to_nhwc_bf16(q.dy_q, op.dyq[j], q.B, q.Cout, q.H, q.W, n.st));
+        TRY(pa_launch_nchw_f32_to_nhwc_bf16(q.x, op.x[j], q.B, q.Cin, q.H, q.W, n.st));
+        PaWgradArgs& a = args[j]; memset(&a, 0, sizeof a);
+        a.dy = pa_plain(op.dy[j]);
+        if (q.dy_q) { a.dy.mode = PA_LD_LIN2; a.dy.q = op.dyq[j]; a.dy.k0 = q.dy_k; a.dy.k1 = q.dy_k + q.Cout; a.dy.k2 = q.dy_k + 2 * q.Cout; }
+        a.x = pa_plain(op.x[j]);
+        if (q.x_k) { a.x.mode = PA_LD_BNRELU; a.x.k0 = q.x_k; a.x.k1 = q.x_k + q.Cin; }
+        a.part = c.part; a.dbpart = c.dbpart;
+        a.B = q.B; a.H = q.H; a.W = q.W; a.Cin = c.pcin; a.Cout = c.pcout; a.taps = c.taps(); a.splits = c.splits;
+        ptrs[j] = &a;
+    }
+    if (mode == 0) {
+        for (int j = 0; j < njobs; ++j) TRY(pa_launch_wgrad(args[j], n.st));
+    } else {
+        for (int j = 0; j < njobs; ++j)
+            if (!pa_wgrad_group_takes(args[j])) { pa_set_error_msg("pa_wgrad_group: a job the grouped kernel does not take (shape / operand modes)"); return 2; }
+        TRY(pa_launch_wgrad_group(ptrs, njobs, n.st, mode == 2));
+    }
+    TRY(pa_launch_wgrad_reduce(n.red_jobs, n.n_red, n.red_max, n.st));
+    for (int j = 0; j < njobs; ++j) {
+        const pa_wgrad_job& q = jobs[j];
+        PA_CHECK(hipMemcpyAsync(q.dw, op.gbuf + op.c[j].p_w, (size_t)q.Cout * q.Cin * q.k * q.k * sizeof(float), hipMemcpyDeviceToDevice, n.st));
+        if (q.db) PA_CHECK(hipMemcpyAsync(q.db, op.gbuf + op.c[j].p_b, q.Cout * sizeof(float), hipMemcpyDeviceToDevice, n.st));
+    }
+    PA_CHECK(hipStreamSynchronize(n.st));
+    return 0;
+}
+
 // micro-benchmark of ONE conv launch (tools/bench_conv.py): variant bits select what the launch does
 //   bit0: input transform BNRELU (fwd) / LIN2 (dgrad, wgrad dy)      bit1: epilogue STATS (fwd) / BWD (dgrad)
 //   bit2: one residual addend                                         bit3 (wgrad): x operand BNRELU

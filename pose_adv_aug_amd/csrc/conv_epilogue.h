@@ -399,6 +399,9 @@ __device__ __forceinline__ void pa_conv_epilogue_lds_bwd(const PaConvArgs& a, f3
                 const int m = pix(r >> 4, g + pp, r & 15);
                 ok[it] = m >= 0;
                 idx[it] = ok[it] ? (unsigned)m * (unsigned)N + (unsigned)n : 0u;
+#ifdef PA_TUNING
+                if (a.dbg & 16) { xr[it] = bf16x8{}; p1[it] = bf16x8{}; q1[it] = bf16x8{}; p2[it] = bf16x8{}; continue; }      // (timing bound, wrong results: the epilogue without its operand round trip)
+#endif
                 xr[it] = *reinterpret_cast<const bf16x8*>(a.ep.xref + idx[it]);
                 if (m1 != PA_LD_NONE) p1[it] = *reinterpret_cast<const bf16x8*>(a.add1.p + idx[it]);
                 if (m1 == PA_LD_LIN2) q1[it] = *reinterpret_cast<const bf16x8*>(a.add1.q + idx[it]);

@@ -12,6 +12,7 @@
 // fp32 partial slab that pa_launch_wgrad_reduce sums into the PyTorch-layout gradient.
 #include "common.h"
 #include "kernels.h"
+#include "wgrad_reduce.h"
 #include <stdlib.h>
 
 // STEM: x is the 4-channel-padded image and the 'channels' are the 256 (ky*32+kx*4+c) patch
@@ -306,71 +307,15 @@ int pa_launch_wgrad(const PaWgradArgs& a, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// sum the split slabs and scatter into PyTorch layout  dst[n][c][tap]   (one job per conv layer)
-__device__ __forceinline__ void wgrad_reduce_body(const PaWgradReduceJob j) {
-    const int K = j.taps * j.Cin;
-    const int total = j.real_cout * j.real_cin * j.taps;
-    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total + j.real_cout; e += gridDim.x * blockDim.x) {
-        if (e < total) {
-            // e enumerates the SOURCE order (n, tap, c) so that reads are coalesced
-            const int n = e / (j.taps * j.real_cin);
-            const int r = e - n * j.taps * j.real_cin;
-            const int tap = r / j.real_cin, c = r - tap * j.real_cin;
-            const float* src = j.part + (size_t)n * K + tap * j.Cin + c;
-            // (16 loads in flight per thread: the split counts of the networks are multiples of 16 or small; the sum stays in split order)
-            float s = 0.f;
-            int sp = 0;
-            for (; sp + 16 <= j.splits; sp += 16) {
-                float v[16];
-#pragma unroll
-                for (int u = 0; u < 16; ++u) v[u] = src[(size_t)(sp + u) * j.Cout * K];
-#pragma unroll
-                for (int u = 0; u < 16; ++u) s += v[u];
-            }
-            if (sp < j.splits) {                       // the rest in one more batch (clamped, unconditional loads)
-                float v[16];
-#pragma unroll
-                for (int u = 0; u < 16; ++u) v[u] = src[(size_t)(sp + u < j.splits ? sp + u : sp) * j.Cout * K];
-#pragma unroll
-                for (int u = 0; u < 16; ++u) if (sp + u < j.splits) s += v[u];
-            }
-            j.dst[((size_t)n * j.real_cin + c) * j.taps + tap] = s;
-        } else if (j.dbdst) {
-            const int n = e - total;
-            // (16 loads in flight, the sum in split order: the plain loop compiled to one load per wait -- splits x ~0.9 us, 60 us for the
-            // 16 threads of an output layer's bias while the rest of the launch was long done)
-            float s = 0.f;
-            if (j.dbpart) {
-                const float* src = j.dbpart + n;
-                int sp = 0;
-                for (; sp + 16 <= j.splits; sp += 16) {
-                    float v[16];
-#pragma unroll
-                    for (int u = 0; u < 16; ++u) v[u] = src[(size_t)(sp + u) * j.Cout];
-#pragma unroll
-                    for (int u = 0; u < 16; ++u) s += v[u];
-                }
-                if (sp < j.splits) {
-                    float v[16];
-#pragma unroll
-                    for (int u = 0; u < 16; ++u) v[u] = src[(size_t)(sp + u < j.splits ? sp + u : sp) * j.Cout];
-#pragma unroll
-                    for (int u = 0; u < 16; ++u) if (sp + u < j.splits) s += v[u];
-                }
-            }
-            j.dbdst[n] = s;
-        }
-    }
-}
-
+// sum the split slabs and scatter into PyTorch layout  dst[n][c][tap]   (one job per conv layer): wgrad_reduce.h
 __global__ void wgrad_reduce_kernel(const PaWgradReduceJob* jobs) {
-    wgrad_reduce_body(jobs[blockIdx.y]);
+    wgrad_reduce_body(jobs[blockIdx.y], (int)blockIdx.x, (int)gridDim.x);
 }
 
 // the same reduction for an arbitrary set of <= PA_RED_LIST_MAX layers (job indices by value): the slabs of two or three consecutive
 // flushes of weight gradients in one launch (Net::flush_wgrads)
 __global__ void wgrad_reduce_list_kernel(const PaWgradReduceJob* jobs, PaRedList list) {
-    wgrad_reduce_body(jobs[list.idx[blockIdx.y]]);
+    wgrad_reduce_body(jobs[list.idx[blockIdx.y]], (int)blockIdx.x, (int)gridDim.x);
 }
 
 int pa_launch_wgrad_reduce_list(const PaWgradReduceJob* jobs_dev, const int* idx, int n, int max_elems, hipStream_t st) {

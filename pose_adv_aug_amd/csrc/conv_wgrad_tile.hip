@@ -18,6 +18,7 @@
 // rows touched by a 32-lane half of ds_read_b64_tr_b16 fall into 8 distinct bank groups for any tap shift.
 #include "common.h"
 #include "kernels.h"
+#include "wgrad_reduce.h"
 #include <stdlib.h>
 #include <string.h>
 #include <hip/hip_ext.h>
@@ -493,18 +494,30 @@ __global__ __launch_bounds__(256, PIPE ? OCC : 2) void wgrad_tile_kernel(PaWgrad
 // Plain (two workgroups per CU, <= 244 registers) rather than pipelined bodies: 6.27 vs 6.31 ms per step -- a pipelined workgroup owns its
 // CU's registers, and the main chain's kernels then find no room beside the group.
 #define PA_WG_MAXJOBS 8
+#define PA_WG_RED_WGS_DEFAULT 32
 enum { PA_WGK_9_44 = 0, PA_WGK_9_44L, PA_WGK_1_44, PA_WGK_1_42, PA_WGK_1_24, PA_WGK_1_22, PA_WGK_N };      // 3x3 64 x 64 (n x c) with a plain / BatchNorm-backward dy operand (fixed modes: the 144-accumulator body has no registers to spare for both) | 1x1 128 x 128 | 128 x 64 | 64 x 128 | 64 x 64
 struct PaWgradGroup {
     PaWgradArgs a[PA_WG_MAXJOBS];
     int ntiles[PA_WG_MAXJOBS], S[PA_WG_MAXJOBS], ny[PA_WG_MAXJOBS], kind[PA_WG_MAXJOBS];
-    int begin[PA_WG_MAXJOBS + 1];              // first workgroup of job j (begin[njobs] = grid size)
+    int begin[PA_WG_MAXJOBS + 1];              // first workgroup of job j (begin[njobs] = first workgroup behind the weight-gradient jobs)
     int njobs;
+    // one more job kind (round 6): the slab reduction of EARLIER launches' layers (red_n entries of the reduce table, red_wgs workgroups at the
+    // end of the grid) -- 16 reduction launches per step on the queue that decides the tail of the backward pass become part of the group
+    // launches that follow them; same body, same (split) order of every sum as the launch of its own
+    const PaWgradReduceJob* red_jobs;
+    PaRedList red;
+    int red_n, red_wgs;
 };
 
 __global__ __launch_bounds__(256, 2) void wgrad_group_kernel(PaWgradGroup g) {
     constexpr int L9 = wg_lds_elems<9, 4, 1, 1>(), L1 = wg_lds_elems<1, 4, 4, 2>();
     __shared__ __attribute__((aligned(16))) bf16 lds[L9 > L1 ? L9 : L1];
     const int id = (int)blockIdx.x;
+    if (id >= g.begin[g.njobs]) {                  // the reduction job
+        const int local = id - g.begin[g.njobs];
+        for (int i = 0; i < g.red_n; ++i) wgrad_reduce_body(g.red_jobs[g.red.idx[i]], local, g.red_wgs);
+        return;
+    }
     int j = 0;
 #pragma unroll
     for (int k = 1; k < PA_WG_MAXJOBS; ++k) if (k < g.njobs && id >= g.begin[k]) j = k;
@@ -699,8 +712,9 @@ int pa_wgrad_job_workgroups(const PaWgradArgs& a) {
 }
 
 // n <= PA_WG_MAXJOBS launches that pa_wgrad_group_takes() admitted, in one launch (the longest jobs first: their workgroups start first)
-int pa_launch_wgrad_group(const PaWgradArgs* const* as, int n, hipStream_t st) {
+int pa_launch_wgrad_group(const PaWgradArgs* const* as, int n, hipStream_t st, bool keep_order, const PaWgradReduceJob* red_jobs, const int* red_idx, int red_n) {
     if (n < 1 || n > PA_WG_MAXJOBS) { pa_set_error_msg("pa_launch_wgrad_group: 1 .. 8 jobs"); return 1; }
+    if (red_n < 0 || red_n > PA_RED_LIST_MAX || (red_n > 0 && (!red_jobs || !red_idx))) { pa_set_error_msg("pa_launch_wgrad_group: bad reduction list"); return 1; }
     PaWgradGroup g;
     memset(&g, 0, sizeof g);
     int order[PA_WG_MAXJOBS]; long work[PA_WG_MAXJOBS];
@@ -711,7 +725,7 @@ int pa_launch_wgrad_group(const PaWgradArgs* const* as, int n, hipStream_t st) {
         order[j] = j;
         work[j] = (long)((cs[j].ntiles + as[j]->splits - 1) / as[j]->splits) * (as[j]->taps == 9 ? 3 : 2);      // tiles per workgroup x relative tile cost
     }
-    for (int i = 1; i < n; ++i)                      // insertion sort, descending work
+    for (int i = 1; i < n && !keep_order; ++i)       // insertion sort, descending work
         for (int k = i; k > 0 && work[order[k]] > work[order[k - 1]]; --k) { const int t = order[k]; order[k] = order[k - 1]; order[k - 1] = t; }
     int begin = 0;
     for (int jj = 0; jj < n; ++jj) {
@@ -721,6 +735,13 @@ int pa_launch_wgrad_group(const PaWgradArgs* const* as, int n, hipStream_t st) {
         begin += as[j]->splits * (as[j]->Cout / cs[j].nb) * (as[j]->Cin / cs[j].cb);
     }
     g.begin[n] = begin; g.njobs = n;
+    if (red_n > 0) {
+        static int rw = -1;
+        if (rw < 0) { const char* e = pa_getenv("PA_WG_RED_WGS"); rw = e ? atoi(e) : PA_WG_RED_WGS_DEFAULT; if (rw < 1) rw = 1; }
+        g.red_jobs = red_jobs; g.red_n = red_n; g.red_wgs = rw;
+        for (int i = 0; i < PA_RED_LIST_MAX; ++i) g.red.idx[i] = red_idx[i < red_n ? i : 0];
+        begin += rw;
+    }
     hipLaunchKernelGGL(wgrad_group_kernel, dim3(begin), dim3(256), 0, st, g);
     return (int)hipGetLastError();
 }

@@ -725,6 +725,10 @@ __global__ __launch_bounds__(1024) void upadd_bwd_kernel(const bf16* dout, PaEpi
 // accesses and per-use loads of the per-channel constants serialise their loads.  Here the modes are template parameters,
 // the per-channel constants sit in LDS as float4 {scale, shift, mean, invstd}, and ALL loads of an item (9 x 16 bytes) are
 // issued before the first use, so that a 1024-thread workgroup keeps ~150 KB in flight.
+// LOW / SKIP: which of the two outputs this launch produces.  Both: the one-launch form.  One each: the hourglass' backward pass needs dlow on
+// its main chain (the low-resolution path below) and dskip only on the side stream that runs the skip block's backward pass -- the main
+// chain then waits for 75 MB of traffic instead of 175 (round 6)
+template <bool LOW, bool SKIP>
 __global__ __launch_bounds__(1024) void upadd_bwd_bb_kernel(const bf16* __restrict__ dout, PaEpilogue epl, bf16* __restrict__ dlow,
                                                             PaEpilogue eps, bf16* __restrict__ dskip, int rows, int W, int C) {
     PA_SET_ELT_PRIO();
@@ -733,8 +737,8 @@ __global__ __launch_bounds__(1024) void upadd_bwd_bb_kernel(const bf16* __restri
     extern __shared__ float red[];     // [nwaves][2*C] partial statistics, then the two constant tables
     float4* cl = reinterpret_cast<float4*>(red + (blockDim.x / 64) * 2 * C);
     float4* cs = cl + C;
-    stage_bwd_consts(cl, epl, C);
-    stage_bwd_consts(cs, eps, C);
+    if (LOW) stage_bwd_consts(cl, epl, C);
+    if (SKIP) stage_bwd_consts(cs, eps, C);
     __syncthreads();
     const int CG = C / 8, Wl = W / 2;
     const unsigned row_items = (unsigned)Wl * CG;
@@ -762,9 +766,10 @@ __global__ __launch_bounds__(1024) void upadd_bwd_bb_kernel(const bf16* __restri
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 g[k] = *reinterpret_cast<const bf16x8*>(dout + off[k]);
-                xs[k] = *reinterpret_cast<const bf16x8*>(xsk + off[k]);
+                if (SKIP) xs[k] = *reinterpret_cast<const bf16x8*>(xsk + off[k]);
             }
-            const bf16x8 xlow = *reinterpret_cast<const bf16x8*>(xlo + li);
+            bf16x8 xlow;
+            if (LOW) xlow = *reinterpret_cast<const bf16x8*>(xlo + li);
             __builtin_amdgcn_sched_barrier(0);        // all nine loads are issued; the constant reads below stay next to their use
             float sum[8];
 #pragma unroll
@@ -774,31 +779,50 @@ __global__ __launch_bounds__(1024) void upadd_bwd_bb_kernel(const bf16* __restri
                 float v[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) { v[j] = (float)g[k][j]; sum[j] += v[j]; }
-                *reinterpret_cast<bf16x8*>(dskip + off[k]) = Bwd8::apply(cs, cc, xs[k], v, k1, k2);
-                __builtin_amdgcn_sched_barrier(0);
+                if (SKIP) {
+                    *reinterpret_cast<bf16x8*>(dskip + off[k]) = Bwd8::apply(cs, cc, xs[k], v, k1, k2);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
-            *reinterpret_cast<bf16x8*>(dlow + li) = Bwd8::apply(cl, cc, xlow, sum, l1, l2);
+            if (LOW) *reinterpret_cast<bf16x8*>(dlow + li) = Bwd8::apply(cl, cc, xlow, sum, l1, l2);
         }
     }
-    flush_stats(red, epl.stats, C, c, l1, l2);
-    flush_stats(red, eps.stats, C, c, k1, k2);
+    if (LOW) flush_stats(red, epl.stats, C, c, l1, l2);
+    if (SKIP) flush_stats(red, eps.stats, C, c, k1, k2);
+}
+
+bool pa_upadd_bwd_splits(const PaEpilogue& ep_low, const PaEpilogue& ep_skip, int B, int H, int W, int C) {
+    size_t total = (size_t)B * (H / 2) * (W / 2) * (C / 8);
+    int blocks, threads;
+    stream_launch_dims(total, blocks, threads);
+    fit_threads_to_rows(threads, W, C);
+    const size_t row_items = (size_t)(W / 2) * (C / 8);
+    return !pa_getenv("PA_ELTWISE_OLD") && ep_low.mode == PA_OUT_BWD && ep_skip.mode == PA_OUT_BWD && threads % (C / 8) == 0 &&
+           (row_items % threads == 0 || threads % row_items == 0) && (size_t)B * H * W * C < ((size_t)1 << 31);
 }
 
 int pa_launch_upadd_bwd(const bf16* dout, const PaEpilogue& ep_low, bf16* dlow, const PaEpilogue& ep_skip, bf16* dskip,
-                        int B, int H, int W, int C, hipStream_t st, int* stat_rows) {
+                        int B, int H, int W, int C, hipStream_t st, int* stat_rows, int part) {
     size_t total = (size_t)B * (H / 2) * (W / 2) * (C / 8);
     int blocks, threads;
     stream_launch_dims(total, blocks, threads);
     fit_threads_to_rows(threads, W, C);
     if (stat_rows) *stat_rows = blocks;
-    if (ep_low.rows_out) *ep_low.rows_out = blocks;
-    if (ep_skip.rows_out) *ep_skip.rows_out = blocks;
+    if (ep_low.rows_out && (part & 1)) *ep_low.rows_out = blocks;
+    if (ep_skip.rows_out && (part & 2)) *ep_skip.rows_out = blocks;
+    if (part != 3) {           // one output only: the streaming kernel or nothing (callers ask pa_upadd_bwd_splits first)
+        if (!pa_upadd_bwd_splits(ep_low, ep_skip, B, H, W, C) || (part != 1 && part != 2)) { pa_set_error_msg("pa_launch_upadd_bwd: this launch cannot be split"); return 1; }
+        const size_t lds = (threads / 64) * 2 * C * sizeof(float) + 2 * C * sizeof(float4);
+        if (part == 1) hipLaunchKernelGGL((upadd_bwd_bb_kernel<true, false>), dim3(blocks), dim3(threads), lds, st, dout, ep_low, dlow, ep_skip, dskip, B * (H / 2), W, C);
+        else hipLaunchKernelGGL((upadd_bwd_bb_kernel<false, true>), dim3(blocks), dim3(threads), lds, st, dout, ep_low, dlow, ep_skip, dskip, B * (H / 2), W, C);
+        return (int)hipGetLastError();
+    }
     static int old = -1;
     if (old < 0) old = pa_getenv("PA_ELTWISE_OLD") ? 1 : 0;
     const size_t row_items = (size_t)(W / 2) * (C / 8);
     if (!old && ep_low.mode == PA_OUT_BWD && ep_skip.mode == PA_OUT_BWD && threads % (C / 8) == 0 &&
         (row_items % threads == 0 || threads % row_items == 0) && (size_t)B * H * W * C < ((size_t)1 << 31)) {
-        hipLaunchKernelGGL(upadd_bwd_bb_kernel, dim3(blocks), dim3(threads), (threads / 64) * 2 * C * sizeof(float) + 2 * C * sizeof(float4), st,
+        hipLaunchKernelGGL((upadd_bwd_bb_kernel<true, true>), dim3(blocks), dim3(threads), (threads / 64) * 2 * C * sizeof(float) + 2 * C * sizeof(float4), st,
                            dout, ep_low, dlow, ep_skip, dskip, B * (H / 2), W, C);
         return (int)hipGetLastError();
     }

@@ -55,7 +55,11 @@ int pa_launch_wgrad_tile(const PaWgradArgs& a, hipStream_t st);
 int pa_wgrad_group_splits(int B, int H, int W, int Cin, int Cout, int taps);
 bool pa_wgrad_group_takes(const PaWgradArgs& a);
 int pa_wgrad_job_workgroups(const PaWgradArgs& a);          // workgroups of the launch as a job
-int pa_launch_wgrad_group(const PaWgradArgs* const* jobs, int n, hipStream_t st);
+struct PaWgradReduceJob;
+// keep_order: jobs in the caller's order (default: longest first); red_*: red_n <= PA_RED_LIST_MAX entries of the reduce table whose slabs
+// (complete on `st` before this launch) are summed by a few more workgroups of the same launch
+int pa_launch_wgrad_group(const PaWgradArgs* const* jobs, int n, hipStream_t st, bool keep_order = false,
+                          const PaWgradReduceJob* red_jobs = nullptr, const int* red_idx = nullptr, int red_n = 0);
 void pa_wgrad_set_launch_flags(unsigned flags);      // hipExtAnyOrderLaunch for the tile weight gradients launched next by this thread (0 = in-order)
 
 // reduce partial slabs into the fp32 gradient in PyTorch layout  dst[n][c][tap]  (real_cin/real_cout
@@ -94,8 +98,11 @@ int pa_launch_maxpool_bwd(const bf16* dout, const PaOperand& in, const PaOperand
                           int B, int H, int W, int C, hipStream_t st, int* stat_rows = nullptr);
 // out = nearest_up2(low) + skip        (low: [B][H/2][W/2][C], skip/out: [B][H][W][C])
 int pa_launch_upadd_fwd(const PaOperand& low, const PaOperand& skip, bf16* out, int B, int H, int W, int C, hipStream_t st);
+// part: 3 = both outputs in one launch; 1 = dlow only, 2 = dskip only (two launches on two streams: pa_upadd_bwd_splits() says whether the
+// streaming kernel, the only one with the one-output forms, takes the shape)
 int pa_launch_upadd_bwd(const bf16* dout, const PaEpilogue& ep_low, bf16* dlow, const PaEpilogue& ep_skip, bf16* dskip,
-                        int B, int H, int W, int C, hipStream_t st, int* stat_rows = nullptr);
+                        int B, int H, int W, int C, hipStream_t st, int* stat_rows = nullptr, int part = 3);
+bool pa_upadd_bwd_splits(const PaEpilogue& ep_low, const PaEpilogue& ep_skip, int B, int H, int W, int C);
 
 // ---- stem 7x7 stride-2 conv as a K=256 GEMM over the 4-channel-padded NHWC bf16 image
 // (in.p / x.p = img4 [B][2H][2W][4], Cin = 256 virtual patch length, Cout = 64, H/W = OUTPUT dims)

@@ -9,7 +9,8 @@
 static const int g_nosync = 0;
 static bool nosync() { return false; }
 // PA_ABLATE=<mask> (tuning builds only; results are WRONG, timing bounds only): 1 no slab reductions, 2 no weight-gradient
-// launches, 4 no BatchNorm finalize launches, 8 no 3x3 convolutions, 16 no 1x1 data gradients
+// launches, 4 no BatchNorm finalize launches, 8 no 3x3 convolutions, 16 no 1x1 data gradients; 1024 no upsample-add backward, 2048 no
+// pooling backward, 4096 no pooling / upsample-add forward (bounds of what fusing them into their neighbours can return)
 static int ablate() { static int v = -1; if (v < 0) { const char* e = pa_getenv("PA_ABLATE"); v = e ? atoi(e) : 0; } return v; }
 // bits 128 / 256 / 512: forward convolutions + finalize / data gradients + backward finalize / weight gradients of maps up to
 // PA_ABLATE_H (default 8) pixels high are skipped: what the low-resolution stretch costs the step at most (wrong results)
@@ -17,6 +18,8 @@ static int ablate_h() { static int v = -1; if (v < 0) { const char* e = pa_geten
 #define PA_STEM_ON_MAIN_DEFAULT 1
 #define PA_WG_GROUP_CAP_DEFAULT 256
 #define PA_WREDUCE_LAG_DEFAULT 2
+#define PA_UPADD_SPLIT_DEFAULT 1
+#define PA_WG_RED_IN_GROUP_DEFAULT 1
 #define TRY(x) do { int _r = (x); if (_r) return _r; } while (0)
 
 PaOperand pa_plain(const bf16* p) { PaOperand o; o.p = p; o.q = nullptr; o.k0 = o.k1 = o.k2 = nullptr; o.mode = PA_LD_PLAIN; return o; }
@@ -551,7 +554,13 @@ int Net::flush_wgrads() {
                 if (q.flops > pending_wgrads[jidx[big]].flops) big = j;
             }
             ProfEntry* pe = prof.begin(pending_wgrads[jidx[big]].cls, bytes, flops, ws);
-            const int rc = nj == 1 ? pa_launch_wgrad(*jobs[0], ws) : pa_launch_wgrad_group(jobs, nj, ws);
+            // the slabs of EARLIER flushes (the stash) are summed by a few more workgroups of this launch instead of by a launch of their own
+            static int red_in_group = -1;
+            if (red_in_group < 0) { const char* e = pa_getenv("PA_WG_RED_IN_GROUP"); red_in_group = e ? atoi(e) : PA_WG_RED_IN_GROUP_DEFAULT; }
+            const bool carry = red_in_group && ms && reduce_early && !(ablate() & 1) && !red_stash.empty();
+            const int rc = (nj == 1 && !carry) ? pa_launch_wgrad(*jobs[0], ws)
+                                               : pa_launch_wgrad_group(jobs, nj, ws, false, red_jobs, carry ? red_stash.data() : nullptr, carry ? (int)red_stash.size() : 0);
+            if (carry && !rc) { red_stash.clear(); red_stash_mx = 0; red_stash_flushes = 0; }
             prof.end(pe, ws);
             nj = 0; first = false;
             return rc;
@@ -603,7 +612,10 @@ int Net::flush_wgrads() {
             red_stash.push_back(p.c->red_index);
             red_stash_mx = el > red_stash_mx ? el : red_stash_mx;
         }
-        if (++red_stash_flushes >= lag || n_w > 1) TRY(flush_red_stash(ws));          // (several weight-gradient streams, tuning builds: no lag across streams)
+        // (in-group reductions: the stash waits for the next group launch of this stream; a launch of its own only when none came for `lag` + 2 flushes)
+        static int rig = -1;
+        if (rig < 0) { const char* e = pa_getenv("PA_WG_RED_IN_GROUP"); rig = e ? atoi(e) : PA_WG_RED_IN_GROUP_DEFAULT; }
+        if (++red_stash_flushes >= (rig && n_w == 1 ? lag + 2 : lag) || n_w > 1) TRY(flush_red_stash(ws));          // (several weight-gradient streams, tuning builds: no lag across streams)
     }
     pending_wgrads.clear();
     return 0;
@@ -612,22 +624,27 @@ int Net::flush_wgrads() {
 // the streaming launches with their operand bytes counted (Net::cnt, pa_net_design_bytes)
 static int c_maxpool_fwd(Net& n, const PaOperand& in, bf16* out, int B, int H, int W, int C, hipStream_t st) {
     const double e = (double)B * H * W * C; n.cnt(Net::opb(in, e), 2.0 * e / 4);
+    if (ablate() & 4096) return 0;
     return pa_launch_maxpool_fwd(in, out, B, H, W, C, st);
 }
 static int c_maxpool_bwd(Net& n, const bf16* dout, const PaOperand& in, const PaOperand& add, const PaEpilogue& ep, bf16* din, int B, int H, int W, int C,
                          hipStream_t st, int* rows = nullptr) {
     const double e = (double)B * H * W * C; n.cnt(2.0 * e / 4 + Net::opb(in, e) + Net::opb(add, e) + (ep.mode == PA_OUT_BWD ? 2.0 * e : 0.0), 2.0 * e);
+    if (ablate() & 2048) { if (ep.rows_out) *ep.rows_out = 1; return 0; }
     return pa_launch_maxpool_bwd(dout, in, add, ep, din, B, H, W, C, st, rows);
 }
 static int c_upadd_fwd(Net& n, const PaOperand& low, const PaOperand& skip, bf16* out, int B, int H, int W, int C, hipStream_t st) {
     const double e = (double)B * H * W * C; n.cnt(Net::opb(low, e / 4) + Net::opb(skip, e), 2.0 * e);
+    if (ablate() & 4096) return 0;
     return pa_launch_upadd_fwd(low, skip, out, B, H, W, C, st);
 }
 static int c_upadd_bwd(Net& n, const bf16* dout, const PaEpilogue& ep_low, bf16* dlow, const PaEpilogue& ep_skip, bf16* dskip, int B, int H, int W, int C,
-                       hipStream_t st, int* rows = nullptr) {
+                       hipStream_t st, int* rows = nullptr, int part = 3) {
     const double e = (double)B * H * W * C;
-    n.cnt(2.0 * e + (ep_low.mode == PA_OUT_BWD ? 2.0 * e / 4 : 0.0) + (ep_skip.mode == PA_OUT_BWD ? 2.0 * e : 0.0), 2.0 * e / 4 + 2.0 * e);
-    return pa_launch_upadd_bwd(dout, ep_low, dlow, ep_skip, dskip, B, H, W, C, st, rows);
+    n.cnt(2.0 * e + ((part & 1) && ep_low.mode == PA_OUT_BWD ? 2.0 * e / 4 : 0.0) + ((part & 2) && ep_skip.mode == PA_OUT_BWD ? 2.0 * e : 0.0),
+          ((part & 1) ? 2.0 * e / 4 : 0.0) + ((part & 2) ? 2.0 * e : 0.0));
+    if (ablate() & 1024) { if (ep_low.rows_out && (part & 1)) *ep_low.rows_out = 1; if (ep_skip.rows_out && (part & 2)) *ep_skip.rows_out = 1; return 0; }
+    return pa_launch_upadd_bwd(dout, ep_low, dlow, ep_skip, dskip, B, H, W, C, st, rows, part);
 }
 template <class... A> static int c_head_fwd(Net& n, const PaOperand& x, A... rest) {
     const double M = (double)n.B * (n.res / 4) * (n.res / 4); n.cnt(Net::opb(x, M * n.chan) + 2.0 * 16 * n.chan, M * 16 * 4 + M * 64 * 2);
@@ -780,6 +797,26 @@ int Hourglass::bwd(Net& n, const Act& in, const PaOperand& extra0) {
     for (int k = 0; k < 4; ++k) {
         if (k == n.hold_level) TRY(n.release_held(k));
         const Act& m = merged[k];
+        // the two outputs of the upsample-add backward as two launches: d low on the main chain (the low-resolution path waits for it), d skip
+        // on the side stream in front of the skip block's backward pass, its only reader -- the main chain waits for 75 MB instead of 175
+        static int split_env = -1;
+        if (split_env < 0) { const char* e = pa_getenv("PA_UPADD_SPLIT"); split_env = e ? atoi(e) : PA_UPADD_SPLIT_DEFAULT; }
+        if (split_env && !n.drop_mask && n.forks(k) && pa_upadd_bwd_splits(n.final_ep(up[k].x3), n.final_ep(skip[k].x3), m.B, m.H, m.W, m.C)) {
+            const Act& upin_ = (k == 3) ? neck.x3 : merged[k + 1];
+            const Act& x = (k == 0) ? in : down[k - 1].x3;
+            TRY(n.fork_to(k));
+            {
+                StreamScope sc(n, n.side[k]);
+                TRY(c_upadd_bwd(n, m.grad, n.final_ep(up[k].x3), up[k].x3.grad, n.final_ep(skip[k].x3), skip[k].x3.grad, m.B, m.H, m.W, m.C, n.st, nullptr, 2));
+                TRY(n.finish_grad_or_defer(skip[k].x3, n.x3_fin_ok(skip[k], x)));
+                TRY(skip[k].bwd_a(n, x));
+            }
+            TRY(n.record_join(k));
+            TRY(c_upadd_bwd(n, m.grad, n.final_ep(up[k].x3), up[k].x3.grad, n.final_ep(skip[k].x3), skip[k].x3.grad, m.B, m.H, m.W, m.C, n.st, nullptr, 1));
+            TRY(n.finish_grad_or_defer(up[k].x3, n.x3_fin_ok(up[k], upin_)));
+            TRY(up[k].bwd(n, upin_, pa_none(), true));
+            continue;
+        }
         if (n.drop_mask) {              // the skip tensor entered the sum through the cell mask: d skip = mask * d (masked skip)
             TRY(c_upadd_bwd(n, m.grad, n.final_ep(up[k].x3), up[k].x3.grad, ep_plain(), skipm[k].grad, m.B, m.H, m.W, m.C, n.st));
             TRY(pa_launch_cell_mask(pa_plain(skipm[k].grad), n.drop_mask, n.final_ep(skip[k].x3), skip[k].x3.grad, m.B, m.H, m.W, m.C, n.st));

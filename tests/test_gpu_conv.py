@@ -126,3 +126,107 @@ def test_conv3x3_tile_has_no_sporadic_elements(B, H):
         y, _ = run_conv(0, x, None, w, None, B, Cin, Cout, H, H, 3)
         err = (y - ref).abs()
         assert float(err.max()) < 0.05, (rep, float(err.max()), float((err > 0.05).float().mean()))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The grouped weight-gradient launch (wgrad_group_kernel, conv_wgrad_tile.hip): the training step's dominant kernel by time.  It is
+# reached here through pa_wgrad_group (mode 0: the same layers launched alone, 1: ONE group launch ordered longest-first like
+# Net::flush_wgrads does, 2: one group launch in the given order) and checked against autograd of F.conv2d on the bf16-rounded EFFECTIVE
+# operands (x through BatchNorm + ReLU, dy through the BatchNorm backward, exactly as the kernel forms them before its MFMAs).
+def _wg_job(g, B, Cin, Cout, H, W, k, lin2, bnrelu, want_db):
+    """one layer: host tensors + the fp32 reference gradient"""
+    dy = torch.from_numpy(g.standard_normal((B, Cout, H, W)).astype(np.float32)).bfloat16().float()
+    x = torch.from_numpy(g.standard_normal((B, Cin, H, W)).astype(np.float32)).bfloat16().float()
+    job = dict(B=B, Cin=Cin, Cout=Cout, H=H, W=W, k=k, dy=dy, x=x, dy_q=None, dy_k=None, x_k=None, want_db=want_db)
+    dye, xe = dy, x
+    if lin2:
+        q = torch.from_numpy(g.standard_normal((B, Cout, H, W)).astype(np.float32)).bfloat16().float()
+        kk = torch.from_numpy(np.stack([g.uniform(0.5, 1.5, Cout), g.uniform(-0.5, 0.5, Cout), g.uniform(-0.1, 0.1, Cout)]).astype(np.float32))
+        job['dy_q'] = q; job['dy_k'] = kk
+        # fmaf(k0, p, fmaf(k1, q, k2)) rounded to the 16-bit storage type once (conv_wgrad_tile.hip staging)
+        dye = (kk[0].view(1, -1, 1, 1).double() * dy.double() + (kk[1].view(1, -1, 1, 1).double() * q.double() + kk[2].view(1, -1, 1, 1).double())).float().bfloat16().float()
+    if bnrelu:
+        kx = torch.from_numpy(np.stack([g.uniform(0.5, 1.5, Cin), g.uniform(-0.3, 0.3, Cin)]).astype(np.float32))
+        job['x_k'] = kx
+        xe = torch.clamp(kx[0].view(1, -1, 1, 1).double() * x.double() + kx[1].view(1, -1, 1, 1).double(), min=0).float().bfloat16().float()
+    wr = torch.zeros((Cout, Cin, k, k), requires_grad=True)
+    br = torch.zeros(Cout, requires_grad=True)
+    F.conv2d(xe, wr, br, padding=k // 2).backward(dye)
+    job['ref_dw'] = wr.grad; job['ref_db'] = br.grad
+    return job
+
+
+def _run_wgrad_group(jobs, mode):
+    import ctypes as C
+    from pose_adv_aug_amd._lib import lib, check, ptr, stream
+
+    class Job(C.Structure):
+        _fields_ = [(n, C.c_int) for n in ('B', 'Cin', 'Cout', 'H', 'W', 'k')] + [(n, C.c_void_p) for n in ('dy', 'dy_q', 'dy_k', 'x', 'x_k', 'dw', 'db')]
+
+    L = lib()
+    arr = (Job * len(jobs))()
+    keep = []
+    outs = []
+    for i, j in enumerate(jobs):
+        dev = {n: (j[n].cuda().contiguous() if j[n] is not None else None) for n in ('dy', 'dy_q', 'dy_k', 'x', 'x_k')}
+        dw = torch.full((j['Cout'], j['Cin'], j['k'], j['k']), float('nan'), device='cuda')
+        db = torch.full((j['Cout'],), float('nan'), device='cuda') if j['want_db'] else None
+        keep.append((dev, dw, db)); outs.append((dw, db))
+        for n in ('B', 'Cin', 'Cout', 'H', 'W', 'k'):
+            setattr(arr[i], n, j[n])
+        for n in ('dy', 'dy_q', 'dy_k', 'x', 'x_k'):
+            setattr(arr[i], n, dev[n].data_ptr() if dev[n] is not None else None)
+        arr[i].dw = dw.data_ptr(); arr[i].db = db.data_ptr() if db is not None else None
+    nbytes = L.pa_wgrad_group_workspace_bytes(C.addressof(arr), len(jobs))
+    assert nbytes > 0
+    ws = torch.zeros(nbytes + 4096, dtype=torch.uint8, device='cuda')
+    ws[nbytes:] = 0xA5                                      # guard region behind the workspace
+    check(L.pa_wgrad_group(C.addressof(arr), len(jobs), mode, ptr(ws), stream()), 'pa_wgrad_group')
+    torch.cuda.synchronize()
+    assert bool((ws[nbytes:] == 0xA5).all()), 'pa_wgrad_group wrote behind its workspace'
+    return [(dw.cpu(), db.cpu() if db is not None else None) for dw, db in outs]
+
+
+# (B, Cin, Cout, H, W, k, dy through BatchNorm backward, x through BatchNorm + ReLU, bias gradient)
+_R64 = [  # one residual block of the 64 x 64 level at a small batch: conv3 / conv2 (dz stored: plain dy) / conv1 (LIN2 dy)
+    (3, 128, 256, 64, 64, 1, False, True, False), (3, 128, 128, 64, 64, 3, False, True, False), (3, 256, 128, 64, 64, 1, True, False, False)]
+WG_GROUPS = {
+    'two_1x1_128x128_and_3x3_lin2': [(3, 128, 128, 64, 64, 3, True, True, False), (3, 128, 128, 32, 32, 1, False, True, True)],
+    'residual_block_64': _R64,
+    # ragged: tile counts that the jobs' split counts do not divide (56 halo tiles; 40 and 38 row tiles of 128 pixels, the last one partly empty)
+    'ragged_splits': [(7, 128, 128, 32, 32, 3, True, True, False), (5, 64, 128, 32, 32, 1, False, False, True), (5, 128, 64, 24, 40, 1, True, True, True)],
+    # eight jobs, every tile shape of the kernel (3x3 64x64 plain and LIN2; 1x1 128x128, 128x64, 64x128, 64x64), mixed operand modes
+    'eight_mixed': [(2, 128, 128, 64, 64, 3, False, True, False), (2, 64, 64, 64, 64, 3, True, True, False),
+                    (2, 128, 128, 64, 64, 1, True, True, True), (2, 64, 128, 64, 64, 1, False, False, True),
+                    (2, 128, 64, 64, 64, 1, True, False, False), (2, 64, 64, 64, 64, 1, False, True, True),
+                    (2, 256, 128, 32, 32, 1, True, True, False), (2, 128, 256, 32, 32, 1, False, True, True)],
+}
+
+
+@pytest.mark.parametrize('name', sorted(WG_GROUPS))
+def test_wgrad_group_kernel_matches_conv2d_and_the_single_launches(name):
+    torch.set_num_threads(8)
+    g = inputs.rng(400, len(name))
+    jobs = [_wg_job(g, *spec) for spec in WG_GROUPS[name]]
+    alone = _run_wgrad_group(jobs, 0)
+    group = _run_wgrad_group(jobs, 1)
+    # the step's order is longest-first; here: the caller's order reversed (begin[] of the kernel not sorted by work)
+    rev = _run_wgrad_group(jobs[::-1], 2)[::-1]
+    for j, (dw0, db0), (dw1, db1), (dw2, db2) in zip(jobs, alone, group, rev):
+        tag = (name, j['Cin'], j['Cout'], j['H'], j['k'])
+        assert torch.isfinite(dw1).all() and torch.isfinite(dw2).all(), tag
+        assert rel_rms(dw1, j['ref_dw']) < 1e-4, tag            # the single-layer tolerance of test_conv_wgrad
+        assert rel_rms(dw0, j['ref_dw']) < 1e-4, tag
+        assert rel_rms(dw1, dw0) < 1e-6, tag                    # group == the same layers launched alone (same tiles, same split order)
+        assert rel_rms(dw2, dw0) < 1e-6, tag                    # ... in any job order
+        if j['want_db']:
+            assert rel_rms(db1, j['ref_db']) < 1e-4 and rel_rms(db1, db0) < 1e-6 and rel_rms(db2, db0) < 1e-6, tag
+
+
+def test_wgrad_group_refuses_shapes_the_grouped_kernel_does_not_take():
+    from pose_adv_aug_amd._lib import PoseAdvError
+    g = inputs.rng(401)
+    jobs = [_wg_job(g, 2, 64, 64, 8, 8, 3, False, True, False)]            # 8 x 8 map: no 8 x 16 tiles
+    assert rel_rms(_run_wgrad_group(jobs, 0)[0][0], jobs[0]['ref_dw']) < 1e-4      # alone: the generic kernel takes it
+    with pytest.raises(PoseAdvError):
+        _run_wgrad_group(jobs, 1)
