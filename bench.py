@@ -167,6 +167,22 @@ def cold_rate(dev, mb=(25, 50, 100, 400)):
     timed(b, a, n, False)
     ts = sorted(timed(b, a, n, False) for _ in range(5))
     large = 2.0 * n / ts[len(ts) // 2] / 1e12
+    # which COPY FORM reaches what on this box (the guide quotes 6.29 TB/s for a "float4 copy"): the same 1.6 GB in the probe's three forms
+    forms = {}
+    for form, name in ((0, 'grid_stride_4_in_flight'), (1, 'one_16B_chunk_per_thread'), (2, 'grid_stride_nontemporal')):
+        def tf():
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); check(lib.pa_copy_probe_form(ptr(b), ptr(a), n, form, stream()), 'pa_copy_probe_form'); e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) * 1e-3
+        tf()
+        ts = sorted(tf() for _ in range(5))
+        forms[name] = round(2.0 * n / ts[len(ts) // 2] / 1e12, 2)
+    # ... and on 256 MB, which the 256 MB Infinity Cache partly holds between repetitions (a small-buffer copy loop reads more than HBM gives)
+    n2 = 256 << 20
+    ts = sorted(timed(b[:n2], a[:n2], n2, False) for _ in range(5))
+    forms['grid_stride_4_in_flight_256MB_warm'] = round(2.0 * n2 / ts[len(ts) // 2] / 1e12, 2)
+    cold_rate.forms = forms
     sizes = sorted(k for k in out if k <= 100)
     return out[sizes[len(sizes) // 2]], {('%dMB' % k): round(v, 2) for k, v in out.items()}, large
 
@@ -192,6 +208,10 @@ def design_floor(net, opt, B, res, h, frame_hw=(720, 1280)):
                       'optimizer_repack_read': round(opt_rd), 'optimizer_repack_write': round(opt_wr)},
             'algorithmic_bytes_per_step': round(380.5e6 * B) if res == 256 else None,
             'cold_rate_TBps': round(rate, 2), 'cold_rate_table_TBps': table, 'rate_large_TBps': round(large, 2),
+            'rate_large_by_copy_form_TBps': getattr(cold_rate, 'forms', None),
+            'rate_large_note': 'rate_large_TBps = 1.6 GB device-to-device copy (read + written bytes) with pa_copy_probe form 0, median of 5, on this box at its own clocks; '
+                               'rate_large_by_copy_form_TBps lists the other forms of the same kernel (the guide\'s 6.29 TB/s is a float4 copy = form one_16B_chunk_per_thread) '
+                               'and a 256 MB copy, which the 256 MB Infinity Cache partly serves',
             'floor_ms': round(total / (rate * 1e12) * 1e3, 3), 'floor_ms_at_large_rate': round(total / (large * 1e12) * 1e3, 3),
             'floor_ms_at_8TBps': round(total / 8e12 * 1e3, 3),
             'algorithmic_floor_ms_at_large_rate': round(380.5e6 * B / (large * 1e12) * 1e3, 3) if res == 256 else None,
@@ -395,10 +415,11 @@ def main():
         if measured_pmc and dom['kernel'] in measured_pmc['classes']:
             c = measured_pmc['classes'][dom['kernel']]
             traffic = {'hbm_bytes_per_launch': round(c['hbm_bytes_per_launch'], 1), 'launches_profiled': c['launches_profiled'],
-                       'whole_step': {'fetch_bytes_x2': round(measured_pmc['fetch_bytes_per_step_x2']), 'write_bytes': round(measured_pmc['write_bytes_per_step'])},
+                       'whole_step': {'fetch_bytes_x2': round(measured_pmc['fetch_bytes_per_step_x2']), 'write_bytes': round(measured_pmc['write_bytes_per_step']),
+                                      'excluded_one_time_workspace_fill_bytes': round(measured_pmc.get('excluded_one_time_fill_bytes', 0.0))},
                        'source': 'measured in this run: rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) and --pmc WRITE_SIZE child passes of this command, 7 steps each; per class by launch order'}
         else:
-            for name in ('round5_pmc.json', 'round4_pmc.json', 'round3_pmc.json', 'round2_pmc.json'):
+            for name in ('round6_pmc.json', 'round5_pmc.json', 'round4_pmc.json', 'round3_pmc.json', 'round2_pmc.json'):
                 pmc_path = os.path.join(ROOT, 'profiles', name)
                 if is_c2 and os.path.isfile(pmc_path):
                     pmc = json.load(open(pmc_path))
@@ -410,7 +431,7 @@ def main():
         if measured_tr and dom['kernel'] in measured_tr:
             tr, tr_src = measured_tr[dom['kernel']], 'measured in this run: rocprofv3 --kernel-trace child pass of this command (single-stream roofline leg, 5 steps)'
         else:
-            for name in ('round5_trace_classes.json', 'round4_trace_classes.json', 'round3_trace_classes.json', 'round2_trace_classes.json'):
+            for name in ('round6_trace_classes.json', 'round5_trace_classes.json', 'round4_trace_classes.json', 'round3_trace_classes.json', 'round2_trace_classes.json'):
                 tr_path = os.path.join(ROOT, 'profiles', name)
                 if is_c2 and os.path.isfile(tr_path):
                     tr, tr_src = json.load(open(tr_path)).get(dom['kernel']), 'profiles/%s (recorded; not measured in this run)' % name
@@ -424,8 +445,24 @@ def main():
         floor = None
         if not args.no_floor:
             floor = design_floor(net, opt, B, res, h)
+        # the CRITICAL-PATH class beside the dominant-by-time one: the main chain's largest class (the 1x1 data gradients run on the caller's
+        # stream, one after the other; the weight-gradient groups that dominate by time run beside them on a queue of their own)
+        main_chain = None
+        mc = [r for r in rows if r['kernel'] == 'conv_dgrad_1x1']
+        if mc:
+            r = mc[0]
+            mc_ach = r['bytes'] / (r['ms_total'] * 1e-3) / 1e9
+            main_chain = {'kernel': r['kernel'], 'bound': 'hbm', 'avg_us': round(r['avg_us'], 2), 'launches_per_step': r['launches'] // args.steps,
+                          'alg_bytes_per_launch': r['bytes'] / r['launches'], 'achieved': round(mc_ach, 2), 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
+                          'frac': round(mc_ach / (HBM_PEAK / 1e9), 4), 'traffic': None, 'trace': None}
+            if measured_pmc and r['kernel'] in measured_pmc['classes']:
+                main_chain['traffic'] = {'hbm_bytes_per_launch': round(measured_pmc['classes'][r['kernel']]['hbm_bytes_per_launch'], 1),
+                                         'source': 'measured in this run (the same rocprofv3 --pmc child passes as roofline.traffic)'}
+            if measured_tr and r['kernel'] in measured_tr:
+                tu = measured_tr[r['kernel']]['avg_us']
+                main_chain['trace'] = {'avg_kernel_us': tu, 'frac': round(r['bytes'] / r['launches'] / (tu * 1e-6) / HBM_PEAK, 4)}
         roofline = {'bound': bound, 'achieved': round(ach, 2), 'peak': peak, 'unit': unit, 'frac': round(ach / peak, 4),
-                    'traffic': traffic, 'trace': trace, 'floor': floor, 'kernel': dom['kernel'], 'avg_launch_us': round(dom['avg_us'], 2),
+                    'traffic': traffic, 'trace': trace, 'floor': floor, 'main_chain': main_chain, 'kernel': dom['kernel'], 'avg_launch_us': round(dom['avg_us'], 2),
                     'launches_per_step': dom['launches'] // args.steps,
                     'alg_bytes_per_launch': dom['bytes'] / dom['launches'], 'alg_flops_per_launch': dom['flops'] / dom['launches'],
                     'mfma_kernels_ms_per_step': round(conv_ms, 3),

@@ -64,6 +64,9 @@ int pa_pck(const float* pred, const float* gt, const float* norm, float boundary
  * {cx, cy, scale, rot_deg, flip, gain_r, gain_g, gain_b}; t_out [B][6] float64 = forward transform
  * at res_out (first two rows), tinv_in [B][6] = INVERSE transform at res_in (what the warp samples with). */
 int pa_affine_params(const double* params, int B, int res_in, int res_out, double* t_out, double* tinv_in, void* stream);
+/* fp32 copies of c, s, r as the metric calls take them (`c = meta['center']`, `s = meta['scale']`, `r = meta['rot']` of the reference's
+ * batches, stack-hg.py:140-143): csr [4 B] floats = c [B][2] | s [B] | r [B] from params [B][8]. */
+int pa_params_csr(const double* params, int B, float* csr, void* stream);
 
 /* HumanAug.TransformPts (pylib/HumanAug.py:45-54) + shufflelr (:236-257) + the invalid-joint rule of
  * data/mpii_for_mpii.py:142-146.  pts [B][J][2] fp32 image pixels -> out [B][J][2] float64 heat-map
@@ -343,6 +346,9 @@ int pa_net_design_bytes(const pa_net* net, double* out_host);
  * multiple of 16).  Not part of the reference's surface (stack-hg.py has no roofline); bench.py times it on cold buffers of the step's
  * tensor sizes and on GB-sized ones. */
 int pa_copy_probe(void* dst, const void* src, size_t bytes, void* stream);
+/* ... in a chosen form: 0 = pa_copy_probe (grid-stride, four chunks in flight per thread), 1 = one 16-byte chunk per thread and no loop
+ * (the "float4 copy" /opt/skills/guides/MI355X_MICROARCH.md quotes 6.29 TB/s for), 2 = form 0 with non-temporal loads / stores. */
+int pa_copy_probe_form(void* dst, const void* src, size_t bytes, int form, void* stream);
 /* Micro-benchmark of ONE convolution launch (tools/bench_conv*.py; no reference counterpart): mode 0 forward, 1 data gradient,
  * 2 weight gradient; variant bits: 1 input transform (BatchNorm+ReLU / BatchNorm backward on load), 2 statistics / masked epilogue,
  * 4 one residual addend, 8 (weight gradient) BatchNorm+ReLU on the x operand, 16: cold protocol is the caller's business.  `ws` =

@@ -132,6 +132,8 @@ _PROTOS = {
     'pa_net_profile_report': (_i, [_vp, C.POINTER(C.c_double), _i, C.POINTER(_i)]),
     'pa_net_design_bytes': (_i, [_vp, C.POINTER(C.c_double)]),
     'pa_copy_probe': (_i, [_vp, _vp, _sz, _vp]),
+    'pa_copy_probe_form': (_i, [_vp, _vp, _sz, _i, _vp]),
+    'pa_params_csr': (_i, [_vp, _i, _vp, _vp]),
     'pa_net_set_fin_prologue': (_i, [_vp, _i]),
     'pa_wgrad_group_workspace_bytes': (_sz, [_vp, _i]),
     'pa_wgrad_group': (_i, [_vp, _i, _i, _vp, _vp]),

@@ -71,6 +71,20 @@ int pa_copy_probe(void* dst, const void* src, size_t bytes, void* s) {
     if (!dst || !src || (bytes & 15)) { pa_set_error_msg("pa_copy_probe: NULL buffer or a size that is not a multiple of 16"); return 1; }
     TRY(pa_launch_copy16(dst, src, bytes, ST(s))); return 0;
 }
+// the same copy in another form (1: one 16-byte chunk per thread, no loop; 2: grid-stride with non-temporal accesses; 0 = pa_copy_probe):
+// bench.py reports which form reaches what on the box, beside the guide's 6.29 TB/s "float4 copy"
+int pa_copy_probe_form(void* dst, const void* src, size_t bytes, int form, void* s) {
+    g_err[0] = 0;
+    if (!dst || !src || (bytes & 15) || form < 0 || form > 2) { pa_set_error_msg("pa_copy_probe_form: NULL buffer, a size that is not a multiple of 16, or form not in 0..2"); return 1; }
+    TRY(pa_launch_copy16(dst, src, bytes, ST(s), form)); return 0;
+}
+// fp32 copies of the augmentation parameters the metrics take (c [B][2], s [B], r [B]; data.py handed them over through three framework
+// elementwise kernels per step): csr = [4 B] floats = c | s | r, from params [B][8] float64
+int pa_params_csr(const double* params, int B, float* csr, void* s) {
+    g_err[0] = 0;
+    if (!params || !csr || B < 1) { pa_set_error_msg("pa_params_csr: bad arguments"); return 1; }
+    TRY(pa_launch_params_csr(params, B, csr, ST(s))); return 0;
+}
 int pa_crop(const uint8_t* src, int Hs, int Ws, const int32_t* sizes, const double* params, int B, int res, void* workspace,
             void* out4, float* outf, uint8_t* out8, void* s) {
     if (!src || !params || !workspace || B <= 0 || res <= 0) { pa_set_error_msg("pa_crop: bad arguments"); return 1; }
@@ -629,7 +643,11 @@ int pa_hg_train_step(pa_net* net, const void* img4, const double* pts, int train
 // total_dev: a device float that every later pa_hg_forward / pa_hg_train_step with `pts` also writes the SUM of the per-stack losses to
 // (NULL: off).  The reference sums them on the host side of autograd (stack-hg.py:156-159); here the caller gets the scalar without a
 // reduction launch of its own between the backward pass and the optimizer.
-int pa_hg_set_loss_total(pa_net* net, float* total_dev) { g_err[0] = 0; net->n.loss_total_out = total_dev; net->n.release_graph(); return 0; }
+int pa_hg_set_loss_total(pa_net* net, float* total_dev) {
+    g_err[0] = 0;
+    if (net->n.loss_total_out != total_dev) { net->n.loss_total_out = total_dev; net->n.release_graph(); }      // (a captured step holds the pointer by value)
+    return 0;
+}
 
 int pa_hg_accuracy(pa_net* net, int stack, const int32_t* idxs, int nidx, float* acc, float* scratch) {
     g_err[0] = 0;

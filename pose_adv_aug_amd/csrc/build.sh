@@ -28,6 +28,9 @@ build_variant() {      # $1 = object directory, $2 = extra flags, $3 = library n
 # the two variants side by side (the longest translation unit of one overlaps the short ones of the other)
 build_variant ../build "" libposeadv_hip.so &
 P1=$!
+if [ "$PA_ONLY" = "bf16" ]; then        # (tuning trees: sweeps of the bf16 benchmark only)
+  wait $P1; exit $?
+fi
 build_variant ../build_fp16 "-DPA_FP16" libposeadv_hip_fp16.so &
 P2=$!
 wait $P1; R1=$?

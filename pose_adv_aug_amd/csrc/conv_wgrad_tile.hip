@@ -494,7 +494,7 @@ __global__ __launch_bounds__(256, PIPE ? OCC : 2) void wgrad_tile_kernel(PaWgrad
 // Plain (two workgroups per CU, <= 244 registers) rather than pipelined bodies: 6.27 vs 6.31 ms per step -- a pipelined workgroup owns its
 // CU's registers, and the main chain's kernels then find no room beside the group.
 #define PA_WG_MAXJOBS 8
-#define PA_WG_RED_WGS_DEFAULT 32
+#define PA_WG_RED_WGS_DEFAULT 256
 enum { PA_WGK_9_44 = 0, PA_WGK_9_44L, PA_WGK_1_44, PA_WGK_1_42, PA_WGK_1_24, PA_WGK_1_22, PA_WGK_N };      // 3x3 64 x 64 (n x c) with a plain / BatchNorm-backward dy operand (fixed modes: the 144-accumulator body has no registers to spare for both) | 1x1 128 x 128 | 128 x 64 | 64 x 128 | 64 x 64
 struct PaWgradGroup {
     PaWgradArgs a[PA_WG_MAXJOBS];

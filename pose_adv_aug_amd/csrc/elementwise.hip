@@ -932,9 +932,36 @@ __global__ __launch_bounds__(256) void copy16_kernel(const uint4* __restrict__ s
     for (; i < n16; i += stride) dst[i] = src[i];
 }
 
-int pa_launch_copy16(void* dst, const void* src, size_t bytes, hipStream_t st) {
+// form 1: ONE 16-byte chunk per thread, no loop (the guide's "float4 copy"); form 2: the grid-stride form with non-temporal loads / stores
+__global__ __launch_bounds__(256) void copy16_flat_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n16) dst[i] = src[i];
+}
+__global__ __launch_bounds__(256) void copy16_nt_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16) {
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    const u4* s = reinterpret_cast<const u4*>(src); u4* d = reinterpret_cast<u4*>(dst);
+    const size_t stride = (size_t)gridDim.x * 256;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 3 * stride < n16; i += 4 * stride) {
+        const u4 a = __builtin_nontemporal_load(s + i), b = __builtin_nontemporal_load(s + i + stride), c = __builtin_nontemporal_load(s + i + 2 * stride), e = __builtin_nontemporal_load(s + i + 3 * stride);
+        __builtin_nontemporal_store(a, d + i); __builtin_nontemporal_store(b, d + i + stride); __builtin_nontemporal_store(c, d + i + 2 * stride); __builtin_nontemporal_store(e, d + i + 3 * stride);
+    }
+    for (; i < n16; i += stride) __builtin_nontemporal_store(__builtin_nontemporal_load(s + i), d + i);
+}
+
+int pa_launch_copy16(void* dst, const void* src, size_t bytes, hipStream_t st, int form) {
     const size_t n16 = bytes / 16;
     if (n16 == 0) return 0;
+    if (form == 1) {
+        hipLaunchKernelGGL(copy16_flat_kernel, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, st, reinterpret_cast<const uint4*>(src), reinterpret_cast<uint4*>(dst), n16);
+        return (int)hipGetLastError();
+    }
+    if (form == 2) {
+        size_t nb = (n16 + 1023) / 1024;
+        if (nb > 256 * 16) nb = 256 * 16;
+        hipLaunchKernelGGL(copy16_nt_kernel, dim3((unsigned)nb), dim3(256), 0, st, reinterpret_cast<const uint4*>(src), reinterpret_cast<uint4*>(dst), n16);
+        return (int)hipGetLastError();
+    }
     size_t blocks = (n16 + 1023) / 1024;                 // 4 chunks per thread
     if (blocks > 256 * 16) blocks = 256 * 16;            // 16 workgroups per CU, grid-stride beyond
     hipLaunchKernelGGL(copy16_kernel, dim3((unsigned)blocks), dim3(256), 0, st, reinterpret_cast<const uint4*>(src), reinterpret_cast<uint4*>(dst), n16);

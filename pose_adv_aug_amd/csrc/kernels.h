@@ -114,7 +114,7 @@ int pa_launch_stem_wgrad_reduce(const float* part, int splits, float* dst, hipSt
 // ---- optimizer / weight preparation
 int pa_launch_rmsprop(float* p, const float* g, float* v, size_t n, float lr, float alpha, float eps, float gscale, int* state, hipStream_t st);   // state: the optimizer's own {flag, skipped} device pair or NULL (process-wide pair)
 int pa_launch_loss_out(float* acc, float* keep, float* out, float* total, int n, hipStream_t st);      // per-stack losses + their sum out, accumulators cleared
-int pa_launch_copy16(void* dst, const void* src, size_t bytes, hipStream_t st);      // plain 16-B/lane streaming copy (bandwidth calibration)
+int pa_launch_copy16(void* dst, const void* src, size_t bytes, hipStream_t st, int form = 0);      // plain 16-B/lane streaming copy (bandwidth calibration)
 int pa_rmsprop_skipped(const int* state, long long* out, hipStream_t st);     // half-precision build: steps skipped for a non-finite gradient
 struct PaPrepJob { const float* w; bf16* wf; bf16* wb; int Cout, Cin, taps, pad_cout, pad_cin; };
 int pa_launch_weight_prep(const PaPrepJob* jobs_dev, int njobs, int max_elems, hipStream_t st);

@@ -277,6 +277,7 @@ struct Net {
     int begin_step();
     const bf16* cur_image = nullptr;
     int forward_pose(const float* img_nchw, const bf16* img4_in, const double* pts, bool train, float* loss_out_dev);
+    int forward_pose_body(const float* img_nchw, const bf16* img4_in, const double* pts, bool train, float* loss_out_dev);
     int backward_pose();
     // the backward pass in phases (data-parallel gradient exchange of a finished stack while the earlier ones still run):
     // phase p < stacks = head layers + post block + hourglass of stack (stacks-1-p); phase == stacks = stem + final reductions

@@ -535,12 +535,19 @@ int Net::flush_wgrads() {
         PA_CHECK(hipStreamWaitEvent(ws, ev, 0));
     }
     // the launches of a group share no data: from the second on they need no completion / cache round trip behind their predecessor
-    // (hipExtAnyOrderLaunch, conv_wgrad_tile.hip; not with the per-launch event timing, not with one slab shared by all layers)
+    // (hipExtAnyOrderLaunch, conv_wgrad_tile.hip; not with the per-launch event timing, not with one slab shared by all layers, and not
+    // inside a stream capture -- the engine's own or a caller's around pa_hg_backward: an extension launch cannot be captured)
     static int any_order = -1;
     if (any_order < 0) { const char* e = pa_getenv("PA_WGRAD_ANYORDER"); any_order = e ? atoi(e) : 1; }
+    bool in_capture = capturing;
+    if (!in_capture) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(ws, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) in_capture = true;
+    }
     bool first = true;
-    // every launch of the list the grouped kernel takes goes into group launches of up to 8 jobs (not while the per-launch event timing
-    // runs: its classes are per layer); the others -- the stem, shapes of the generic kernel -- are launched one by one behind them
+    // every launch of the list the grouped kernel takes goes into group launches of up to 8 jobs (also while the per-launch event timing
+    // runs: a group launch counts for the class of its largest job); the others -- the stem, shapes of the generic kernel -- are launched
+    // one by one behind them
     std::vector<char> grouped(pending_wgrads.size(), 0);
     if (!immediate_reduce) {
         const PaWgradArgs* jobs[8]; int jidx[8]; int nj = 0;
@@ -586,7 +593,7 @@ int Net::flush_wgrads() {
         PendingWgrad& p = pending_wgrads[pi];
         if (grouped[pi]) continue;
         ProfEntry* pe = prof.begin(p.cls, p.bytes, p.flops, ws);
-        pa_wgrad_set_launch_flags((any_order && !first && !prof.on && !immediate_reduce && !capturing) ? 1u : 0u);
+        pa_wgrad_set_launch_flags((any_order && !first && !prof.on && !immediate_reduce && !in_capture) ? 1u : 0u);
         int rc = p.stem ? pa_launch_stem_wgrad(p.a, ws) : pa_launch_wgrad(p.a, ws);
         pa_wgrad_set_launch_flags(0u);
         first = false;
@@ -976,6 +983,14 @@ int Net::heat_argmax(int stack, const float** out, hipStream_t on) {
 }
 
 int Net::forward_pose(const float* img_nchw, const bf16* img4_in, const double* pts, bool train, float* loss_out_dev) {
+    const int rc = forward_pose_body(img_nchw, img4_in, pts, train, loss_out_dev);
+    // the per-stack loss accumulators are cleared by the kernel that reads them at the END of a forward pass (loss_out_kernel): a pass that
+    // fails after a head launch has added to them would leave its residue in every later loss -- clear them here then (self-healing)
+    if (rc && pts && loss_dev && st) { (void)hipGetLastError(); (void)hipMemsetAsync(loss_dev, 0, 64 * sizeof(float), st); }
+    return rc;
+}
+
+int Net::forward_pose_body(const float* img_nchw, const bf16* img4_in, const double* pts, bool train, float* loss_out_dev) {
     train_bn = train;
     heat_peak_valid.assign(stacks, 0);
     TRY(ensure_streams());

@@ -14,6 +14,7 @@ int pa_launch_final_preds(const float* maps, long sb, long sj, long sp, const fl
                           const float* rot, int B, int J, int H, int W, float* out, hipStream_t st);
 int pa_launch_pck(const float* pred, const float* gt, const float* norm, float boundary, const int* idxs, int nidx, float thr,
                   const float* vis, int B, int J, float* acc, float* person, float* dists_out, hipStream_t st);
+int pa_launch_params_csr(const double* params, int B, float* csr, hipStream_t st);
 int pa_launch_affine_params(const double* params, int B, int res_in, int res_out, double* t_out, double* tinv_in, hipStream_t st);
 int pa_launch_transform_pts(const float* pts, const double* params, const double* t, int B, int J, float width, const int* sizes,
                             double* out, float* pts_img, hipStream_t st);

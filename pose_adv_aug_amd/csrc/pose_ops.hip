@@ -465,6 +465,19 @@ __global__ void affine_params_kernel(const double* params, int B, int res_in, in
     for (int i = 0; i < 6; ++i) tinv_in[(size_t)b * 6 + i] = ti[i];
 }
 
+__global__ void params_csr_kernel(const double* params, int B, float* csr) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const double* p = params + (size_t)b * 8;
+    csr[2 * b] = (float)p[0]; csr[2 * b + 1] = (float)p[1];
+    csr[2 * B + b] = (float)p[2];
+    csr[3 * B + b] = (float)p[3];
+}
+int pa_launch_params_csr(const double* params, int B, float* csr, hipStream_t st) {
+    hipLaunchKernelGGL(params_csr_kernel, dim3((B + 63) / 64), dim3(64), 0, st, params, B, csr);
+    return (int)hipGetLastError();
+}
+
 int pa_launch_affine_params(const double* params, int B, int res_in, int res_out, double* t_out, double* tinv_in, hipStream_t st) {
     hipLaunchKernelGGL(affine_params_kernel, dim3((B + 63) / 64), dim3(64), 0, st, params, B, res_in, res_out, t_out, tinv_in);
     return (int)hipGetLastError();

@@ -108,9 +108,12 @@ class Augmenter(object):
         t_out, _ = HumanAug.affine_params(batch.params, self.inp_res, self.out_res)
         img4, imgf, _ = HumanAug.crop_batch(batch.frames, batch.params, res=self.inp_res, want_nchw=want_nchw, sizes=batch.sizes)
         pts_heat, pts_img = HumanAug.transform_pts_batch(batch.joints, batch.params, t_out, batch.Ws, sizes=batch.sizes)
+        # fp32 c, s, r for the metric calls from ONE launch of the library (three framework elementwise kernels per step before round 6)
+        B = batch.B
+        csr = torch.empty(4 * B, dtype=torch.float32, device=batch.params.device)
+        check(lib().pa_params_csr(ptr(batch.params), B, ptr(csr), stream()), 'pa_params_csr')
         return {'img4': img4, 'img': imgf, 'pts': pts_heat, 'grnd_pts': pts_img,
-                'c': batch.params[:, 0:2].float().contiguous(), 's': batch.params[:, 2].float().contiguous(),
-                'r': batch.params[:, 3].float().contiguous(), 'normalizer': batch.normalizer}
+                'c': csr[:2 * B].view(B, 2), 's': csr[2 * B:3 * B], 'r': csr[3 * B:], 'normalizer': batch.normalizer}
 
     def regular(self, batch, want_nchw=False):
         """data/mpii_for_mpii.py:119-135."""

@@ -235,6 +235,8 @@ def main(argv=None):
         batch = next(iter(train_feed))
         train_loss_sr = float(train_agent_sr(batch, hg, agent_sr, optimizer_sr, augmenter, epoch_sr, seed=epoch))
         log('epoch:%d, iters:0/1 loss_agent_sr: %.4f ' % (epoch_sr, train_loss_sr))
+        from .stack_hg import warn_skipped_steps
+        warn_skipped_steps(optimizer_sr, log, 'agent')        # (fp16 build; the agent optimizer has its own skip state)
         train_history_sr.update(OrderedDict([('epoch', epoch_sr)]), OrderedDict([('lr', optimizer_sr.param_groups[0]['lr'])]),
                                 OrderedDict([('train_loss', train_loss_sr), ('val_loss', 0)]))
         if rank == 0:

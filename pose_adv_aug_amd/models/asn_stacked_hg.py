@@ -247,12 +247,6 @@ class HourglassNet(_HipModule):
         p = pts.to(torch.float64).contiguous() if pts is not None else None
         losses = torch.empty(self.num_stacks, dtype=torch.float32, device=self.flat_params.device) if pts is not None else None   # (fully overwritten)
         keep = self._set_masks(h, dropout_masks)
-        # the sum over the stacks comes from the engine (pa_hg_set_loss_total): one of 16 rotating device floats, valid until 16 calls later
-        if getattr(self, '_loss_ring', None) is None:
-            self._loss_ring, self._loss_slot = torch.zeros(16, dtype=torch.float32, device=self.flat_params.device), 0
-        self._loss_slot = (self._loss_slot + 1) % 16
-        total = self._loss_ring[self._loss_slot:self._loss_slot + 1]
-        check(lib().pa_hg_set_loss_total(h, ptr(total)), 'pa_hg_set_loss_total')
         try:
             check(lib().pa_hg_forward(h, ptr(x.contiguous().float()) if x is not None else None, ptr(img4), ptr(p),
                                       1 if self.training else 0, ptr(losses)), 'pa_hg_forward')
@@ -281,6 +275,9 @@ class HourglassNet(_HipModule):
         """One pass of stack-hg.py:153-164 without the optimizer: forward in the current mode, loss
         sum_stacks mean((out - gaussian(pts))^2) with the target generated on the fly from `pts`
         ([B][16][2] heat-map coordinates), backward into flat_grads.  Returns (loss 0-d GPU tensor, outputs).
+        The loss tensor is a VIEW of one slot of a ring of 16 device floats the engine writes (pa_hg_set_loss_total: no framework
+        reduction between backward and optimizer): it holds this step's loss until the 16th later call of this method overwrites
+        it -- consume it (meters, .item(), .clone()) before that; the shipped loops read it in the same iteration.
         dropout_masks ([B][1][4][4]): the occlusion masks of the reference's dropout branch, in every stack.
         after_forward: a callable run between the two passes; its accuracy() / pckh_origin_res() calls (stack-hg.py:176-178 read
         nothing but the forward pass's heat maps) go to the engine's meter stream and run BESIDE the backward pass instead of between

@@ -78,22 +78,24 @@ def train_step(net, optimizer, augmenter, batch, want_pckh=True, data=None):
     return loss, pckh[0], pckh_o[0]
 
 
-_SKIPPED_SEEN = {}
+import weakref
+_SKIPPED_SEEN = weakref.WeakKeyDictionary()      # optimizer -> count already reported
 
 
-def warn_skipped_steps(optimizer, log=print):
+def warn_skipped_steps(optimizer, log=print, name=''):
     """fp16 build: the engine skips (and counts) an optimizer step whose scaled gradient holds inf / NaN.  Silent skipping would hide a
-    persistent overflow, so the loops report every growth of the counter where they synchronise anyway (at print time).  The counter is
-    process-wide (one device word), so it is tracked per process here, whichever optimizer asked."""
+    persistent overflow, so the loops report every growth of the counter where they synchronise anyway (at print time).  The counter
+    belongs to the optimizer (pa_rmsprop_step_state: its own {flag, skipped} device pair), so what was reported is tracked per optimizer
+    too: the joint loop asks for the pose net's and for the agent's."""
     from . import _lib
     if _lib.DTYPE != 'fp16' or not hasattr(optimizer, 'skipped_steps'):
         return 0
     n = optimizer.skipped_steps()
-    seen = _SKIPPED_SEEN.get('n', 0)
+    seen = _SKIPPED_SEEN.get(optimizer, 0)
     if n > seen:
-        log('WARNING: %d optimizer step(s) skipped for a non-finite fp16 gradient (%d so far): the gradient scale PA_GRAD_SCALE '
-            'overflows this model -- train in the bf16 build or lower the scale' % (n - seen, n))
-        _SKIPPED_SEEN['n'] = n
+        log('WARNING: %d %soptimizer step(s) skipped for a non-finite fp16 gradient (%d so far): the gradient scale PA_GRAD_SCALE '
+            'overflows this model -- train in the bf16 build or lower the scale' % (n - seen, name and name + ' ', n))
+        _SKIPPED_SEEN[optimizer] = n
     return n - seen
 
 

@@ -56,35 +56,9 @@ class Probe(object):
 _ALL = []          # every comparison of the running test (POSEADV_TEST_VERBOSE=1 prints the ones nearest their tolerance)
 
 
-_SAMPLES = [None]  # (batch, top map size) of the running test: lets _close see how many pixels a BatchNorm of the named node averages over
-
-
-def _few_samples(what):
-    """True for gradients of the 8 x 8 / 4 x 4 levels when they hold fewer than 256 pixels per channel (B = 2: 128 / 32).  There ONE
-    element whose pre-activation rounds to the other side of zero in bf16 (the engine masks on its stored bf16 tensor, the oracle's
-    emulation on its own) moves a channel's BatchNorm sums by ~1 / sqrt(n) of their size, and everything behind the BatchNorm backward
-    with it: observed over six weight seeds 0.5 - 3 % at the higher levels but up to 10 % (one seed in six, either tiling of the stem) at
-    the 32-pixel level -- the bar there is 3 x the usual one."""
-    import re
-    if _SAMPLES[0] is None:
-        return False
-    B, top = _SAMPLES[0]
-    m = re.search(r'(down|up|skip|pool|merge)(\d)', what)
-    if m:
-        k = int(m.group(2))
-        size = top >> (k - 1 if m.group(1) in ('skip', 'merge') else k)
-    elif 'neck' in what:
-        size = top >> 4
-    else:
-        return False
-    return B * size * size < 256
-
-
 def _close(errs, what, got, ref, tol, cos=None):
     e = rel_rms(got, ref)
     c = cosine(got, ref)
-    if cos is not None and _few_samples(what):
-        tol, cos = 3 * tol, 1 - 9 * (1 - cos)
     _ALL.append((e / tol, what, round(e, 4), round(c, 5)))
     if not (e < tol and (cos is None or c > cos)):
         errs.append((what, round(e, 4), round(c, 5)))
@@ -99,8 +73,10 @@ def test_every_node_of_the_training_graph_matches_locally():
     gradients) against the oracle, in place."""
     torch.set_num_threads(8)
     bf16_emul.ROUND_GRADS = True        # the engine stages gradient operands in bf16 (standard mixed precision)
-    stacks, B, res, chan = 2, 2, 256, 128
-    _SAMPLES[0] = (B, res // 4)
+    # B = 8: the 8 x 8 / 4 x 4 levels then hold 512 / 128 pixels per channel.  (At B = 2 -- 128 / 32 pixels -- ONE element whose
+    # pre-activation rounds to the other side of zero in bf16 moved a channel's BatchNorm sums by ~1 / sqrt(n) and everything behind the
+    # BatchNorm backward with it; round 5 gave those levels 3 x the bar.  Round 6 raises the batch instead: one bar for every node.)
+    stacks, B, res, chan = 2, 8, 256, 128
     ref, net = _hg_pair(stacks, chan, B, res, seed=int(os.environ.get('POSEADV_TEST_SEED', '7')))
     img = t(inputs.images(8, B, res))
     pts = inputs.heat_pts(9, B, res=res // 4)
@@ -223,7 +199,6 @@ def test_every_node_of_the_training_graph_matches_locally():
     if os.environ.get('POSEADV_TEST_VERBOSE'):
         print('NEAREST THE TOLERANCE:', sorted(_ALL, reverse=True)[:8])
     del _ALL[:]
-    _SAMPLES[0] = None
     assert not errs, '%d local mismatches, first: %s' % (len(errs), errs[:15])
 
 
@@ -270,7 +245,6 @@ def test_blocks_of_every_resolution_match_locally_at_the_benchmark_size():
     if os.environ.get('POSEADV_TEST_VERBOSE'):
         print('NEAREST THE TOLERANCE:', sorted(_ALL, reverse=True)[:8])
     del _ALL[:]
-    _SAMPLES[0] = None
     assert not errs, '%d local mismatches, first: %s' % (len(errs), errs[:15])
 
 
@@ -338,7 +312,6 @@ def test_stem_second_stack_and_head_layers_match_locally_at_the_benchmark_size()
     if os.environ.get('POSEADV_TEST_VERBOSE'):
         print('NEAREST THE TOLERANCE:', sorted(_ALL, reverse=True)[:8])
     del _ALL[:]
-    _SAMPLES[0] = None
     assert not errs, '%d local mismatches, first: %s' % (len(errs), errs[:15])
 
 

@@ -542,46 +542,74 @@ def test_training_trajectory_tracks_the_oracle_over_150_steps(wseed, dseed):
     """The "PCKh-matching" half of the metric at TRAINING level: a 1-stack hourglass (chan 128, B = 4, 128x128) trained for
     150 RMSprop steps on a small learnable set (colour-coded blobs at the joints), engine (bf16 storage) and fp32 oracle
     from the same weights on the same batches.  Both learn: loss falls by > 3x and PCKh@0.5 in heat-map space
-    (Evaluation.accuracy, computed by the ORACLE code on each side's own heat maps of a held-out batch) rises; at the end
-    the two agree on each of three seeds (weights, data): smoothed loss within 9 %, held-out PCKh within -0.08 / +0.17 of the oracle's, held-out loss within 17 %."""
+    (Evaluation.accuracy, computed by the ORACLE code on each side's own heat maps of HELD-OUT images) rises; at the end
+    the two agree on each of three seeds (weights, data) at the bars of round 4: smoothed loss within 5 %, held-out PCKh within
+    +-0.08, held-out mse within 12 %.
+
+    Round 5 had widened these bars (9 %, -0.08 / +0.17, 17 %) after seeing three seeds.  Round 6 narrows the STATISTIC instead: the
+    held-out set is 20 images (~290 visible joints, one joint = 0.0035) instead of 4 (~58 joints, one joint = 0.017), so that the
+    sampling noise of the held-out numbers no longer dominates what two equally good models differ by.
+
+    A third trajectory runs beside the two: the oracle's modules evaluated with the engine's bf16 STORAGE points and bf16 gradient
+    roundings (tests/bf16_emul.py), i.e. "the engine's numerics without the engine's kernels".  It is NOT a tighter reference for a
+    150-step trajectory -- measured on the three seeds (round 6): emulation vs fp32 oracle tail loss 2.4 - 6.1 %, engine vs fp32 oracle
+    0.2 - 0.9 %, engine vs emulation 2.9 - 4.9 %: the three trajectories are mutually as far apart as bf16 storage noise amplified over
+    150 steps makes ANY two of them; the emulation-level bars that ARE tight are the one-step ones (first-step loss 3e-3 here,
+    test_residual_block / test_gpu_local.py 3e-3 ... 4e-2).  The three-way distances are printed."""
+    import copy
+    from tests import bf16_emul
     from pose_adv_aug_amd.utils.optim import RMSprop
     torch.set_num_threads(16)
     B, res, chan, steps = 4, 128, 128, 150
     ref, net = _hg_pair(1, chan, B, res, seed=wseed)
-    imgs, pts = _blob_dataset(24, res, seed=dseed)
+    emu = copy.deepcopy(ref)                  # the SAME oracle modules evaluated with the engine's bf16 storage points (tests/bf16_emul.py)
+    imgs, pts = _blob_dataset(40, res, seed=dseed)               # 20 training images (5 batches), 20 held out
     heat = inputs.heatmaps_from_pts(pts, res=res // 4)
     opt_ref = ostep.make_optimizer(ref)
+    opt_emu = ostep.make_optimizer(emu)
     opt = RMSprop(net, lr=2.5e-4, alpha=0.99, eps=1e-8)
-    ref.train(); net.train()
-    l_ref, l_dev = [], []
-    for i in range(steps):
-        sl = slice((i % 5) * B, (i % 5) * B + B)                 # 5 training batches, the 6th is held out
-        _, l = ostep.pose_loss_and_grads(ref, t(imgs[sl]), t(heat[sl])); opt_ref.step(); l_ref.append(float(l))
-        l2, _ = net.loss_and_backward(t(imgs[sl]).cuda(), t(pts[sl]).cuda()); opt.step(); l_dev.append(float(l2))
+    ref.train(); net.train(); emu.train()
+    l_ref, l_dev, l_emu = [], [], []
+    rg = bf16_emul.ROUND_GRADS
+    bf16_emul.ROUND_GRADS = True              # ... and its bf16 gradient storage
+    try:
+        for i in range(steps):
+            sl = slice((i % 5) * B, (i % 5) * B + B)
+            _, l = ostep.pose_loss_and_grads(ref, t(imgs[sl]), t(heat[sl])); opt_ref.step(); l_ref.append(float(l))
+            le = opl.stack_mse(bf16_emul.emul_hourglass_net(emu, t(imgs[sl])), t(heat[sl]))
+            emu.zero_grad(); le.backward(); opt_emu.step(); l_emu.append(float(le))
+            l2, _ = net.loss_and_backward(t(imgs[sl]).cuda(), t(pts[sl]).cuda()); opt.step(); l_dev.append(float(l2))
+    finally:
+        bf16_emul.ROUND_GRADS = rg
     assert abs(l_dev[0] - l_ref[0]) / l_ref[0] < 1e-2
+    assert abs(l_dev[0] - l_emu[0]) / l_emu[0] < 3e-3            # (one step: the emulation's distance, not the fp32 oracle's)
     tail = lambda v: float(np.mean(v[-20:]))
     assert tail(l_ref) < l_ref[0] / 3 and tail(l_dev) < l_dev[0] / 3, (l_ref[0], tail(l_ref), l_dev[0], tail(l_dev))
-    # bars = 2 x the spread observed over the three seeds (round 5: tail loss 0.0005 / 0.018 / 0.044, held-out PCKh 0.052 / 0.000 / 0.016,
-    # held-out mse 0.085 / 0.013 / 0.072 relative -- 150 bf16 steps amplify a last-bit difference; one seed's value says little)
-    assert abs(tail(l_dev) - tail(l_ref)) / tail(l_ref) < 0.09, (tail(l_dev), tail(l_ref))
-    # held-out batch, eval mode (running statistics of 150 steps), PCKh by the oracle's Evaluation on each side's maps
-    sl = slice(20, 24)
-    ref.eval(); net.eval()
-    with torch.no_grad():
-        o_ref = ref(t(imgs[sl]))[-1]
-    o_dev = net(t(imgs[sl]).cuda(), pts=t(pts[sl]).cuda())[-1].cpu()
+    assert abs(tail(l_dev) - tail(l_ref)) / tail(l_ref) < 0.05, (tail(l_dev), tail(l_ref))
+    # held-out images, eval mode (running statistics of 150 steps), PCKh by the oracle's Evaluation on each side's maps
+    ref.eval(); net.eval(); emu.eval()
+    o_ref, o_dev, o_emu = [], [], []
+    for k in range(5, 10):
+        sl = slice(k * B, k * B + B)
+        with torch.no_grad():
+            o_ref.append(ref(t(imgs[sl]))[-1])
+            o_emu.append(bf16_emul.emul_hourglass_net(emu, t(imgs[sl]))[-1])
+        o_dev.append(net(t(imgs[sl]).cuda(), pts=t(pts[sl]).cuda())[-1].cpu())
+        if k == 9:          # ... and the engine's own metric kernel on its own maps says the same as the oracle code on those maps
+            assert abs(float(net.accuracy(list(range(16)))[0]) - float(opl.accuracy(o_dev[-1], t(heat[sl]), list(range(16)))[0])) < 1e-4
+    o_ref, o_dev, o_emu = torch.cat(o_ref), torch.cat(o_dev), torch.cat(o_emu)
+    held = t(heat[5 * B:10 * B])
     idx = list(range(16))
-    a_ref, a_dev = float(opl.accuracy(o_ref, t(heat[sl]), idx)[0]), float(opl.accuracy(o_dev, t(heat[sl]), idx)[0])
-    v_ref, v_dev = float(((o_ref - t(heat[sl])) ** 2).mean()), float(((o_dev - t(heat[sl])) ** 2).mean())
+    a_ref, a_dev, a_emu = (float(opl.accuracy(o, held, idx)[0]) for o in (o_ref, o_dev, o_emu))
+    v_ref, v_dev, v_emu = (float(((o - held) ** 2).mean()) for o in (o_ref, o_dev, o_emu))
     print('TRAJECTORY observed: tail loss dev %.6g ref %.6g (rel %.4f); held-out PCKh dev %.4f ref %.4f; held-out mse dev %.6g ref %.6g (rel %.4f)'
           % (tail(l_dev), tail(l_ref), abs(tail(l_dev) - tail(l_ref)) / tail(l_ref), a_dev, a_ref, v_dev, v_ref, abs(v_dev - v_ref) / v_ref))
+    print('TRAJECTORY vs bf16 emulation: tail loss emu %.6g (rel %.4f); held-out PCKh emu %.4f (dev - emu %+.4f); held-out mse emu %.6g (rel %.4f); '
+          'emu vs fp32: tail %.4f PCKh %+.4f mse %.4f'
+          % (tail(l_emu), abs(tail(l_dev) - tail(l_emu)) / tail(l_emu), a_emu, a_dev - a_emu, v_emu, abs(v_dev - v_emu) / v_emu,
+             abs(tail(l_emu) - tail(l_ref)) / tail(l_ref), a_emu - a_ref, abs(v_emu - v_ref) / v_ref))
     assert a_ref > 0.2 and a_dev > 0.2, (a_ref, a_dev)
-    # held-out PCKh is counted on ~58 visible joints of 4 images (one joint = 0.017).  Over the three seeds and two summation orders of the
-    # BatchNorm partial rows (rounds 5a / 5b) the engine's value was the oracle's -0.016 ... +0.115, its held-out mse the LOWER one in five
-    # of six: the bar is asymmetric -- at most 0.08 below the oracle, at most 0.17 above
-    assert -0.08 <= a_dev - a_ref <= 0.17 and abs(v_dev - v_ref) / v_ref < 0.17, (a_ref, a_dev, v_ref, v_dev)
-    # ... and the engine's own metric kernel on its own maps says the same as the oracle code on those maps
-    assert abs(float(net.accuracy(idx)[0]) - a_dev) < 1e-4
+    assert abs(a_dev - a_ref) <= 0.08 and abs(v_dev - v_ref) / v_ref < 0.12, (a_ref, a_dev, v_ref, v_dev)
 
 
 def test_engine_against_the_reference_golden_directly():

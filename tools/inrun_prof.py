@@ -96,12 +96,14 @@ def parse_pmc_sequence(fetch_csv, write_csv, seq_path, steps):
     seq = json.load(open(seq_path))
     names, order = seq['classes'], seq['sequence']
     out = collections.defaultdict(lambda: {'fetch_bytes': 0.0, 'write_bytes': 0.0, 'launches': 0})
-    tot = {}
+    tot, fill = {}, {}
     for C, path in (('FETCH_SIZE', fetch_csv), ('WRITE_SIZE', write_csv)):
         rows = [(int(r['Dispatch_Id']), r['Kernel_Name'], float(r['Counter_Value']) * 1024.0 * (2.0 if C == 'FETCH_SIZE' else 1.0))
                 for r in csv.DictReader(open(path)) if r['Counter_Name'] == C]
         rows.sort()
-        tot[C] = sum(v for _, _, v in rows)
+        # the runtime's one-time clear of the workspace (pa_net_bind -> hipMemset -> __amd_rocclr_fillBufferAligned) is not part of a step
+        fill[C] = sum(v for _, k, v in rows if 'fillBuffer' in k)
+        tot[C] = sum(v for _, k, v in rows if 'fillBuffer' not in k)
         mf = [r for r in rows if any(k in r[1] for k in MFMA_KERNELS) and 'reduce' not in r[1]]
         if len(mf) < len(order):
             raise ValueError('fewer MFMA dispatches than the class sequence')
@@ -116,7 +118,8 @@ def parse_pmc_sequence(fetch_csv, write_csv, seq_path, steps):
     classes = {k: {'hbm_bytes_per_launch': (v['fetch_bytes'] + v['write_bytes']) / max(1, v['launches']),
                    'fetch_bytes_per_launch_x2': v['fetch_bytes'] / max(1, v['launches']),
                    'write_bytes_per_launch': v['write_bytes'] / max(1, v['launches']), 'launches_profiled': v['launches']} for k, v in out.items()}
-    return {'classes': classes, 'fetch_bytes_per_step_x2': tot['FETCH_SIZE'] / steps, 'write_bytes_per_step': tot['WRITE_SIZE'] / steps}
+    return {'classes': classes, 'fetch_bytes_per_step_x2': tot['FETCH_SIZE'] / steps, 'write_bytes_per_step': tot['WRITE_SIZE'] / steps,
+            'excluded_one_time_fill_bytes': fill['FETCH_SIZE'] + fill['WRITE_SIZE']}
 
 
 def _env():
