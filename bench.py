@@ -183,6 +183,9 @@ def cold_rate(dev, mb=(25, 50, 100, 400)):
     ts = sorted(timed(b[:n2], a[:n2], n2, False) for _ in range(5))
     forms['grid_stride_4_in_flight_256MB_warm'] = round(2.0 * n2 / ts[len(ts) // 2] / 1e12, 2)
     cold_rate.forms = forms
+    # the large-buffer rate of the floor = the best form's (round 6: the grid-stride form of rounds 4 - 5 reaches 4.3 - 4.6 TB/s on boxes where
+    # the one-chunk-per-thread form reaches 6.2, the guide's figure -- the 4.58 of round 5 was the probe's form, not the box)
+    large = max(large, forms['one_16B_chunk_per_thread'], forms['grid_stride_nontemporal'])
     sizes = sorted(k for k in out if k <= 100)
     return out[sizes[len(sizes) // 2]], {('%dMB' % k): round(v, 2) for k, v in out.items()}, large
 
@@ -209,7 +212,7 @@ def design_floor(net, opt, B, res, h, frame_hw=(720, 1280)):
             'algorithmic_bytes_per_step': round(380.5e6 * B) if res == 256 else None,
             'cold_rate_TBps': round(rate, 2), 'cold_rate_table_TBps': table, 'rate_large_TBps': round(large, 2),
             'rate_large_by_copy_form_TBps': getattr(cold_rate, 'forms', None),
-            'rate_large_note': 'rate_large_TBps = 1.6 GB device-to-device copy (read + written bytes) with pa_copy_probe form 0, median of 5, on this box at its own clocks; '
+            'rate_large_note': 'rate_large_TBps = 1.6 GB device-to-device copy (read + written bytes), median of 5, the BEST of pa_copy_probe\'s three forms on this box at its own clocks; '
                                'rate_large_by_copy_form_TBps lists the other forms of the same kernel (the guide\'s 6.29 TB/s is a float4 copy = form one_16B_chunk_per_thread) '
                                'and a 256 MB copy, which the 256 MB Infinity Cache partly serves',
             'floor_ms': round(total / (rate * 1e12) * 1e3, 3), 'floor_ms_at_large_rate': round(total / (large * 1e12) * 1e3, 3),

@@ -28,6 +28,9 @@ PA_STAMP_DECL(pa_conv1t_clk, pa_debug_conv1t_clocks)
 #endif
 
 #define PA_CONV1_K32_DEFAULT 1
+#ifndef PA_CONV1_UP_OCC
+#define PA_CONV1_UP_OCC(up) 3          // workgroups per CU of the 3-workgroup instances (the UP instance included)
+#endif
 #define PA_CONV1_C64_BM64_DEFAULT 1
 #define PA_GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 #define PA_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
@@ -36,8 +39,10 @@ PA_STAMP_DECL(pa_conv1t_clk, pa_debug_conv1t_clocks)
 // round 5 (KS = 32): its LDS is 32 KB of activations + 2 x 8 KB of ring (+ 4 KB table) = 52 KB and its registers <= 168, so that THREE
 // workgroups share a CU like the 128-channel instance's -- these kernels are chains of memory round trips (stage, slices, epilogue) and
 // what a CU moves is proportional to the chains it interleaves (128-channel instance: 5.4 TB/s hot, the two-workgroup 256-channel one 4.0)
-template <int CIN, int BM, int BN, int LDMODE, int KS = 64>
-__global__ __launch_bounds__(256, (((CIN == 128 || KS == 32) && BM == 64) || (CIN == 64 && (BN == 64 || BM == 64))) ? 3 : 2) void conv1x1_tile_kernel(PaConvArgs a, int nb_per_wg) {
+// UP (round 6; CIN = 128, BM = 64, BN = 128, LIN2): the workgroup's 64 rows are 2 IMAGE ROWS x 32 columns instead of 64 consecutive pixels, and
+// the epilogue is pa_conv_epilogue_lds_up: d(merged) plus the low-resolution half of the upsample-add backward (a.out2 / a.ep2)
+template <int CIN, int BM, int BN, int LDMODE, int KS = 64, bool UP = false>
+__global__ __launch_bounds__(256, (((CIN == 128 || KS == 32) && BM == 64) || (CIN == 64 && (BN == 64 || BM == 64))) ? PA_CONV1_UP_OCC(UP) : 2) void conv1x1_tile_kernel(PaConvArgs a, int nb_per_wg) {
     constexpr int CPP = CIN / 8;                     // 16-byte chunks per pixel row
     constexpr int NI = BN / 32, MI = BM / 32;
     constexpr int KT = CIN / KS;
@@ -63,6 +68,14 @@ __global__ __launch_bounds__(256, (((CIN == 128 || KS == 32) && BM == 64) || (CI
     const int nit = nb_per_wg * KT;
     PA_SET_MAIN_PRIO();
     PA_STAMPT(0);
+    // tile row -> flattened pixel: consecutive pixels, or (UP) row r of the tile = image row 2 * rp + r / 32, column cx * 32 + r % 32
+    // (B * H rows in one column: H is even, a row pair never straddles two images)
+    int up_rp = 0, up_cx = 0;
+    if constexpr (UP) { const int tpr = a.W / (BM / 2); up_rp = (int)blockIdx.x / tpr; up_cx = (int)blockIdx.x - up_rp * tpr; }
+    auto pixel_of_row = [&](int row) -> int {
+        if constexpr (UP) return (2 * up_rp + row / (BM / 2)) * a.W + up_cx * (BM / 2) + row % (BM / 2);
+        else return m0 + row;
+    };
 
     // ---- weight slices: iteration it -> n-block nb0 + it / KT, k-slice it % KT
     // slot swizzle of a slice row: 128-byte rows (KS = 64): 16-byte slot ^ (row & 7); 64-byte rows (KS = 32): slot ^ 3 * bit 3 of the row --
@@ -100,7 +113,7 @@ __global__ __launch_bounds__(256, (((CIN == 128 || KS == 32) && BM == 64) || (CI
             bf16x8 ra[UN], rq[UN];
 #pragma unroll
             for (int u = 0; u < UN; ++u) {
-                const int m = m0 + (p0 + u) * PSTEP + tid / CPP;
+                const int m = pixel_of_row((p0 + u) * PSTEP + tid / CPP);
                 const size_t idx = m < M ? (size_t)m * CIN + c : 0;        // clamped, unconditional loads
                 ra[u] = *reinterpret_cast<const bf16x8*>(a.in.p + idx);
                 if (LDMODE == PA_LD_LIN2) rq[u] = *reinterpret_cast<const bf16x8*>(a.in.q + idx);
@@ -120,14 +133,14 @@ __global__ __launch_bounds__(256, (((CIN == 128 || KS == 32) && BM == 64) || (CI
                     for (int j = 0; j < 8; ++j)
                         o[j] = (bf16)fmaf(k0[j], (float)ra[u][j], fmaf(k1[j], (float)rq[u][j], k2[j]));
                 }
-                if (m0 + row >= M) {
+                if (pixel_of_row(row) >= M) {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) o[j] = (bf16)0.f;
                 }
                 const int sw = CPP >= 16 ? (row & 15) : ((row >> 1) & 7);
                 *reinterpret_cast<bf16x8*>(As + row * CIN + ((chunk ^ sw) << 3)) = o;
-                if (LDMODE == PA_LD_LIN2 && a.dz_out && blockIdx.y == 0 && m0 + row < M)
-                    *reinterpret_cast<bf16x8*>(a.dz_out + (size_t)(m0 + row) * CIN + c) = o;
+                if (LDMODE == PA_LD_LIN2 && a.dz_out && blockIdx.y == 0 && pixel_of_row(row) < M)
+                    *reinterpret_cast<bf16x8*>(a.dz_out + (size_t)pixel_of_row(row) * CIN + c) = o;
             }
         }
     }
@@ -187,6 +200,11 @@ __global__ __launch_bounds__(256, (((CIN == 128 || KS == 32) && BM == 64) || (CI
         // BatchNorm-backward epilogue through LDS for 256 input channels (cold 70 vs 76 us) and for 64 (round 5: the 128 x 128 maps of
         // residual1, where the direct form's 64-byte runs are HALF a pixel row); the 128-channel kernels (3 workgroups per CU,
         // 168 registers) spill with the plain LDS form (98 vs 70 us) and take the table form (CTAB)
+        if constexpr (UP) {
+            pa_conv_epilogue_lds_up<BN, NI, MI>(a, acc, (nb0 + nbi) * BN, wm, wn, pixel_of_row,
+                                                [&](int x) { return up_rp * (a.W / 2) + up_cx * (BM / 4) + (x >> 1); },
+                                                T, (int)blockIdx.x, reinterpret_cast<float4*>(lds + BM * CIN + 2 * BN * KS));
+        } else
         pa_conv_epilogue_auto<BN, NI, MI, (CIN == 256 || CIN == 64 || CTAB), CTAB, 256, (BN < 128)>(a, acc, (nb0 + nbi) * BN, wm, wn,
                                          [&](int wr, int mi, int p) { const int m = m0 + wr * (BM / 2) + mi * 16 + p; return m < M ? m : -1; },
                                          T, (int)blockIdx.x, CTAB ? reinterpret_cast<float4*>(lds + BM * CIN + 2 * BN * KS) : nullptr);
@@ -217,6 +235,27 @@ static int row_bm(int Cin) {
     return (Cin == 256 || (Cin == 128 && !big)) ? 64 : 128;
 }
 
+// the UP instance: 128 -> 256 (any multiple of 128) channels, BatchNorm backward on load, one plain addend, plain output, maps whose rows are
+// multiples of 32 pixels with an even row count, enough tiles for the row-tile kernel
+bool pa_conv1x1_tile_up_supported(const PaConvArgs& a) {
+    if (!a.out2 || a.taps != 1 || a.Cin != 128 || a.Cout % 128 != 0 || a.in.mode != PA_LD_LIN2 || a.bias || a.dz_out || a.fin.rows > 0) return false;
+    if (a.add1.mode != PA_LD_PLAIN || a.add2.mode != PA_LD_NONE || a.ep.mode != PA_OUT_PLAIN || a.ep2.mode != PA_OUT_BWD) return false;
+    if (a.W % 32 != 0 || a.H % 2 != 0) return false;
+    const long M = (long)a.B * a.H * a.W;
+    if ((size_t)M * (size_t)a.Cout >= ((size_t)1 << 31)) return false;
+    return M / 64 >= 192;
+}
+
+static int launch_conv1x1_tile_up(const PaConvArgs& a, hipStream_t st, int* stat_rows) {
+    const int M = a.B * a.H * a.W, tiles = M / 64;
+    if (stat_rows) *stat_rows = tiles;
+    if (a.ep2.rows_out) *a.ep2.rows_out = tiles;
+    const int nb = a.Cout / 128;
+    const int nbw = tiles >= 512 ? nb : 1;
+    hipLaunchKernelGGL((conv1x1_tile_kernel<128, 64, 128, PA_LD_LIN2, 64, true>), dim3(tiles, nb / nbw), dim3(256), 0, st, a, nbw);
+    return (int)hipGetLastError();
+}
+
 bool pa_conv1x1_tile_supported(const PaConvArgs& a) {
     if (a.taps != 1 || (a.Cin != 64 && a.Cin != 128 && a.Cin != 256) || a.Cout % 64 != 0) return false;
     const int M = a.B * a.H * a.W;
@@ -227,6 +266,10 @@ bool pa_conv1x1_tile_supported(const PaConvArgs& a) {
 }
 
 int pa_launch_conv1x1_tile(const PaConvArgs& a, hipStream_t st, int* stat_rows) {
+    if (a.out2) {
+        if (!pa_conv1x1_tile_up_supported(a)) { pa_set_error_msg("pa_launch_conv1x1_tile: not a launch of the 2 x 32-pixel instance (pa_conv1x1_tile_up_supported)"); return 1; }
+        return launch_conv1x1_tile_up(a, st, stat_rows);
+    }
     if (!pa_conv1x1_tile_supported(a)) { pa_set_error_msg("pa_launch_conv1x1_tile: unsupported shape"); return 1; }
     const int M = a.B * a.H * a.W;
     int bm = row_bm(a.Cin);

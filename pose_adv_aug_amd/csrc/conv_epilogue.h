@@ -481,6 +481,85 @@ __device__ __forceinline__ void pa_conv_epilogue_lds_bwd(const PaConvArgs& a, f3
     }
 }
 
+// Plain epilogue (output = accumulators + ONE plain addend, stored bf16) of a tile that owns 2 image rows x 32 columns, PLUS the low-resolution
+// half of the upsample-add backward (elementwise.hip upadd_bwd_bb_kernel<LOW>): the 2 x 2 sums of the stored (bf16-rounded) output values, masked by
+// the ReLU of the low-resolution tensor they belong to (ep2: BatchNorm-backward mode), stored to out2, with that tensor's two per-channel
+// reductions as a partial row.  The main chain of the hourglass' backward pass then has no streaming kernel between this data gradient and the
+// low-resolution path (75 MB of traffic, 8 launches per step).
+//   256 threads, BN = 128: pass mi holds tile rows {mi*16 + p (image row 0), 32 + mi*16 + p (image row 1)}, p = 0..15; the reading thread
+//   (chunk = tid % 16, rsub = tid / 16) owns column x = mi*16 + rsub of BOTH image rows (sweeps 0 / 1) and finds the column's horizontal
+//   neighbour x ^ 1 in lane ^ 16 of its own wave.  Sum order = the streaming kernel's: ((top-left + top-right) + bottom-left) + bottom-right.
+//   pix(row) -> flattened pixel of tile row `row`; low(x) -> flattened low-resolution pixel of tile column x (even x)
+//   ctab: BN float4 of LDS outside T ({scale, shift} of ep2, entry j * 16 + chunk)
+template <int BN, int NI, int MI, class PixFn, class LowFn>
+__device__ __forceinline__ void pa_conv_epilogue_lds_up(const PaConvArgs& a, f32x4 (&acc)[NI][MI], int n0, int wm, int wn,
+                                                        PixFn pix, LowFn low, float* T, int stat_row, float4* ctab) {
+    static_assert(BN == 128 && MI == 2, "2 x 32-pixel tiles of the 128-channel row-tile kernel");
+    constexpr int CPR = BN / 8, NT = 256;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int N = a.Cout;
+    const int chunk = tid % CPR, rsub = tid / CPR;
+    const int n = n0 + chunk * 8;
+    float l1[8], l2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { l1[j] = 0.f; l2[j] = 0.f; }
+    for (int i = tid; i < BN; i += NT) ctab[(i & 7) * CPR + (i >> 3)] = make_float4(a.ep2.scale[n0 + i], a.ep2.shift[n0 + i], 0.f, 0.f);      // (visible after the first pass barrier)
+    const int wrow = wm * 16 + (lane & 15);
+    const int wslot0 = (wn * (BN / 2)) / 4 + 2 * (lane >> 4);
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        // ---- operands of the pass: the addend of both image rows, the low-resolution reference tensor
+        const int x = mi * 16 + rsub;
+        const unsigned i0 = (unsigned)pix(x) * (unsigned)N + (unsigned)n, i1 = (unsigned)pix(32 + x) * (unsigned)N + (unsigned)n;
+        const unsigned il = (unsigned)low(x & ~1) * (unsigned)N + (unsigned)n;
+        const bf16x8 p0 = *reinterpret_cast<const bf16x8*>(a.add1.p + i0), p1 = *reinterpret_cast<const bf16x8*>(a.add1.p + i1);
+        const bf16x8 xl = *reinterpret_cast<const bf16x8*>(a.ep2.xref + il);
+        if (mi) pa_lds_barrier();                    // the previous pass has been read
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+            *reinterpret_cast<f32x4*>(T + wrow * BN + (((wslot0 + 8 * (ni >> 1) + (ni & 1)) ^ (wrow & 7)) << 2)) = acc[ni][mi];
+        pa_lds_barrier();
+        float r0[8], r1[8];
+        {
+            const int ra = rsub, rb = 16 + rsub;
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(T + ra * BN + (((2 * chunk) ^ (ra & 7)) << 2));
+            const f32x4 a1 = *reinterpret_cast<const f32x4*>(T + ra * BN + (((2 * chunk + 1) ^ (ra & 7)) << 2));
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(T + rb * BN + (((2 * chunk) ^ (rb & 7)) << 2));
+            const f32x4 b1 = *reinterpret_cast<const f32x4*>(T + rb * BN + (((2 * chunk + 1) ^ (rb & 7)) << 2));
+            bf16x8 o0, o1;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                o0[j] = (bf16)((j < 4 ? a0[j & 3] : a1[j & 3]) + (float)p0[j]);
+                o1[j] = (bf16)((j < 4 ? b0[j & 3] : b1[j & 3]) + (float)p1[j]);
+                r0[j] = (float)o0[j]; r1[j] = (float)o1[j];
+            }
+            *reinterpret_cast<bf16x8*>(a.out + i0) = o0;
+            *reinterpret_cast<bf16x8*>(a.out + i1) = o1;
+        }
+        // ---- 2 x 2 sum with the neighbouring column (lane ^ 16), mask, store, reductions (even columns)
+        bf16x8 ol;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float q0 = __shfl_xor(r0[j], 16, 64), q1 = __shfl_xor(r1[j], 16, 64);
+            const float sum = ((r0[j] + q0) + r1[j]) + q1;
+            const float4 e = ctab[j * CPR + chunk];
+            const float xv = (float)xl[j];
+            const float dz = (fmaf(e.x, xv, e.y) > 0.f) ? sum : 0.f;
+            ol[j] = (bf16)dz;
+            if (!(rsub & 1)) { const float dzr = (float)ol[j]; l1[j] += dzr; l2[j] += dzr * xv; }
+        }
+        if (!(rsub & 1)) *reinterpret_cast<bf16x8*>(a.out2 + il) = ol;
+    }
+    float cm = 0.f, ci = 0.f;
+    if (tid < BN) { cm = a.ep2.mean[n0 + tid]; ci = a.ep2.invstd[n0 + tid]; }
+    pa_lds_barrier();                                // T is dead
+    const f32x2 t = pa_stats_reduce<BN, NT, false>(l1, l2, T);
+    if (tid < BN) {
+        f32x2 v = {t[0], ci * (t[1] - cm * t[0])};
+        *reinterpret_cast<f32x2*>(a.ep2.stats + ((size_t)stat_row * N + n0 + tid) * 2) = v;
+    }
+}
+
 // host side of the dispatch below: can the LDS variant of the BatchNorm-backward epilogue take this launch?
 __host__ __device__ inline bool pa_bwd_epilogue_lds_ok(const PaConvArgs& a) {
     return a.xcd < 2 && a.bias == nullptr && (a.add1.mode == PA_LD_NONE || a.add1.mode == PA_LD_PLAIN || a.add1.mode == PA_LD_LIN2) &&

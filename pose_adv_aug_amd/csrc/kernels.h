@@ -18,7 +18,14 @@ struct PaConvArgs {
     int low_prio;        // != 0: a launch of a side branch (skip blocks beside the main chain): the kernel keeps wave priority 0 instead of PA_MAIN_PRIO
     int dbg;             // tuning builds only (0 in the release library): conv3x3_tile.hip phase ablation bits 1 / 2 / 4, bit 8 = per-workgroup tap rotation
     int xcd;             // set by the launchers: workgroup i works on tile (i % 8) * (tiles / 8) + i / 8 (one contiguous range per XCD)
+    // round 6 -- the LOW half of the upsample-add backward (reference models/asn_stacked_hg.py:192-203) folded into the 1x1 data gradient that
+    // produces d(merged) (pa_conv1x1_tile_up_supported): besides `out` = d(merged) [B][H][W][Cout] the launch stores
+    // out2 [B][H/2][W/2][Cout] = ep2(sum of the 2x2 block of d(merged)) with ep2's BatchNorm-backward mask and its two partial reductions
+    PaEpilogue ep2;
+    bf16* out2;          // nullptr = off
 };
+// the row-tile instance whose workgroups own 2 image rows x 32 columns and carry the epilogue above
+bool pa_conv1x1_tile_up_supported(const PaConvArgs& a);
 // stat_rows (optional) receives the number of partial-statistics rows the launch writes (= grid.x)
 int pa_launch_conv(const PaConvArgs& a, hipStream_t st, int* stat_rows = nullptr);
 // will pa_launch_conv send this launch to a kernel that carries the finalize prologue (generic kernel, 3x3 tile kernel)?

@@ -99,6 +99,12 @@ struct Residual {
     void layout(Net& n, Arena& a, int B, int H, int W, bool need_grad);
     int fwd(Net& n, const Act& in);
     int bwd(Net& n, const Act& in, const PaOperand& extra, bool in_needs_grad);
+    // round 6: `in` is the upsample-add output merged[k] of an hourglass and low_of_in the low-resolution tensor up[k].x3 under it -- conv1's data
+    // gradient (which produces d merged) then also emits d up[k].x3 (2 x 2 sums, mask, reductions) where its tile kernel can
+    // (Net::conv_dgrad / pa_conv1x1_tile_up_supported); low_fused says whether it did
+    const Act* low_of_in = nullptr;
+    bool low_fused = false;
+    int b3_rows_scale = 1;   // partial-row capacity of bn3's backward reductions in units of this block's own map (4: the rows may come from a launch over the 2x larger map)
     int bwd_a(Net& n, const Act& in, const PaOperand* extra = nullptr);    // everything except the input gradient (extra: known already -- lets the adapter's data gradient start early)
     bool ad_forked = false;                                            // the adapter's data gradient of this backward pass runs on the side stream
     int bwd_b(Net& n, const Act& in, const PaOperand& extra);           // input gradient (needs `extra`)
@@ -109,12 +115,14 @@ struct Hourglass {
     Act pooled[4], merged[4];     // pool outputs p_k (k=1..4), upsample-add outputs o_k
     Act skipm[4], neckm;          // occlusion branch only: skip / neck outputs times the 4x4 cell mask (reference :79-100)
     bf16* poolgrad[4] = {nullptr, nullptr, nullptr, nullptr};   // gradient of the pool routed back to its input
+    bool low_done[4] = {false, false, false, false};             // d up[k].x3 of this backward pass came out of the data gradient that produced d merged[k]
     void declare(Net& n, const std::string& prefix, int chan);
     void layout(Net& n, Arena& a, int B, int H, int W, bool need_grad);
     int encode(Net& n, const Act& in);
     int decode(Net& n);
     int bwd(Net& n, const Act& in, const PaOperand& extra0);
     const Act& out() const { return merged[0]; }
+    bool low_fusable(const Net& n, int k) const;     // may the producer of d merged[k] also emit d up[k].x3 (the skip half then needs the one-output launch)
 };
 
 struct Net {
@@ -260,7 +268,8 @@ struct Net {
     int conv_fwd(ConvLayer& c, const PaOperand& in, int B, int H, int W, const PaOperand& add1, const PaOperand& add2,
                  bf16* out, BNLayer* bn_after, BNLayer* pending_in = nullptr, bool defer_after = false);
     int conv_dgrad(ConvLayer& c, const PaOperand& dy, int B, int H, int W, const PaOperand& add1, const PaOperand& add2,
-                   const PaEpilogue& ep, bf16* out, bf16* dz_out = nullptr, bool* dz_done = nullptr, BNLayer* pending_in = nullptr);
+                   const PaEpilogue& ep, bf16* out, bf16* dz_out = nullptr, bool* dz_done = nullptr, BNLayer* pending_in = nullptr,
+                   const Act* low = nullptr, bool* low_done = nullptr);      // low: also emit the upsample-add backward's low-resolution output (Residual::low_of_in)
     // BatchNorm finalize in the consumer's prologue for launches with at most this many partial rows (the 16 x 16 and smaller levels;
     // 0 = always a launch of its own).  Same bits either way (bn_fin.h)
     int fin_rows_max = PA_FIN_SMALL_ROWS;

@@ -19,6 +19,7 @@ static int ablate_h() { static int v = -1; if (v < 0) { const char* e = pa_geten
 #define PA_WG_GROUP_CAP_DEFAULT 256
 #define PA_WREDUCE_LAG_DEFAULT 2
 #define PA_UPADD_SPLIT_DEFAULT 1
+#define PA_UPADD_FUSE_DEFAULT 1
 #define PA_WG_RED_IN_GROUP_DEFAULT 1
 #define TRY(x) do { int _r = (x); if (_r) return _r; } while (0)
 
@@ -168,7 +169,7 @@ Act Net::new_act(Arena& a, int B_, int H, int W, int C, BNLayer* bn, bool need_g
 void Residual::layout(Net& n, Arena& a, int B, int H, int W, bool need_grad) {
     const int M = B * H * W, mid = cout / 2;
     n.layout_conv(c1, a, M, H, W); n.layout_conv(c2, a, M, H, W); n.layout_conv(c3, a, M, H, W);      // explicit map size: the split counts depend on it
-    n.layout_bn(b1, a, M); n.layout_bn(b2, a, M); n.layout_bn(b3, a, M);
+    n.layout_bn(b1, a, M); n.layout_bn(b2, a, M); n.layout_bn(b3, a, M * b3_rows_scale);
     x1 = n.new_act(a, B, H, W, mid, &b1, need_grad);
     x2 = n.new_act(a, B, H, W, mid, &b2, need_grad);
     x3 = n.new_act(a, B, H, W, cout, &b3, need_grad);
@@ -191,6 +192,7 @@ void Hourglass::layout(Net& n, Arena& a, int B, int H, int W, bool need_grad) {
     }
     neck.layout(n, a, B, H >> 4, W >> 4, need_grad);
     for (int k = 3; k >= 0; --k) {
+        up[k].b3_rows_scale = 4;          // (its backward reductions can come from the data gradient over merged[k], 4 x the pixels: Residual::low_of_in)
         up[k].layout(n, a, B, H >> (k + 1), W >> (k + 1), need_grad);
         merged[k] = n.new_act(a, B, H >> k, W >> k, C, nullptr, need_grad);
     }
@@ -437,8 +439,9 @@ int Net::conv_fwd(ConvLayer& c, const PaOperand& in, int B_, int H, int W, const
 }
 
 int Net::conv_dgrad(ConvLayer& c, const PaOperand& dy, int B_, int H, int W, const PaOperand& add1, const PaOperand& add2,
-                    const PaEpilogue& ep, bf16* out, bf16* dz_out, bool* dz_done, BNLayer* pending_in) {
+                    const PaEpilogue& ep, bf16* out, bf16* dz_out, bool* dz_done, BNLayer* pending_in, const Act* low, bool* low_done) {
     PaConvArgs a; memset(&a, 0, sizeof a);
+    if (low_done) *low_done = false;
     if (pending_in && pending_in->bfin_pending) { a.fin = fin_bwd(*pending_in, B_ * H * W); pending_in->bfin_pending = false; }
     a.in = dy; a.w = c.wb; a.bias = nullptr; a.add1 = add1; a.add2 = add2; a.out = out; a.ep = ep; a.low_prio = on_side ? 1 : 0;
     a.B = B_; a.H = H; a.W = W; a.Cin = c.pcout; a.Cout = c.pcin; a.taps = c.taps();
@@ -453,10 +456,20 @@ int Net::conv_dgrad(ConvLayer& c, const PaOperand& dy, int B_, int H, int W, con
     double wb, wf; conv_work(B_ * H * W, c.Cin, c.Cout, c.taps(), false, wb, wf);
     ProfEntry* pe = prof.begin((long)B_ * H * W < PA_PROF_LOW_M ? PA_PROF_LOW_DGRAD : (c.k == 3 ? PA_PROF_DGRAD3 : PA_PROF_DGRAD1), wb, wf, st);
     if ((c.k == 3 && (ablate() & 8)) || (c.k == 1 && (ablate() & 16)) || ((ablate() & 256) && H <= ablate_h())) { if (a.ep.rows_out) *a.ep.rows_out = 1; prof.end(pe, st); return 0; }
+    // the low-resolution half of the upsample-add backward in this launch's epilogue (round 6)
+    static int up_fuse = -1;
+    if (up_fuse < 0) { const char* e = pa_getenv("PA_UPADD_FUSE"); up_fuse = e ? atoi(e) : PA_UPADD_FUSE_DEFAULT; }
+    bool up = false;
+    if (low && up_fuse && low->bn && !drop_mask && !(ablate() & 1024)) {
+        a.out2 = low->grad; a.ep2 = final_ep(*low);
+        if (pa_conv1x1_tile_up_supported(a)) up = true; else { a.out2 = nullptr; memset(&a.ep2, 0, sizeof a.ep2); }
+    }
     { const double M = (double)B_ * H * W;
-      cnt(opb(dy, M * a.Cin) + opb(add1, M * a.Cout) + opb(add2, M * a.Cout) + (ep.mode == PA_OUT_BWD ? 2.0 * M * a.Cout : 0.0) + 2.0 * a.Cout * a.taps * a.Cin,
-          2.0 * M * a.Cout + (a.dz_out ? 2.0 * M * a.Cin : 0.0)); }
-    int rc = pa_launch_conv(a, st);
+      cnt(opb(dy, M * a.Cin) + opb(add1, M * a.Cout) + opb(add2, M * a.Cout) + (ep.mode == PA_OUT_BWD ? 2.0 * M * a.Cout : 0.0) + 2.0 * a.Cout * a.taps * a.Cin
+              + (up ? 2.0 * M * a.Cout / 4 : 0.0),
+          2.0 * M * a.Cout + (a.dz_out ? 2.0 * M * a.Cin : 0.0) + (up ? 2.0 * M * a.Cout / 4 : 0.0)); }
+    int rc = up ? pa_launch_conv1x1_tile(a, st) : pa_launch_conv(a, st);
+    if (up && low_done) *low_done = true;
     prof.end(pe, st);
     return rc;
 }
@@ -700,6 +713,7 @@ int Residual::fwd(Net& n, const Act& in) {
 // part that needs `extra`, the gradient arriving at the input from its other consumers)
 int Residual::bwd_a(Net& n, const Act& in, const PaOperand* extra) {
     const int B = in.B, H = in.H, W = in.W;
+    low_fused = false;
     // conv3's data gradient goes first: its kernel also stores dz3 = BatchNorm-backward(x3.grad, x3.raw), and the weight
     // gradients / the shortcut addend after it read that one tensor instead of recomputing it from two
     // (x3.bn: its finalize may be pending -- then this launch does it in its prologue, Net::x3_fin_ok)
@@ -743,7 +757,7 @@ int Residual::bwd_b(Net& n, const Act& in, const PaOperand& extra) {
         else TRY(n.conv_dgrad(ad, g3, B, H, W, extra, pa_none(), ep_plain(), adgrad));
         TRY(n.conv_dgrad(c1, g1, B, H, W, pa_plain(adgrad), pa_none(), n.final_ep(in), in.grad));
     } else {
-        TRY(n.conv_dgrad(c1, g1, B, H, W, g3, extra, n.final_ep(in), in.grad));
+        TRY(n.conv_dgrad(c1, g1, B, H, W, g3, extra, n.final_ep(in), in.grad, nullptr, nullptr, nullptr, low_of_in, &low_fused));
     }
     return 0;
 }
@@ -797,6 +811,12 @@ int Hourglass::decode(Net& n) {
     return 0;
 }
 
+bool Hourglass::low_fusable(const Net& n, int k) const {
+    if (n.drop_mask || k < 0 || k > 3) return false;
+    const Act& m = merged[k];
+    return pa_upadd_bwd_splits(n.final_ep(up[k].x3), n.final_ep(skip[k].x3), m.B, m.H, m.W, m.C);
+}
+
 // precondition: merged[0].grad holds the finished (plain) gradient of the hourglass output.
 // extra0: gradient reaching the hourglass INPUT from consumers outside the hourglass.
 int Hourglass::bwd(Net& n, const Act& in, const PaOperand& extra0) {
@@ -819,17 +839,21 @@ int Hourglass::bwd(Net& n, const Act& in, const PaOperand& extra0) {
                 TRY(skip[k].bwd_a(n, x));
             }
             TRY(n.record_join(k));
-            TRY(c_upadd_bwd(n, m.grad, n.final_ep(up[k].x3), up[k].x3.grad, n.final_ep(skip[k].x3), skip[k].x3.grad, m.B, m.H, m.W, m.C, n.st, nullptr, 1));
+            // (d up[k].x3 may have come out of the data gradient that produced d merged[k]: low_done)
+            if (!low_done[k]) TRY(c_upadd_bwd(n, m.grad, n.final_ep(up[k].x3), up[k].x3.grad, n.final_ep(skip[k].x3), skip[k].x3.grad, m.B, m.H, m.W, m.C, n.st, nullptr, 1));
             TRY(n.finish_grad_or_defer(up[k].x3, n.x3_fin_ok(up[k], upin_)));
+            up[k].low_of_in = low_fusable(n, k + 1) ? &up[k + 1].x3 : nullptr;
             TRY(up[k].bwd(n, upin_, pa_none(), true));
+            if (k < 3) low_done[k + 1] = up[k].low_fused;
             continue;
         }
         if (n.drop_mask) {              // the skip tensor entered the sum through the cell mask: d skip = mask * d (masked skip)
             TRY(c_upadd_bwd(n, m.grad, n.final_ep(up[k].x3), up[k].x3.grad, ep_plain(), skipm[k].grad, m.B, m.H, m.W, m.C, n.st));
             TRY(pa_launch_cell_mask(pa_plain(skipm[k].grad), n.drop_mask, n.final_ep(skip[k].x3), skip[k].x3.grad, m.B, m.H, m.W, m.C, n.st));
         } else {
+            // (low_done: only d skip is left -- the launch that can do one half exists wherever the fused data gradient does)
             TRY(c_upadd_bwd(n, m.grad, n.final_ep(up[k].x3), up[k].x3.grad, n.final_ep(skip[k].x3), skip[k].x3.grad,
-                                    m.B, m.H, m.W, m.C, n.st));
+                                    m.B, m.H, m.W, m.C, n.st, nullptr, low_done[k] ? 2 : 3));
         }
         {
             const Act& upin_ = (k == 3) ? (n.drop_mask ? neckm : neck.x3) : merged[k + 1];
@@ -843,7 +867,9 @@ int Hourglass::bwd(Net& n, const Act& in, const PaOperand& extra0) {
             TRY(n.record_join(k));
         }
         const Act& upin = (k == 3) ? (n.drop_mask ? neckm : neck.x3) : merged[k + 1];
+        up[k].low_of_in = low_fusable(n, k + 1) ? &up[k + 1].x3 : nullptr;
         TRY(up[k].bwd(n, upin, pa_none(), true));
+        if (k < 3) low_done[k + 1] = up[k].low_fused;
     }
     if (n.drop_mask) {
         const Act& x = neck.x3;
@@ -1051,7 +1077,9 @@ int Net::backward_stack(int i) {
     if (gl_stored) gl = pa_plain(lgrad_tmp[i]);
     TRY(conv_wgrad(lin[i], gl, op(post[i].x3), B, Hh, Hh));
     TRY(finish_grad(post[i].x3));
+    post[i].low_of_in = hg[i].low_fusable(*this, 0) ? &hg[i].up[0].x3 : nullptr;          // (post_res reads merged[0]: its conv1 data gradient can emit d up1 too)
     TRY(post[i].bwd(*this, hg[i].out(), pa_none(), true));
+    hg[i].low_done[0] = post[i].low_fused;
     TRY(hg[i].bwd(*this, xin[i], inner ? pa_plain(xin[i + 1].grad) : pa_none()));
     return 0;
 }
