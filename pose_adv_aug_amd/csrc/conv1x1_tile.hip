@@ -68,6 +68,13 @@ __global__ __launch_bounds__(256, (((CIN == 128 || KS == 32) && BM == 64) || (CI
     const int nit = nb_per_wg * KT;
     PA_SET_MAIN_PRIO();
     PA_STAMPT(0);
+#ifdef PA_TUNING
+    // a.dbg >> 16 (tuning builds): stagger -- workgroups of the 2nd / 3rd slot of a CU start 1x / 2x (dbg >> 16) x 1024 cycles late
+    if ((a.dbg >> 16) > 0 && gridDim.x > 256) {
+        const int slot = ((int)blockIdx.x / 256) % 3;
+        for (int i = 0; i < slot * (a.dbg >> 16); ++i) __builtin_amdgcn_s_sleep(16);
+    }
+#endif
     // tile row -> flattened pixel: consecutive pixels, or (UP) row r of the tile = image row 2 * rp + r / 32, column cx * 32 + r % 32
     // (B * H rows in one column: H is even, a row pair never straddles two images)
     int up_rp = 0, up_cx = 0;

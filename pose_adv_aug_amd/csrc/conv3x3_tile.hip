@@ -78,6 +78,12 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? 1 : (TW == 16 ? (TH == 4 ? (SPS ==
 #else
     constexpr int dbg = 0;
 #endif
+#ifdef PA_TUNING
+    // a.dbg bits 8.. (tuning builds): stagger -- the workgroups of the SECOND slot of every CU (dispatch order: workgroup 256 .. 511 of a launch that
+    // fills 256 CUs twice) start (dbg >> 8) x 64 x 16 cycles late, so that co-resident workgroups are not in the same phase (staging / K loop / epilogue)
+    if ((a.dbg >> 8) > 0 && gridDim.x * gridDim.y > 256 && ((blockIdx.x + blockIdx.y * gridDim.x) / 256) % 2 == 1)
+        for (int i = 0; i < (a.dbg >> 8); ++i) __builtin_amdgcn_s_sleep(16);
+#endif
     constexpr int NW = NT / 64, WM = NW / 2;                             // waves; waves along the pixels (2 along the channels)
     constexpr int BM = TRI ? 384 : ((TW == 16 && TH == 4) ? 64 : 128);
     constexpr int IMG = BM / (TW * TH), PW = TW + 2, PHh = TH + 2, HP = IMG * PHh * PW;   // 180 / 108 / 200 / 288 / 540 halo pixels
