@@ -111,7 +111,7 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? 1 : (TW == 16 ? (TH == 4 ? (SPS ==
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave % WM, wn = wave / WM;
-    const int tiles_x = a.W / TW, tiles_y = a.H / TH;
+    const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH;      // (ragged only for the small tiles: maps up to 8 x 8 that are not 8 x 8 / 4 x 4)
     // consecutive workgroups go to different XCDs (round robin), each with its own L2: give every XCD one contiguous range
     // of tiles so that the halo rows / columns shared by neighbouring tiles are found in that L2
     int t = (a.xcd & 1) ? (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
@@ -139,6 +139,16 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? 1 : (TW == 16 ? (TH == 4 ? (SPS ==
             bb = im == 0 ? ob[0] : (im == 1 ? ob[1] : ob[2]);
             yy = im == 0 ? oy[0] : (im == 1 ? oy[1] : oy[2]);
             xx = im == 0 ? ox[0] : (im == 1 ? ox[1] : ox[2]);
+        } else if constexpr (IMG > 1) {
+            // small tiles (8 x 8 / 4 x 4): the tile IS the image (8 x 8 / 4 x 4 maps) -- or, round 6, sub-tile t0 + im of the tile grid of a map
+            // whose sides are multiples of the tile (24 x 24, 12 x 12 of the 384 x 384 configuration); a workgroup's sub-tiles may lie in two images
+            if (tiles_x * tiles_y == 1) { bb = b + im; yy = 0; xx = 0; }
+            else {
+                int tt = t0 + im;
+                xx = (tt % tiles_x) * TW; tt /= tiles_x;
+                yy = (tt % tiles_y) * TH;
+                bb = tt / tiles_y;
+            }
         } else { bb = b + im; yy = y0; xx = x0; }
     };
 
@@ -411,7 +421,7 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? 1 : (TW == 16 ? (TH == 4 ? (SPS ==
                                          const int im = l / (TW * TH), r = l - im * (TW * TH);
                                          int bb, yy, xx;
                                          origin(im, bb, yy, xx);
-                                         return bb < a.B ? (bb * a.H + yy + r / TW) * a.W + xx + r % TW : -1;
+                                         return (bb < a.B && yy + r / TW < a.H && xx + r % TW < a.W) ? (bb * a.H + yy + r / TW) * a.W + xx + r % TW : -1;
                                      },
                                      reinterpret_cast<float*>(lds), (int)blockIdx.x);
     PA_STAMP(5);
@@ -489,7 +499,10 @@ bool pa_conv3x3_tile_takes_fin(const PaConvArgs& a) {
     return a.Cout % 128 != 0;                                                  // 64 input channels: the 16 x 8 <64, 64> instance
 }
 
-static bool small_map(const PaConvArgs& a) { return (a.H == 8 && a.W == 8) || (a.H == 4 && a.W == 4); }
+// maps tiled by the 8 x 8 / 4 x 4 variants: sides multiples of 8 (that the 16 x 8 tiles do not take: W % 16 != 0) or of 4
+// (any map up to 8 x 8 -- the 6 x 6 necks of the 384 x 384 configuration -- is ONE 8 x 8 tile whose pixels outside the map are masked)
+static int small_tile(const PaConvArgs& a) { return (a.H % 8 == 0 && a.W % 8 == 0) ? 8 : ((a.H % 4 == 0 && a.W % 4 == 0) ? 4 : ((a.H <= 8 && a.W <= 8) ? 8 : 0)); }
+static bool small_map(const PaConvArgs& a) { return small_tile(a) != 0; }
 
 bool pa_conv3x3_tile_supported(const PaConvArgs& a) {
     static int nosmall = -1;
@@ -502,14 +515,15 @@ bool pa_conv3x3_tile_supported(const PaConvArgs& a) {
 int pa_launch_conv3x3_tile(const PaConvArgs& a, hipStream_t st, int* stat_rows) {
     if (!pa_conv3x3_tile_supported(a)) { pa_set_error_msg("pa_launch_conv3x3_tile: unsupported shape"); return 1; }
     const bool small = !(a.H % 8 == 0 && a.W % 16 == 0);
-    const int img = small ? 128 / (a.H * a.W) : 1;
+    const int st_ = small ? small_tile(a) : 0;                      // side of the small tile
+    const int img = small ? 128 / (st_ * st_) : 1;                  // sub-tiles per workgroup
     // 16 x 4 pixel tiles (3 workgroups per CU) where 16 x 8 tiles would leave CUs idle: measured 64x64 maps (768 tiles)
     // 39.8 vs 42.8 us in favour of 16 x 8, 32x32 maps (192 tiles) 17.6 vs 14.6 us in favour of 16 x 4
     static int bm64 = -1;
     if (bm64 < 0) { const char* e = pa_getenv("PA_CONV3_BM64"); bm64 = e ? atoi(e) : -2; }
     const int tiles128 = small ? 0 : a.B * (a.H / 8) * (a.W / 16);
     const bool half = !small && a.Cin == 128 && (bm64 == -2 ? tiles128 < 512 : bm64 != 0);
-    const int tiles = small ? (a.B + img - 1) / img : a.B * (a.H / (half ? 4 : 8)) * (a.W / 16);
+    const int tiles = small ? (a.B * ((a.H + st_ - 1) / st_) * ((a.W + st_ - 1) / st_) + img - 1) / img : a.B * (a.H / (half ? 4 : 8)) * (a.W / 16);
     if (stat_rows) *stat_rows = tiles;
     if (a.ep.rows_out) *a.ep.rows_out = tiles;
     static int n64 = -1;
@@ -556,7 +570,7 @@ int pa_launch_conv3x3_tile(const PaConvArgs& a, hipStream_t st, int* stat_rows) 
 #endif
     if (half) { if (sps) launch_tile_shape<16, 4, 2>(b, grid, bigN, st); else launch_tile_shape<16, 4, 1>(b, grid, bigN, st); }
     else if (!small) launch_tile_shape<16, 8, 1>(b, grid, bigN, st);
-    else if (a.H == 8) { if (sps) launch_tile_shape<8, 8, 4>(b, grid, bigN, st); else launch_tile_shape<8, 8, 1>(b, grid, bigN, st); }
+    else if (st_ == 8) { if (sps) launch_tile_shape<8, 8, 4>(b, grid, bigN, st); else launch_tile_shape<8, 8, 1>(b, grid, bigN, st); }
     else { if (sps) launch_tile_shape<4, 4, 4>(b, grid, bigN, st); else launch_tile_shape<4, 4, 1>(b, grid, bigN, st); }
     return (int)hipGetLastError();
 }

@@ -616,7 +616,8 @@ static inline void fit_threads_to_rows(int& threads, int W, int C) {
     const size_t row_items = (size_t)(W / 2) * (C / 8);
     auto fit = [&](int t) { return t % (C / 8) == 0 && (row_items % t == 0 || t % row_items == 0); };
     if (fit(threads)) return;
-    if (fit(512)) threads = 512; else if (fit(256)) threads = 256;
+    // (384 / 192 / 128: the 24 x 24 and 12 x 12 maps of the 384 x 384 configuration -- 12 / 6 low-resolution pixels x 32 channel groups per row)
+    for (int t : {512, 256, 384, 192, 128}) if (fit(t)) { threads = t; return; }
 }
 
 int pa_launch_maxpool_bwd(const bf16* dout, const PaOperand& in, const PaOperand& add, const PaEpilogue& ep, bf16* din,

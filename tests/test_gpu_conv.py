@@ -66,6 +66,16 @@ SHAPES = [
     (3, 128, 128, 8, 8, 3),
     (5, 64, 128, 4, 4, 3),
     (24, 128, 128, 4, 4, 3),
+    # round 6: maps TILED by the 8 x 8 / 4 x 4 variants (sides multiples of 8 or 4 that the 16 x 8 tiles do not take): the 24 x 24 and 12 x 12
+    # levels of BASELINE configs[4] (384 x 384 input); sub-tiles of one workgroup in two images, ragged last workgroup
+    (5, 128, 128, 24, 24, 3),
+    (16, 128, 128, 24, 24, 3),
+    (3, 64, 128, 12, 12, 3),
+    (16, 128, 128, 12, 12, 3),
+    (2, 128, 64, 8, 24, 3),
+    # ... and maps up to 8 x 8 that are neither 8 x 8 nor 4 x 4 (the 6 x 6 necks of configs[4]): one masked 8 x 8 tile per image
+    (16, 128, 128, 6, 6, 3),
+    (3, 64, 64, 5, 7, 3),
 ]
 
 
