@@ -45,6 +45,11 @@ SHAPES = [
     (3, 64, 64, 6, 10, 3),       # ragged M, non-square
     (24, 128, 256, 64, 64, 1),   # full-size expand conv: M = 98304 -> 128x128 tiles
     (24, 128, 128, 64, 64, 3),   # full-size 3x3 (BASELINE config 2 shape)
+    # round 6: the persistent kernel with LDS-resident weights (conv1x1_ws.hip: >= 4 row tiles of 64 per CU) -- with the shape above
+    # (128 -> 256 forward, 256 -> 128 data gradient) every instance: 256 -> 128 / 128 -> 256 / 128 -> 128, ragged tile count per workgroup
+    (24, 256, 128, 64, 64, 1),
+    (24, 128, 128, 64, 64, 1),
+    (17, 256, 128, 64, 64, 1),   # 1088 tiles on 256 workgroups: 4.25 tiles each
     # shapes that select the tile kernels (conv3x3_tile.hip: H % 8 == 0, W % 16 == 0; conv_wgrad_tile.hip: >= 48 / 96 tiles)
     (6, 128, 128, 32, 32, 3),    # 48 halo tiles, 128 channels
     (8, 64, 128, 32, 48, 3),     # non-square, Cin != Cout, 96 tiles
