@@ -12,6 +12,10 @@
 #define PA_SET_ELT_PRIO() do { if (PA_ELT_PRIO > 0) __builtin_amdgcn_s_setprio(PA_ELT_PRIO); } while (0)
 #include "bn_fin.h"
 #include <type_traits>
+#include <hip/hip_ext.h>
+// TIMING EXPERIMENT (tuning builds, PA_FIN_ANYORDER=1; results may be WRONG): the finalize launches without the completion / cache round trip
+// behind their producer (hipExtAnyOrderLaunch) -- what a tagged-row hand-off from the producers to the finalize kernel could return at most
+static unsigned fin_launch_flags() { static int v = -1; if (v < 0) { const char* e = pa_getenv("PA_FIN_ANYORDER"); v = e ? atoi(e) : 0; } return v ? hipExtAnyOrderLaunch : 0u; }
 
 // ------------------------------------------------------------------------------------------------
 // BatchNorm bookkeeping (reference semantics: torch.nn.BatchNorm2d, eps 1e-5, momentum 0.1,
@@ -145,8 +149,12 @@ int pa_launch_bn_finalize(const float* stats, int rows, const float* gamma, cons
     if (C & 1) { pa_set_error_msg("BatchNorm finalize: the statistics rows are read as 16-byte channel pairs -- C must be even (the networks pad to 64)"); return 1; }
     fin_dispatch([&](auto ft, auto fc) {
         constexpr int FT = decltype(ft)::value, FC = decltype(fc)::value;
-        hipLaunchKernelGGL((bn_finalize_kernel<FT, FC>), dim3((C + FC - 1) / FC), dim3(FT), 0, st, stats, rows, gamma, beta, rmean, rvar, scale,
-                           shift, mean, invstd, C, count, momentum, eps, update_running);
+        if (fin_launch_flags())
+            hipExtLaunchKernelGGL((bn_finalize_kernel<FT, FC>), dim3((C + FC - 1) / FC), dim3(FT), 0, st, nullptr, nullptr, fin_launch_flags(), stats, rows, gamma, beta, rmean, rvar, scale,
+                                  shift, mean, invstd, C, count, momentum, eps, update_running);
+        else
+            hipLaunchKernelGGL((bn_finalize_kernel<FT, FC>), dim3((C + FC - 1) / FC), dim3(FT), 0, st, stats, rows, gamma, beta, rmean, rvar, scale,
+                               shift, mean, invstd, C, count, momentum, eps, update_running);
     });
     return (int)hipGetLastError();
 }
@@ -221,7 +229,8 @@ int pa_launch_bn_bwd_finalize2(const float* bs0, int rows0, const float* sc0, co
     const int cm = C0 > C1 ? C0 : C1;
     fin_dispatch([&](auto ft, auto fc) {
         constexpr int FT = decltype(ft)::value, FC = decltype(fc)::value;
-        hipLaunchKernelGGL((bn_bwd_finalize2_kernel<FT, FC>), dim3((cm + FC - 1) / FC, 2), dim3(FT), 0, st, a0, a1);
+        if (fin_launch_flags()) hipExtLaunchKernelGGL((bn_bwd_finalize2_kernel<FT, FC>), dim3((cm + FC - 1) / FC, 2), dim3(FT), 0, st, nullptr, nullptr, fin_launch_flags(), a0, a1);
+        else hipLaunchKernelGGL((bn_bwd_finalize2_kernel<FT, FC>), dim3((cm + FC - 1) / FC, 2), dim3(FT), 0, st, a0, a1);
     });
     return (int)hipGetLastError();
 }
@@ -232,8 +241,13 @@ int pa_launch_bn_bwd_finalize(const float* bstats, int rows, const float* scale,
     if (C & 1) { pa_set_error_msg("BatchNorm finalize: the statistics rows are read as 16-byte channel pairs -- C must be even (the networks pad to 64)"); return 1; }
     fin_dispatch([&](auto ft, auto fc) {
         constexpr int FT = decltype(ft)::value, FC = decltype(fc)::value;
-        hipLaunchKernelGGL((bn_bwd_finalize_kernel<FT, FC>), dim3((C + FC - 1) / FC), dim3(FT), 0, st, bstats, rows, scale, mean, invstd, kA, kB,
+        if (fin_launch_flags()) {
+            hipExtLaunchKernelGGL((bn_bwd_finalize_kernel<FT, FC>), dim3((C + FC - 1) / FC), dim3(FT), 0, st, nullptr, nullptr, fin_launch_flags(), bstats, rows, scale, mean, invstd, kA, kB,
                            kC, dgamma, dbeta, C, count);
+        } else {
+            hipLaunchKernelGGL((bn_bwd_finalize_kernel<FT, FC>), dim3((C + FC - 1) / FC), dim3(FT), 0, st, bstats, rows, scale, mean, invstd, kA, kB,
+                           kC, dgamma, dbeta, C, count);
+        }
     });
     return (int)hipGetLastError();
 }
