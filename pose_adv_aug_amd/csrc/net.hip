@@ -577,7 +577,7 @@ int Net::flush_wgrads() {
             // the slabs of EARLIER flushes (the stash) are summed by a few more workgroups of this launch instead of by a launch of their own
             static int red_in_group = -1;
             if (red_in_group < 0) { const char* e = pa_getenv("PA_WG_RED_IN_GROUP"); red_in_group = e ? atoi(e) : PA_WG_RED_IN_GROUP_DEFAULT; }
-            const bool carry = red_in_group && ms && reduce_early && !(ablate() & 1) && !red_stash.empty();
+            const bool carry = red_in_group && ms && n_w == 1 && reduce_early && !(ablate() & 1) && !red_stash.empty();      // (one weight-gradient stream: the stash's slabs were written on THIS stream)
             const int rc = (nj == 1 && !carry) ? pa_launch_wgrad(*jobs[0], ws)
                                                : pa_launch_wgrad_group(jobs, nj, ws, false, red_jobs, carry ? red_stash.data() : nullptr, carry ? (int)red_stash.size() : 0);
             if (carry && !rc) { red_stash.clear(); red_stash_mx = 0; red_stash_flushes = 0; }
