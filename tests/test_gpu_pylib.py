@@ -249,3 +249,21 @@ def test_metric_edge_cases_against_oracle(P):
     pts = np.zeros((1, 16, 2)); pts[0, :6] = [[64.0, 64.0], [64.001, 10.0], [1e-9, 1e-9], [0.0, 5.0], [63.999, 0.001], [32.5, 64.0]]
     hm = P.HumanPts.pts2heatmap_batch(torch.from_numpy(pts).cuda(), 64, 64).cpu().numpy()
     assert np.array_equal(hm[0], inputs.heatmaps_from_pts(pts, 64)[0])
+
+
+def test_params_csr_and_the_copy_probe_forms():
+    """pa_params_csr: the fp32 c / s / r the metric calls take = the float64 parameter block rounded once (what `.float()` of its columns gave
+    through three framework kernels until round 6); pa_copy_probe_form: every form of the calibration copy moves the bytes."""
+    from pose_adv_aug_amd._lib import lib, check, ptr, stream
+    g = inputs.rng(77)
+    B = 24
+    params = torch.from_numpy(g.uniform(-300, 1300, size=(B, 8))).cuda()
+    csr = torch.full((4 * B,), float('nan'), device='cuda')
+    check(lib().pa_params_csr(ptr(params), B, ptr(csr), stream()), 'pa_params_csr')
+    assert torch.equal(csr[:2 * B].view(B, 2), params[:, 0:2].float())
+    assert torch.equal(csr[2 * B:3 * B], params[:, 2].float()) and torch.equal(csr[3 * B:], params[:, 3].float())
+    src = torch.randint(0, 255, (3 * 1024 * 1024 + 16,), dtype=torch.uint8, device='cuda')
+    for form in (0, 1, 2):
+        dst = torch.zeros_like(src)
+        check(lib().pa_copy_probe_form(ptr(dst), ptr(src), src.numel(), form, stream()), 'pa_copy_probe_form')
+        assert torch.equal(dst, src), form
