@@ -1,5 +1,5 @@
 #!/bin/bash
-# Same-box, interleaved comparison of the round-4 tree (ab_base/, a built copy of commit ab_base/BASE_COMMIT: see tools/ab_r3.sh for the
+# Same-box, interleaved comparison of the PREVIOUS round's tree (ab_base/, a built copy of commit ab_base/BASE_COMMIT -- round 5: the round-4 tree, round 6: the round-5 tree; see tools/ab_r3.sh for the
 # recipe) with the current one.   gpurun -- 'bash tools/ab_r5.sh [pairs] > gpurun_out/ab_r5.txt 2>&1'
 PAIRS=${1:-3}
 cd /tmp && export TMPDIR=/tmp
